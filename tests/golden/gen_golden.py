@@ -1,0 +1,374 @@
+"""
+Golden-vector generator.  Runs ONLY in the build container (needs /root/reference); the fixtures it
+writes (tests/golden/*.npz) are committed and are what travels to the GPU box.
+
+It imports the reference's own modules read-only (no reference source is copied into this repo) with the three
+shims of SURVEY.md §8(c): (1) transformers-5.x config normalisation (`rope_scaling=None`, `rope_theta`),
+(2) `SpecModel.__new__` constructor bypass (no tokenizer / hub access), (3) pre-seeded CPU KVCache so
+`specgenerate` never reaches the CUDA assert.  Weights are NOT stored: they are re-created bit-identically from
+numpy PCG64 seeds by vispec_amd/synth.py; only inputs that are not seed-derived and the reference's outputs are saved.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+from transformers import LlamaConfig  # noqa: E402
+from vispec.model import cnets_ours, modeling_llama_kv, utils  # noqa: E402
+from vispec.model.configs import EConfig  # noqa: E402
+from vispec.model.kv_cache import KVCache  # noqa: E402
+from vispec.model.spec_model_ours import SpecModel  # noqa: E402
+
+from vispec_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+T = synth.TINY
+torch.set_grad_enabled(False)
+torch.set_num_threads(4)
+
+
+def t(x, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
+
+
+def build_draft(num_q=2, seed=1, structured=False, target_embed=None, dtype=torch.float32, rho=0.115):
+    ec = EConfig(vocab_size=T["V"], hidden_size=T["D"], intermediate_size=T["I"], num_hidden_layers=1,
+                 num_attention_heads=T["H"], num_key_value_heads=T["H"], max_position_embeddings=T["max_pos"],
+                 rms_norm_eps=1e-5, pad_token_id=0)
+    ec.rope_scaling = None  # shim 1
+    ec.rope_theta = 10000.0
+    m = cnets_ours.Model(ec, bias=True, total_tokens=30, depth=3, top_k=8, num_q=num_q).eval()
+    w = synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"], num_q=num_q, seed=seed, structured=structured,
+                                 target_embed=target_embed, rho=rho)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m = m.to(dtype)
+    m.diff_device = False
+    m.init_tree()
+    return m, w
+
+
+def build_target(seed=0, structured=False, dtype=torch.float32):
+    tc = LlamaConfig(vocab_size=T["V"], hidden_size=T["D"], intermediate_size=T["I"], num_hidden_layers=T["NL"],
+                     num_attention_heads=T["H"], num_key_value_heads=T["H"], max_position_embeddings=T["max_pos"],
+                     rms_norm_eps=1e-5, pad_token_id=0, hidden_act="silu")
+    tc.rope_scaling = None
+    tc.rope_theta = 10000.0
+    tc.pretraining_tp = 1
+    tc.architectures = ["LlamaForCausalLM"]
+    base = modeling_llama_kv.LlamaForCausalLM(tc).eval()
+    w = synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"], seed=seed, structured=structured)
+    sd = {k: t(v) for k, v in w.items()}
+    missing, unexpected = base.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k for k in missing), missing
+    return base.to(dtype), w
+
+
+def make_kv(base):
+    c = base.config
+    NL = c.num_hidden_layers
+    data = torch.zeros(2 * NL, 1, c.num_key_value_heads, c.max_position_embeddings, c.hidden_size // c.num_attention_heads,
+                       dtype=base.dtype)
+    cur = torch.zeros(2 * NL, dtype=torch.long)
+    pkv = [[KVCache(data[2 * i + j], cur[2 * i + j]) for j in (0, 1)] for i in range(NL)]
+    return pkv, [data], cur
+
+
+def build_spec(base, draft):
+    sm = SpecModel.__new__(SpecModel)  # shim 2
+    nn.Module.__init__(sm)
+    sm.base_model, sm.config, sm.spec_layer = base, base.config, draft
+    sm.tokenizer = SimpleNamespace(eos_token_id=2)
+    sm.past_key_values, sm.past_key_values_data, sm.current_length_data = make_kv(base)  # shim 3
+    return sm
+
+
+def f32(x):
+    return x.detach().to(torch.float32).cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------
+def g1_imgadaptor():
+    out = {}
+    for q in (2, 5):
+        m, _ = build_draft(num_q=q, seed=11)
+        rng = np.random.default_rng(100 + q)
+        x = synth.bf16_grid(rng.standard_normal((1, 37, T["D"]), dtype=np.float32) * 0.05)
+        out[f"x_q{q}"] = x
+        out[f"y_q{q}"] = f32(m.imadpt(t(x)))[0]
+    np.savez_compressed(os.path.join(OUT, "g1_imgadaptor.npz"), **out)
+
+
+def g2_prefill():
+    """Model.forward prefill: single image run (q in {2,5}) and text-only; full out, compressed KV, real_len."""
+    out = {}
+    L = 48
+    for tag, q, n_pre, n_img in (("img_q2", 2, 6, 21), ("img_q5", 5, 9, 17), ("txt", 2, 48, 0)):
+        m, _ = build_draft(num_q=q, seed=12)
+        rng = np.random.default_rng(200 + q + n_img)
+        hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+        embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+        mask = np.zeros((1, L), bool)
+        mask[0, n_pre : n_pre + n_img] = True
+        o, kv = m(t(hidden), inputs_embeds=t(embeds), use_cache=True, image_mask=(torch.from_numpy(mask) if n_img else None))
+        out[f"{tag}_hidden"], out[f"{tag}_embeds"], out[f"{tag}_mask"] = hidden[0], embeds[0], mask[0]
+        out[f"{tag}_out"] = f32(o)[0]
+        out[f"{tag}_k"] = f32(kv[0][0])[0]
+        out[f"{tag}_v"] = f32(kv[0][1])[0]
+        out[f"{tag}_real_len"] = np.int64(int(kv[0][2]))
+        out[f"{tag}_g"] = f32(m.last_img_hidden)
+    np.savez_compressed(os.path.join(OUT, "g2_prefill.npz"), **out)
+
+
+def g3_decode():
+    """decode-branch forward with explicit positions + tree mask on top of a prefill KV."""
+    m, _ = build_draft(num_q=2, seed=13)
+    rng = np.random.default_rng(300)
+    L = 40
+    hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+    embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+    mask = np.zeros((1, L), bool)
+    mask[0, 5:25] = True
+    _, kv = m(t(hidden), inputs_embeds=t(embeds), use_cache=True, image_mask=torch.from_numpy(mask))
+    # catch-up of 3 tokens (positions follow real_len)
+    h2 = synth.bf16_grid(rng.standard_normal((1, 3, T["D"]), dtype=np.float32))
+    ids2 = rng.integers(3, T["V"], size=(1, 3))
+    o2, kv2 = m(t(h2), input_ids=torch.from_numpy(ids2), past_key_values=kv, use_cache=True)
+    # one tree level: 8 tokens, same position, eye mask ; then a second level with parent selection
+    h3 = synth.bf16_grid(rng.standard_normal((1, 8, T["D"]), dtype=np.float32))
+    ids3 = rng.integers(3, T["V"], size=(1, 8))
+    m.tree_mask = m.tree_mask_init
+    pos3 = torch.full((8,), L + 3, dtype=torch.long)
+    o3, kv3 = m(t(h3), input_ids=torch.from_numpy(ids3), past_key_values=kv2, position_ids=pos3, use_cache=True)
+    out_ids = np.array([0, 0, 3, 5, 5, 5, 1, 7])
+    tm = torch.cat((m.tree_mask_init[:, :, out_ids], m.tree_mask_init), dim=3)
+    m.tree_mask = tm
+    h4 = synth.bf16_grid(rng.standard_normal((1, 8, T["D"]), dtype=np.float32))
+    ids4 = rng.integers(3, T["V"], size=(1, 8))
+    pos4 = torch.full((8,), L + 4, dtype=torch.long)
+    o4, kv4 = m(t(h4), input_ids=torch.from_numpy(ids4), past_key_values=kv3, position_ids=pos4, use_cache=True)
+    np.savez_compressed(
+        os.path.join(OUT, "g3_decode.npz"), hidden=hidden[0], embeds=embeds[0], mask=mask[0],
+        h2=h2[0], ids2=ids2[0], o2=f32(o2)[0], h3=h3[0], ids3=ids3[0], o3=f32(o3)[0],
+        h4=h4[0], ids4=ids4[0], o4=f32(o4)[0], out_ids=out_ids, tm4=f32(tm)[0, 0],
+        k4=f32(kv4[0][0])[0], v4=f32(kv4[0][1])[0], real_len4=np.int64(int(kv4[0][2])),
+    )
+
+
+def g4_topk():
+    """topK_genrate full outputs: prefill call (image) then a decode call; greedy and sampling row order."""
+    out = {}
+    base, _ = build_target(seed=20)
+    head = base.lm_head
+    for tag, lp in (("greedy", None), ("sampling", object())):
+        m, _ = build_draft(num_q=2, seed=14)
+        m.reset_kv()
+        rng = np.random.default_rng(400)
+        L = 44
+        hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+        embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+        mask = np.zeros((1, L), bool)
+        mask[0, 4:30] = True
+        ids = rng.integers(3, T["V"], size=(1, L + 1))
+        r = m.topK_genrate(t(hidden), torch.from_numpy(ids), head, lp, inputs_embeds=t(embeds),
+                           image_mask=torch.from_numpy(mask))
+        h2 = synth.bf16_grid(rng.standard_normal((1, 3, T["D"]), dtype=np.float32))
+        ids2 = np.concatenate([ids, rng.integers(3, T["V"], size=(1, 3))], axis=1)
+        r2 = m.topK_genrate(t(h2), torch.from_numpy(ids2), head, lp)
+        if tag == "greedy":
+            out.update(hidden=hidden[0], embeds=embeds[0], mask=mask[0], ids=ids[0], h2=h2[0], ids2=ids2[0])
+        for nm, rr in (("a", r), ("b", r2)):
+            out[f"{tag}_{nm}_tokens"] = rr[0][0].numpy()
+            out[f"{tag}_{nm}_retrieve"] = rr[1].numpy()
+            out[f"{tag}_{nm}_mask"] = rr[2][0, 0].numpy()
+            out[f"{tag}_{nm}_pos"] = rr[3].numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_topk.npz"), **out)
+
+
+def g5_verify():
+    """target prefill then tree verify with a tree mask; logits, hidden, KV lengths."""
+    base, _ = build_target(seed=21)
+    pkv, data, cur = make_kv(base)
+    rng = np.random.default_rng(500)
+    L = 23
+    ids = rng.integers(3, T["V"], size=(1, L))
+    o = base(input_ids=torch.from_numpy(ids), past_key_values=pkv, output_hidden_states=True, return_dict=True)
+    # a hand-made 9-node tree
+    parents = [-1, 0, 0, 1, 1, 2, 3, 3, 6]
+    Tn = len(parents)
+    tm = np.zeros((Tn, Tn), np.float32)
+    for i, p in enumerate(parents):
+        tm[i, i] = 1
+        while p >= 0:
+            tm[i, p] = 1
+            p = parents[p]
+    pos = tm.sum(1).astype(np.int64) - 1
+    cand = rng.integers(3, T["V"], size=(1, Tn))
+    base.model.tree_mask = t(tm)[None, None]
+    o2 = base(input_ids=torch.from_numpy(cand), past_key_values=pkv, position_ids=torch.from_numpy(pos + L),
+              output_hidden_states=True, return_dict=True)
+    base.model.tree_mask = None
+    np.savez_compressed(
+        os.path.join(OUT, "g5_verify.npz"), ids=ids[0], prefill_logits=f32(o.logits)[0], prefill_hidden=f32(o.hidden_states[-1])[0],
+        tree_mask=tm, tree_pos=pos, cand=cand[0], logits=f32(o2.logits)[0], hidden=f32(o2.hidden_states[-1])[0],
+        cur=cur.numpy().copy(), k0=f32(data[0][0, 0, :, : L + Tn]), v1=f32(data[0][3, 0, :, : L + Tn]),
+    )
+
+
+def g6_posterior():
+    """evaluate_posterior greedy: random, zero-accept, multi-max ties (first max wins), full accept."""
+    rng = np.random.default_rng(600)
+    out = {}
+    V = 50
+    cases = []
+    for ci in range(6):
+        n_leaf, m = int(rng.integers(2, 9)), int(rng.integers(2, 6))
+        logits = rng.standard_normal((n_leaf, m, V)).astype(np.float32)
+        am = logits.argmax(-1)
+        cand = rng.integers(0, V, size=(n_leaf, m))
+        if ci >= 1:  # plant accepted prefixes
+            for r in range(n_leaf):
+                a = int(rng.integers(0, m))
+                cand[r, 1 : 1 + a] = am[r, :a]
+        if ci == 2:  # tie: two rows share the max accept length
+            cand[1, 1:] = am[1, : m - 1]
+            cand[0, 1:] = am[0, : m - 1]
+        if ci == 3:  # zero accept everywhere
+            cand[:, 1] = (am[:, 0] + 1) % V
+        if ci == 4:  # padding -1 inside candidates
+            cand[:, -1] = -1
+        cases.append((logits, cand))
+    for i, (logits, cand) in enumerate(cases):
+        b, a, p = utils.evaluate_posterior(t(logits), torch.from_numpy(cand), None)
+        out[f"logits{i}"], out[f"cand{i}"] = logits, cand
+        out[f"best{i}"], out[f"acc{i}"], out[f"p{i}"] = np.int64(int(b)), np.int64(int(a)), f32(p)
+    out["n"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g6_posterior.npz"), **out)
+
+
+def g8_loop():
+    """Whole-loop token streams (+ per-round accept lengths, greedy-AR equality):
+    text-only random pair, structured (successor) pair, and image-path structured pair."""
+    out = {}
+    # (a) fully random pair, text-only — SpecModel.specgenerate end to end
+    for si, seed in enumerate((0, 1, 2)):
+        base, _ = build_target(seed=30 + seed)
+        draft, _ = build_draft(seed=40 + seed)
+        sm = build_spec(base, draft)
+        rng = np.random.default_rng(800 + seed)
+        ids = rng.integers(3, T["V"], size=(1, 20))
+        o, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids), temperature=0.0, max_new_tokens=24, log=True,
+                                                 return_acceptance_len=True)
+        base.model.tree_mask = None
+        out[f"rand{si}_ids"], out[f"rand{si}_out"] = ids[0], o[0].numpy()
+        out[f"rand{si}_new_token"], out[f"rand{si}_idx"], out[f"rand{si}_acc"] = np.int64(int(new_token)), np.int64(idx), np.array(acc)
+        out[f"rand{si}_ar"] = greedy_ar(base, ids, o.shape[1] - ids.shape[1])
+    # (b) structured pair, text-only
+    for si, seed in enumerate((0, 1)):
+        base, tw = build_target(seed=50 + seed, structured=True)
+        draft, _ = build_draft(seed=60 + seed, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+        sm = build_spec(base, draft)
+        rng = np.random.default_rng(900 + seed)
+        ids = rng.integers(3, T["V"], size=(1, 16))
+        o, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids), temperature=0.0, max_new_tokens=40, log=True,
+                                                 return_acceptance_len=True)
+        base.model.tree_mask = None
+        out[f"succ{si}_ids"], out[f"succ{si}_out"] = ids[0], o[0].numpy()
+        out[f"succ{si}_new_token"], out[f"succ{si}_idx"], out[f"succ{si}_acc"] = np.int64(int(new_token)), np.int64(idx), np.array(acc)
+        out[f"succ{si}_ar"] = greedy_ar(base, ids, o.shape[1] - ids.shape[1])
+    # (c) image path, structured pair: drive the loop body by hand, restating spec_model_ours.py:455-547
+    base, tw = build_target(seed=70, structured=True)
+    draft, _ = build_draft(seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    sm = build_spec(base, draft)
+    ids, emb, mask = synth.make_request(T["V"], T["D"], 5, 30, 9, seed=7, embed=tw["model.embed_tokens.weight"])
+    o, acc = image_loop(sm, ids, emb, mask, max_new_tokens=30)
+    out["img_ids"], out["img_emb"], out["img_mask"], out["img_out"], out["img_acc"] = ids, emb, mask, o, np.array(acc)
+    np.savez_compressed(os.path.join(OUT, "g8_loop.npz"), **out)
+
+
+def greedy_ar(base, ids, n_new):
+    pkv, _, _ = make_kv(base)
+    base.model.tree_mask = None
+    cur = torch.from_numpy(ids)
+    o = base(input_ids=cur, past_key_values=pkv, return_dict=True)
+    toks = []
+    for _ in range(n_new):
+        tok = int(torch.argmax(o.logits[0, -1]))
+        toks.append(tok)
+        o = base(input_ids=torch.tensor([[tok]]), past_key_values=pkv, return_dict=True)
+    return np.array(toks, dtype=np.int64)
+
+
+def image_loop(sm, ids, emb, mask, max_new_tokens):
+    base, draft = sm.base_model, sm.spec_layer
+    pkv, pkv_data, cur = sm.past_key_values, sm.past_key_values_data, sm.current_length_data
+    cur.zero_()
+    draft.reset_kv()
+    utils.reset_tree_mode(sm)
+    input_ids = torch.from_numpy(ids)[None]
+    inputs_embeds = t(emb)[None]
+    _, orig, hidden = sm(None, past_key_values=pkv, output_orig=True, inputs_embeds=inputs_embeds)
+    token = torch.argmax(orig[:, -1])[None, None]
+    input_ids = torch.cat((input_ids, token), dim=1)
+    dt, ri, tm, tp = draft.topK_genrate(hidden, input_ids, base.lm_head, None, inputs_embeds=inputs_embeds,
+                                        image_mask=torch.from_numpy(mask)[None])
+    input_ids = input_ids[:, :-1]
+    padding = torch.zeros(1, 1, dtype=torch.long) - 1
+    new_token, acc = 0, []
+    for _ in range(200):
+        base.model.tree_mask = tm
+        logits, hidden_new, _ = utils.tree_decoding(sm, dt, pkv, tp, input_ids, ri)
+        dt2 = torch.cat((dt, padding), dim=1)
+        cand = dt2[0, ri]
+        best, al, sample_p = utils.evaluate_posterior(logits, cand, None)
+        acc.append(int(al))
+        input_ids, dt, ri, tm, tp, new_token, _, _ = utils.update_inference_inputs(
+            input_ids, cand, best, al, ri, None, new_token, pkv_data, cur, sm, hidden_new, sample_p)
+        if new_token > max_new_tokens:
+            break
+    base.model.tree_mask = None
+    return input_ids[0].numpy(), acc
+
+
+def g9_bf16():
+    """Reference run in torch-bf16 on CPU: pins the oracle's bf16 rounding-point emulation (tolerance-level)."""
+    out = {}
+    m, _ = build_draft(num_q=2, seed=15, dtype=torch.bfloat16)
+    rng = np.random.default_rng(950)
+    L = 36
+    hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+    embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+    mask = np.zeros((1, L), bool)
+    mask[0, 3:27] = True
+    o, kv = m(t(hidden, torch.bfloat16), inputs_embeds=t(embeds, torch.bfloat16), use_cache=True, image_mask=torch.from_numpy(mask))
+    h2 = synth.bf16_grid(rng.standard_normal((1, 4, T["D"]), dtype=np.float32))
+    ids2 = rng.integers(3, T["V"], size=(1, 4))
+    o2, _ = m(t(h2, torch.bfloat16), input_ids=torch.from_numpy(ids2), past_key_values=kv, use_cache=True)
+    out.update(d_hidden=hidden[0], d_embeds=embeds[0], d_mask=mask[0], d_out_last=f32(o)[0, -1], d_k=f32(kv[0][0])[0],
+               d_h2=h2[0], d_ids2=ids2[0], d_o2=f32(o2)[0])
+    base, _ = build_target(seed=22, dtype=torch.bfloat16)
+    pkv, data, cur = make_kv(base)
+    ids = rng.integers(3, T["V"], size=(1, 19))
+    o = base(input_ids=torch.from_numpy(ids), past_key_values=pkv, output_hidden_states=True, return_dict=True)
+    out.update(t_ids=ids[0], t_logits=f32(o.logits)[0], t_hidden=f32(o.hidden_states[-1])[0])
+    np.savez_compressed(os.path.join(OUT, "g9_bf16.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g8=g8_loop, g9=g9_bf16)
+    for k in which:
+        print("generating", k, flush=True)
+        fns[k]()
+    print("done")

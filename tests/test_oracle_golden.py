@@ -1,0 +1,168 @@
+"""CPU: the numpy oracle (oracle/vispec_oracle.py) against golden vectors captured from the reference itself
+(tests/golden/gen_golden.py).  fp32 floats: 2e-4 abs on O(1) activations / logits; integer outputs exact."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import T, oracle_draft, oracle_target, vo
+
+ATOL = 2e-4
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def close(a, b, atol=ATOL, rtol=1e-4):
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_bf16_round_is_rne():
+    x = np.array([1.0, 1.00390625, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -3.3895314e38, 0.1], np.float32)
+    import torch
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(vo.bf16_round(x), want)
+
+
+def test_g1_imgadaptor(golden_dir):
+    g = load(golden_dir, "g1_imgadaptor.npz")
+    for q in (2, 5):
+        d, _ = oracle_draft(num_q=q, seed=11)
+        close(d.imgadaptor(g[f"x_q{q}"][0]), g[f"y_q{q}"])
+
+
+@pytest.mark.parametrize("tag,q", [("img_q2", 2), ("img_q5", 5), ("txt", 2)])
+def test_g2_prefill(golden_dir, tag, q):
+    g = load(golden_dir, "g2_prefill.npz")
+    d, _ = oracle_draft(num_q=q, seed=12)
+    mask = g[f"{tag}_mask"] if tag != "txt" else None
+    out, kv, pos = d.forward_prefill(g[f"{tag}_hidden"], g[f"{tag}_embeds"], mask)
+    close(kv[0], g[f"{tag}_k"])
+    close(kv[1], g[f"{tag}_v"])
+    assert kv[2] == int(g[f"{tag}_real_len"])
+    close(d.last_img_hidden, g[f"{tag}_g"])
+    ref = g[f"{tag}_out"]  # [L, D] scattered back through trans_mat: compressed row i lives at original row pos[i]...
+    close(out[-1], ref[-1])  # the only row topK_genrate consumes (cnets_ours.py:1109)
+    if tag == "txt":
+        close(out, ref)
+    else:
+        # text rows keep their index; the (q-1) compressed tokens sit on the last (q-1) image positions
+        close(out, ref[pos])
+        others = np.setdiff1d(np.arange(ref.shape[0]), pos)
+        assert np.all(ref[others] == 0)
+
+
+def test_g3_decode(golden_dir):
+    g = load(golden_dir, "g3_decode.npz")
+    d, _ = oracle_draft(num_q=2, seed=13)
+    _, kv, _ = d.forward_prefill(g["hidden"], g["embeds"], g["mask"])
+    o2, kv2 = d.forward_decode(g["h2"], g["ids2"], kv)
+    close(o2, g["o2"])
+    L = g["hidden"].shape[0]
+    o3, kv3 = d.forward_decode(g["h3"], g["ids3"], kv2, pos=np.full(8, L + 3), tree_mask=np.eye(8, dtype=bool))
+    close(o3, g["o3"])
+    o4, kv4 = d.forward_decode(g["h4"], g["ids4"], kv3, pos=np.full(8, L + 4), tree_mask=g["tm4"] > 0)
+    close(o4, g["o4"])
+    close(kv4[0], g["k4"])
+    close(kv4[1], g["v4"])
+    assert kv4[2] == int(g["real_len4"])
+
+
+@pytest.mark.parametrize("tag", ["greedy", "sampling"])
+def test_g4_topk_genrate(golden_dir, tag):
+    g = load(golden_dir, "g4_topk.npz")
+    t, _ = oracle_target(seed=20)
+    d, _ = oracle_draft(num_q=2, seed=14)
+    d.reset_kv()
+    r = d.topK_genrate(g["hidden"], g["ids"], t.lm_head, inputs_embeds=g["embeds"], image_mask=g["mask"], sampling=tag == "sampling")
+    r2 = d.topK_genrate(g["h2"], g["ids2"], t.lm_head, sampling=tag == "sampling")
+    for nm, rr in (("a", r), ("b", r2)):
+        np.testing.assert_array_equal(rr[0], g[f"{tag}_{nm}_tokens"])
+        np.testing.assert_array_equal(rr[1], g[f"{tag}_{nm}_retrieve"])
+        np.testing.assert_array_equal(rr[2], g[f"{tag}_{nm}_mask"] > 0)
+        np.testing.assert_array_equal(rr[3], g[f"{tag}_{nm}_pos"])
+
+
+def test_g5_target_verify(golden_dir):
+    g = load(golden_dir, "g5_verify.npz")
+    t, _ = oracle_target(seed=21)
+    pkv, data, cur = vo.initialize_past_key_values(T["NL"], T["H"], T["max_pos"], T["D"] // T["H"])
+    logits, hidden = t.forward(pkv, input_ids=g["ids"])
+    close(logits, g["prefill_logits"])
+    close(hidden, g["prefill_hidden"])
+    t.tree_mask = g["tree_mask"] > 0
+    L = g["ids"].shape[0]
+    logits, hidden = t.forward(pkv, input_ids=g["cand"], position_ids=g["tree_pos"] + L)
+    close(logits, g["logits"])
+    close(hidden, g["hidden"])
+    np.testing.assert_array_equal(cur, g["cur"])
+    n = L + g["cand"].shape[0]
+    close(data[0][0, 0, :, :n], g["k0"])
+    close(data[0][3, 0, :, :n], g["v1"])
+
+
+def test_g6_evaluate_posterior(golden_dir):
+    g = load(golden_dir, "g6_posterior.npz")
+    seen = set()
+    for i in range(int(g["n"])):
+        b, a, p = vo.evaluate_posterior_greedy(g[f"logits{i}"], g[f"cand{i}"])
+        assert (b, a) == (int(g[f"best{i}"]), int(g[f"acc{i}"]))
+        np.testing.assert_array_equal(p, g[f"p{i}"])
+        seen.add(a)
+    assert 0 in seen and max(seen) >= 2
+
+
+@pytest.mark.parametrize("case", ["rand0", "rand1", "rand2", "succ0", "succ1"])
+def test_g8_whole_loop_text(golden_dir, case):
+    g = load(golden_dir, "g8_loop.npz")
+    kind, si = case[:4], int(case[4:])
+    if kind == "rand":
+        t, _ = oracle_target(seed=30 + si)
+        d, _ = oracle_draft(seed=40 + si)
+        mnt = 24
+    else:
+        t, tw = oracle_target(seed=50 + si, structured=True)
+        d, _ = oracle_draft(seed=60 + si, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+        mnt = 40
+    out, new_token, idx, acc = vo.specgenerate(t, d, g[f"{case}_ids"], max_new_tokens=mnt, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out, g[f"{case}_out"])
+    assert new_token == int(g[f"{case}_new_token"]) and idx == int(g[f"{case}_idx"])
+    np.testing.assert_array_equal(acc, g[f"{case}_acc"])
+    # the reference's own invariant: speculative output == greedy AR of the same target
+    L = g[f"{case}_ids"].shape[0]
+    np.testing.assert_array_equal(out[L:], g[f"{case}_ar"])
+    ar = vo.baseline_forward(t, g[f"{case}_ids"], max_steps=len(out) - L, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(ar[: len(out)], out)
+
+
+def test_g8_whole_loop_image(golden_dir):
+    g = load(golden_dir, "g8_loop.npz")
+    t, tw = oracle_target(seed=70, structured=True)
+    d, _ = oracle_draft(seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    out, new_token, idx, acc = vo.specgenerate(t, d, g["img_ids"], inputs_embeds=g["img_emb"], image_mask=g["img_mask"],
+                                               max_new_tokens=30, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out, g["img_out"])
+    np.testing.assert_array_equal(acc, g["img_acc"])
+    assert max(acc) == 4 and d.stable_kv[0].shape[1] < len(out) - 20  # compressed draft KV is shorter than the context
+
+
+def test_g9_bf16_rounding_points(golden_dir):
+    """Oracle in bf16-emulation mode vs the reference run in torch-bf16 on CPU.  Reduction orders differ, so the
+    bound is a few bf16 ulps (2^-8 relative), not bitwise."""
+    g = load(golden_dir, "g9_bf16.npz")
+    d, _ = oracle_draft(num_q=2, seed=15, bf16=True)
+    out, kv, _ = d.forward_prefill(g["d_hidden"], g["d_embeds"], g["d_mask"])
+    tol = dict(atol=0.02, rtol=0.02)
+    np.testing.assert_allclose(kv[0], g["d_k"], **tol)
+    np.testing.assert_allclose(out[-1], g["d_out_last"], **tol)
+    o2, _ = d.forward_decode(g["d_h2"], g["d_ids2"], kv)
+    np.testing.assert_allclose(o2, g["d_o2"], **tol)
+    # typical error is far below the bound: most entries agree to 1 ulp
+    rel = np.abs(o2 - g["d_o2"]) / (np.abs(g["d_o2"]) + 1e-2)
+    assert np.median(rel) < 2 ** -8
+    t, _ = oracle_target(seed=22, bf16=True)
+    pkv, _, _ = vo.initialize_past_key_values(T["NL"], T["H"], T["max_pos"], T["D"] // T["H"])
+    logits, hidden = t.forward(pkv, input_ids=g["t_ids"])
+    np.testing.assert_allclose(hidden, g["t_hidden"], **tol)
+    np.testing.assert_allclose(logits, g["t_logits"], atol=0.02, rtol=0.03)
