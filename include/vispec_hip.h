@@ -1,0 +1,152 @@
+/*
+ * libvispec_hip — C-ABI of the MI355X (gfx950) ViSpec draft-and-verify hot path.
+ *
+ * The reference (KangJialiang/ViSpec) is pure Python and has no FFI; the boundary it exposes for this path
+ * is its Python object API.  This header is the C-ABI that sits *under* the Python mirror
+ * of that API (vispec_amd/model/ *.py) — each entry point names the reference function(s) it replaces
+ * (paths relative to /root/reference/vispec/model/).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; tensors are bf16 (uint16 storage) unless noted;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and never synchronises,
+ *    except the *_host getters documented as blocking;
+ *  - return value: 0 = ok, negative = error (vispec_last_error() gives the text);
+ *  - no ownership transfer: the caller owns weights, KV caches and I/O buffers; the library owns only the
+ *    opaque vispec_ctx and the workspace it allocates at create time;
+ *  - one ctx per (process, device); calls on one ctx are not re-entrant; different ctxs are independent.
+ */
+#ifndef VISPEC_HIP_H
+#define VISPEC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vispec_ctx vispec_ctx;
+
+typedef struct {
+  /* target language model (modeling_llama_kv.py) */
+  int hidden_size, num_heads, num_kv_heads, head_dim, intermediate_size, vocab_size, num_layers;
+  int max_pos;            /* KV-cache capacity per layer (kv_cache.py:109: config.max_position_embeddings) */
+  float rms_eps;
+  int qkv_bias;           /* Qwen-style q/k/v bias */
+  /* draft (cnets_ours.py): one decoder layer, MHA, same hidden size */
+  int draft_heads, draft_intermediate, draft_max_pos, draft_qkv_bias, draft_fc_bias;
+  float draft_rms_eps;
+  /* tree shape (cnets_ours.py:732-735) */
+  int total_token, depth, top_k, num_q;
+  int eos_token_id;
+  int eager_scores;       /* 1: target attention rounds scores to bf16 like modeling_llama_kv.py:602-604 */
+} vispec_config;
+
+/* per-layer target weights; wqkv = rows [q | k | v] fused, wgu = rows [gate | up] fused (done once at load) */
+typedef struct {
+  const void *wqkv, *bqkv, *wo, *wgu, *wdown, *ln1, *ln2;
+} vispec_layer_weights;
+
+typedef struct {
+  const void *embed;      /* [V, D]   model.embed_tokens.weight */
+  const void *norm;       /* [D]      model.norm.weight */
+  const void *lm_head;    /* [V, D]   lm_head.weight (also the draft's head, utils.py:300) */
+  const void *rope_cos, *rope_sin; /* [max_pos, head_dim] bf16, built as modeling_llama_kv.py:147-181 */
+} vispec_target_misc;
+
+typedef struct {            /* SURVEY §8 A0 state-dict contract */
+  const void *embed;        /* embed_tokens.weight [V, D] */
+  const void *fc_w, *fc_b;  /* fc [D, 2D] (+[D]) */
+  const void *imgfc_w, *imgfc_b;
+  const void *wqkv, *bqkv, *wo, *wgu, *wdown, *ln2;   /* layers.0.* (no input norm, cnets_ours.py:537-540) */
+  const void *ad_q;         /* imadpt.q [num_q, H, hd] */
+  const void *ad_wkv, *ad_bkv; /* imadpt.{k,v}_proj fused [2D, D] */
+  const void *ad_wo;        /* imadpt.o_proj [D, D] */
+  const void *rope_cos, *rope_sin; /* [draft_max_pos, head_dim] */
+} vispec_draft_weights;
+
+const char* vispec_last_error(void);
+int  vispec_version(void);
+
+int  vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out);
+void vispec_ctx_destroy(vispec_ctx* ctx);
+int  vispec_set_target_layer(vispec_ctx*, int layer, const vispec_layer_weights*);
+int  vispec_set_target_misc(vispec_ctx*, const vispec_target_misc*);
+int  vispec_set_draft_weights(vispec_ctx*, const vispec_draft_weights*);
+/* KV buffers owned by the caller: target [2*layers, 1, H_kv, max_pos, hd] (kv_cache.py:105-126),
+   draft [2, H, draft_max_pos, hd] (replaces the torch.cat growth of cnets_ours.py:393-396) */
+int  vispec_set_kv(vispec_ctx*, void* target_kv, void* draft_kv);
+
+/* ---- single kernels (unit-testable building blocks) ------------------------------------------------ */
+/* Y[M,N] = X[M,K] · W[N,K]^T (+bias) ; epilogue: 0 none, 1 += residual R (bf16 add of two bf16 tensors),
+   2 SwiGLU: W holds [gate rows | up rows] (2N rows), Y = silu(g)*u.  M <= 64.   nn.Linear in every module above. */
+int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias,
+                       void* Y, int ldy, const void* R, int ldr, int M, int N, int K, int epilogue);
+/* LlamaRMSNorm (cnets_ours.py:513-527, modeling_llama_kv.py:104-133) */
+int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps);
+/* rotary (cnets_ours.py:104-119) on fused qkv rows + append K,V to a [H_kv, S_max, hd] cache at rows
+   *kv_base_dev + i ; positions = *pos_base_dev + pos_off_dev[i] (pos_off_dev may be NULL = i). Q is rotated in place. */
+int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cos, const void* sin,
+                       const int* pos_base_dev, const int* pos_off_dev, void* k_cache, void* v_cache, int s_max,
+                       const int* kv_base_dev);
+/* tree-masked attention of M query rows against cache rows [0, *prefix_dev) (all visible) + `tail` rows after
+   them, of which row m sees tail key t iff bit t of mask_dev[m] is set  (cnets_ours.py:781-815 + 428-433;
+   modeling_llama_kv.py:890-924 + 602-623).  q [M, H*hd] row stride ldq ; out [M, H*hd]. */
+int vispec_tree_attention(vispec_ctx*, void* stream, const void* q, int ldq, const void* k_cache, const void* v_cache,
+                          int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev, int tail,
+                          const uint64_t* mask_dev, void* out, int ldo, int eager_scores);
+/* row-wise argmax over bf16 logits (first max wins) -> int32 [M]   (utils.py:290,441,554) */
+int vispec_argmax_rows(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int* out_idx);
+/* row-wise log-softmax (bf16 out) + top-k, value desc / index asc (cnets_ours.py:1113-1115,1146-1149) */
+int vispec_logsoftmax_topk(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int k,
+                           int* out_idx, float* out_logp);
+
+/* ---- the path ------------------------------------------------------------------------------------- */
+/* Request start: context length L already prefetched into the target KV (by the caller's prefill), first sampled
+   token; resets the round state.  (spec_model_ours.py:283-307,476) */
+int vispec_begin_request(vispec_ctx*, void* stream, const int* prompt_ids_host, int L, int max_new_tokens);
+
+/* Draft prefill with fused vision adaptor (cnets_ours.py:879-975 + 1099-1123) followed by the tree growth of
+   topK_genrate (cnets_ours.py:1126-1238).  hidden/embeds [L, D] (embeds = the target's inputs_embeds, un-shifted),
+   image_mask_host [L] (NULL = LLaVA-1.5 / text semantics), first_token_dev = argmax of the prefill's last logits row. */
+int vispec_draft_prefill(vispec_ctx*, void* stream, const void* hidden, const void* embeds, const uint8_t* image_mask_host,
+                         int L, const int* first_token_dev);
+
+/* Target verify forward of the current tree (utils.py:389-412 tree_decoding -> SpecModel.forward ->
+   modeling_llama_kv.py:927-1080) + greedy accept (utils.py:415-451) + KV compaction / bookkeeping
+   (utils.py:496-556).  n_tokens = 0 means "the current tree"; forced_accept >= 0 overrides the measured accept
+   length (bench-only scripted-acceptance mode, never used by the parity tests). */
+int vispec_verify_accept(vispec_ctx*, void* stream, int forced_accept);
+
+/* The two halves of vispec_verify_accept, for the API mirror (utils.tree_decoding / evaluate_posterior +
+   update_inference_inputs are separate calls in the reference): forward leaves logits [T,V], hidden_state_new [T,D]
+   and the per-node argmax in ctx buffers; accept consumes them. */
+int vispec_target_forward(vispec_ctx*, void* stream);
+int vispec_accept(vispec_ctx*, void* stream, int forced_accept);
+/* Install a caller-built tree (host arrays; retrieve is [n_leaf, max_depth] row-major, -1 padded) instead of the one the
+   draft produced — what utils.tree_decoding does with arbitrary tree_candidates / tree_mask.  Blocking. */
+int vispec_set_tree_host(vispec_ctx*, void* stream, const int* tokens_T, const int* pos_T, const uint64_t* mask_T,
+                         const int* retrieve, int n_leaf, int max_depth);
+
+/* One decode call of topK_genrate (cnets_ours.py:1043-1238, stable_kv branch) on the hidden states accepted by the
+   last vispec_verify_accept. */
+int vispec_draft_round(vispec_ctx*, void* stream);
+
+/* Seed the next token to decode (the prefill's argmax) when no draft is used (AR baseline). */
+int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
+/* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */
+int vispec_ar_step(vispec_ctx*, void* stream);
+
+/* Blocking read-back of the round state: out[0]=n_ctx, [1]=new_token, [2]=rounds, [3]=done(eos|max_new), [4]=last accept_len,
+   [5]=next_token, [6]=draft kv len, [7]=n_leaf of current tree. */
+int vispec_get_state_host(vispec_ctx*, void* stream, int* out8_host);
+/* Blocking copies of device-side logs/buffers, for the API mirror and the tests. */
+int vispec_get_tokens_host(vispec_ctx*, void* stream, int* out_host, int n);             /* committed token ids */
+int vispec_get_accept_log_host(vispec_ctx*, void* stream, int* out_host, int n_rounds);
+int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve_Txd2,
+                         int* n_leaf, int* max_depth);
+/* device pointers of internal buffers (hidden_state_new [T,D], verify logits [T,V] bf16, draft last hidden ...) */
+void* vispec_buffer(vispec_ctx*, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,71 @@
+"""CPU (no GPU): the C-ABI library builds/loads and exports every symbol include/vispec_hip.h declares; the product
+path refuses to run without the HIP extension / a GPU (no silent fallback); host-side plumbing."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "vispec_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vispec_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from vispec_amd import lib as L
+    assert declared_symbols() == sorted(L.SIGNATURES)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from vispec_amd import lib as L
+    lib = L.load(build_if_missing=True)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.vispec_version() >= 1
+
+
+def test_ctypes_structs_match_header_layout():
+    import ctypes as C
+    from vispec_amd import lib as L
+    assert C.sizeof(L.VispecConfig) == 22 * 4
+    assert C.sizeof(L.LayerWeights) == 7 * 8 and C.sizeof(L.TargetMisc) == 5 * 8 and C.sizeof(L.DraftWeights) == 17 * 8
+
+
+def test_no_silent_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vispec_amd import lib as L, synth
+    from vispec_amd.engine import DraftConfig, TargetConfig
+    from vispec_amd.model import SpecModel
+    T = synth.TINY
+    tcfg = TargetConfig(T["D"], T["H"], T["H"], T["I"], T["V"], T["NL"], T["max_pos"])
+    dcfg = DraftConfig(T["D"], T["H"], T["I"], T["V"], T["max_pos"])
+    tw = synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"])
+    dw = synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"])
+    with pytest.raises((L.VispecError, RuntimeError, AssertionError)):
+        SpecModel.from_weights(tcfg, dcfg, tw, dw, device="cuda:0")
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "vispec_amd")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(d, f)).read(), flags=re.M):
+                bad.append(f)
+    assert not bad, bad
+
+
+def test_synth_structured_pair_is_a_successor_model():
+    from vispec_amd import synth
+    V, D = 1008, 256
+    w = synth.make_target_weights(D, 2, 704, V, 1, seed=3, structured=True)
+    E, Hd = w["model.embed_tokens.weight"], w["lm_head.weight"]
+    s = synth.succ_table(V)
+    t = np.arange(3, V)
+    assert (np.argmax(E[t] @ Hd.T, axis=1) == s[t]).mean() > 0.999
+    assert s.min() >= 3

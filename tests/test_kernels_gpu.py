@@ -1,0 +1,249 @@
+"""GPU parity of each HIP kernel (through the C-ABI) against the numpy oracle in bf16-emulation mode.
+
+Tolerances (written here, used below):
+  * bf16 results whose fp32 accumulation order differs from numpy's: equal up to ONE bf16 ulp
+    (|a-b| <= 2^-7 * max(|a|,|b|) + 1e-6) on every element, and >= 97 % of the elements bit-identical;
+  * integer outputs (argmax / top-k indices, tree tables): bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from helpers import T, vo  # noqa: E402
+from vispec_amd import lib as L, synth  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tb(x):
+    """numpy fp32 (bf16-representable) -> bf16 device tensor"""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).to(dev()).contiguous()
+
+
+def fn(t):
+    return t.float().cpu().numpy()
+
+
+def p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None):
+    """`scale`: magnitude the ulp is taken at (default: the values themselves).  For a chained epilogue
+    (linear -> round -> + residual -> round) a 1-ulp flip of the FIRST rounding survives at the magnitude of the
+    operands, not of the (possibly cancelling) sum, so the operands' magnitude is passed as scale."""
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    mag = np.maximum(np.abs(got), np.abs(want))
+    if scale is not None:
+        mag = np.maximum(mag, np.abs(scale))
+    tol = ulps * 2.0 ** -7 * mag + 1e-6
+    bad = np.abs(got - want) > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.abs(got - want) / tol), got.shape)
+        raise AssertionError(f"{bad.sum()} / {bad.size} beyond {ulps} bf16 ulp; worst abs {np.abs(got - want).max()}; "
+                             f"worst rel-to-tol {(np.abs(got - want) / tol).max():.2f} at {i}: got {got[i]} want {want[i]}; "
+                             f"exact frac {(got == want).mean():.4f}")
+    exact = (got == want).mean()
+    assert exact >= min_exact, f"only {exact:.4f} bit-identical"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load(build_if_missing=True)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from vispec_amd.engine import DraftConfig, DraftWeightsDev, Engine, TargetConfig, TargetWeights
+    tcfg = TargetConfig(hidden_size=T["D"], num_heads=T["H"], num_kv_heads=T["H"], intermediate_size=T["I"], vocab_size=T["V"],
+                        num_layers=T["NL"], max_position_embeddings=T["max_pos"])
+    dcfg = DraftConfig(hidden_size=T["D"], num_heads=T["H"], intermediate_size=T["I"], vocab_size=T["V"],
+                       max_position_embeddings=T["max_pos"])
+    tw = TargetWeights.from_state_dict(tcfg, synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"], seed=0), dev())
+    dw = DraftWeightsDev.from_state_dict(dcfg, synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"], seed=1), 2, dev())
+    return Engine(tcfg, dcfg, tw, dw)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (5, 64, 704), (8, 1008, 256), (16, 256, 8192), (30, 768, 256),
+                                   (30, 256, 704), (32, 4096, 4096), (33, 128, 512), (64, 96, 11008)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_skinny(lib, M, N, K, epi, bias):
+    rng = np.random.default_rng(M * 131 + N * 7 + K + epi)
+    o = vo.Ops(bf16=True)
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    rows = 2 * N if epi == 2 else N
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32)) if bias else None
+    r = synth.bf16_grid(rng.standard_normal((M, N), dtype=np.float32))
+    scale = None
+    if epi == 0:
+        want = o.linear(x, w, b)
+    elif epi == 1:
+        lin = o.linear(x, w, b)
+        want = o.add(r, lin)
+        scale = np.maximum(np.abs(r), np.abs(lin))
+    else:
+        gu = o.linear(x, w, b)
+        want = o.silu_mul(gu[:, :N], gu[:, N:])
+    X, W, B, R = tb(x), tb(w), (tb(b) if bias else None), tb(r)
+    Y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_skinny(None, stream(), p(X), K, p(W), p(B), p(Y), N, p(R), N, M, N, K, epi))
+    torch.cuda.synchronize()
+    # one extra ulp for the SwiGLU epilogue: it chains three rounded ops, a flipped gate rounding propagates
+    assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale)
+
+
+def test_gemm_strided_output_and_padding_rows_untouched(lib):
+    rng = np.random.default_rng(3)
+    M, N, K = 7, 64, 256
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((N, K), dtype=np.float32) * 0.05)
+    X, W = tb(x), tb(w)
+    Y = torch.full((16, 2 * N), 3.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_skinny(None, stream(), p(X), K, p(W), None, C.c_void_p(Y.data_ptr() + 2 * N), 2 * N, None, 0, M, N, K, 0))
+    torch.cuda.synchronize()
+    y = fn(Y)
+    assert_bf16_close(y[:M, N:], vo.Ops(True).linear(x, w))
+    assert (y[:, :N] == 3.0).all() and (y[M:] == 3.0).all()
+
+
+@pytest.mark.parametrize("M,D", [(1, 256), (30, 4096), (8, 3584)])
+def test_rmsnorm(lib, M, D):
+    rng = np.random.default_rng(D + M)
+    x = synth.bf16_grid(rng.standard_normal((M, D), dtype=np.float32) * 3)
+    w = synth.bf16_grid(1 + 0.1 * rng.standard_normal(D, dtype=np.float32))
+    X, W = tb(x), tb(w)
+    Y = torch.empty_like(X)
+    L.check(lib.vispec_rmsnorm(None, stream(), p(X), p(W), p(Y), M, D, 1e-5))
+    torch.cuda.synchronize()
+    assert_bf16_close(fn(Y), vo.Ops(True).rmsnorm(x, w, 1e-5))
+
+
+@pytest.mark.parametrize("H,Hkv", [(2, 2), (4, 2)])
+def test_rope_append(lib, H, Hkv):
+    rng = np.random.default_rng(11)
+    M, hd, S = 9, 128, 96
+    o = vo.Ops(True)
+    cos, sin = vo.rope_tables(hd, 256, 10000.0)
+    cos, sin = synth.bf16_grid(cos), synth.bf16_grid(sin)
+    qkv = synth.bf16_grid(rng.standard_normal((M, (H + 2 * Hkv) * hd), dtype=np.float32))
+    pos_off = rng.integers(0, 20, size=M).astype(np.int32)
+    base, kvb = 40, 17
+    QKV = tb(qkv)
+    kc = torch.zeros(Hkv, S, hd, dtype=torch.bfloat16, device=dev())
+    vc = torch.zeros_like(kc)
+    d_base = torch.tensor([base], dtype=torch.int32, device=dev())
+    d_kvb = torch.tensor([kvb], dtype=torch.int32, device=dev())
+    d_off = torch.from_numpy(pos_off).to(dev())
+    COS, SIN = tb(cos), tb(sin)  # keep alive: a temporary would be freed (and its block reused) before the launch
+    L.check(lib.vispec_rope_append(None, stream(), p(QKV), M, H, Hkv, hd, p(COS), p(SIN), p(d_base), p(d_off), p(kc), p(vc), S, p(d_kvb)))
+    torch.cuda.synchronize()
+    pos = base + pos_off
+    q = qkv[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2)
+    k = qkv[:, H * hd : (H + Hkv) * hd].reshape(M, Hkv, hd).transpose(1, 0, 2)
+    v = qkv[:, (H + Hkv) * hd :].reshape(M, Hkv, hd).transpose(1, 0, 2)
+    np.testing.assert_array_equal(fn(QKV)[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), o.rope(q, cos, sin, pos))
+    np.testing.assert_array_equal(fn(kc)[:, kvb : kvb + M], o.rope(k, cos, sin, pos))
+    np.testing.assert_array_equal(fn(vc)[:, kvb : kvb + M], v)
+    assert (fn(kc)[:, :kvb] == 0).all() and (fn(kc)[:, kvb + M :] == 0).all()
+
+
+def _tree_mask(rng, M, tail):
+    m = np.zeros((M, tail), bool)
+    for i in range(M):
+        m[i, rng.integers(0, tail)] = True  # at least one visible tail key per row
+        m[i] |= rng.random(tail) < 0.3
+    return m
+
+
+@pytest.mark.parametrize("H,Hkv,M,prefix,tail,eager", [
+    (2, 2, 30, 300, 30, 1), (2, 2, 30, 0, 30, 1), (2, 2, 1, 777, 1, 1), (2, 2, 8, 131, 24, 0), (2, 2, 5, 1, 5, 0),
+    (2, 2, 2, 600, 0, 0), (4, 2, 30, 257, 30, 1), (14, 2, 3, 90, 3, 1), (2, 2, 64, 500, 64, 1), (2, 2, 30, 1500, 30, 1)])
+def test_tree_attention(lib, engine, H, Hkv, M, prefix, tail, eager):
+    rng = np.random.default_rng(H * 1000 + M * 10 + prefix + tail)
+    hd, S = 128, 2048
+    o = vo.Ops(True)
+    q = synth.bf16_grid(rng.standard_normal((M, H, hd), dtype=np.float32))
+    k = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))
+    v = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))
+    mask = _tree_mask(rng, M, tail) if tail else np.zeros((M, 0), bool)
+    bits = np.zeros(M, np.uint64)
+    for i in range(M):
+        for t in range(tail):
+            if mask[i, t]:
+                bits[i] |= np.uint64(1) << np.uint64(t)
+    allow = np.concatenate([np.ones((M, prefix), bool), mask], axis=1)
+    n = prefix + tail
+    rep = H // Hkv
+    kk, vv = np.repeat(k[:, :n], rep, axis=0), np.repeat(v[:, :n], rep, axis=0)
+    qh = q.transpose(1, 0, 2)
+    want = (o.attn_eager if eager else o.attn_sdpa)(qh, kk, vv, allow).transpose(1, 0, 2).reshape(M, H * hd)
+    # magnitude of the summands sum_k p_k |v_k|: rounding P (and, in eager mode, the scores) to bf16 perturbs each term by
+    # 2^-9 relative, so the error lives at THIS scale, not at the scale of the (cancelling) sum
+    sc = np.einsum("hqd,hkd->hqk", qh, kk) / np.sqrt(hd)
+    sc = np.where(allow[None], sc, -np.inf)
+    pr = np.exp(sc - sc.max(-1, keepdims=True))
+    pr /= pr.sum(-1, keepdims=True)
+    scale = np.einsum("hqk,hkd->hqd", pr, np.abs(vv)).transpose(1, 0, 2).reshape(M, H * hd)
+    Q, Kc, Vc = tb(q.reshape(M, H * hd)), tb(k), tb(v)
+    d_prefix = torch.tensor([prefix], dtype=torch.int32, device=dev())
+    d_bits = torch.from_numpy(bits.view(np.int64)).to(dev())
+    O = torch.zeros(M, H * hd, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_tree_attention(engine.h, stream(), p(Q), H * hd, p(Kc), p(Vc), S, H, Hkv, hd, M, p(d_prefix), tail,
+                                      p(d_bits) if tail else None, p(O), H * hd, eager))
+    torch.cuda.synchronize()
+    # P is rounded to bf16 against a different (chunk-local) max than the oracle's global one, and eager mode also
+    # rounds the scores: 2 ulp at the summand scale; about half of the outputs are bit-identical
+    assert_bf16_close(fn(O), want, min_exact=0.40, ulps=2, scale=scale)
+
+
+def test_argmax_rows_first_max_wins(lib):
+    rng = np.random.default_rng(5)
+    M, V = 30, 32064
+    x = synth.bf16_grid(rng.standard_normal((M, V), dtype=np.float32) * 4)
+    x[3, 100] = x[3, 20000] = 99.0  # tie -> lowest index
+    x[4, V - 1] = 120.0
+    x[5, 0] = 120.0
+    X = tb(x)
+    out = torch.zeros(M, dtype=torch.int32, device=dev())
+    L.check(lib.vispec_argmax_rows(None, stream(), p(X), V, M, V, p(out)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), np.argmax(x, axis=1))
+    assert out[3].item() == 100 and out[4].item() == V - 1 and out[5].item() == 0
+
+
+@pytest.mark.parametrize("M,V,k", [(1, 32064, 8), (8, 1008, 8), (8, 152064, 8), (3, 1008, 16)])
+def test_logsoftmax_topk(lib, M, V, k):
+    rng = np.random.default_rng(V + M)
+    o = vo.Ops(True)
+    x = synth.bf16_grid(rng.standard_normal((M, V), dtype=np.float32) * 3)
+    x[0, 7] = x[0, 900] = x[0, 901] = 30.0  # ties inside the top-k
+    X = tb(x)
+    idx = torch.zeros(M, k, dtype=torch.int32, device=dev())
+    lp = torch.zeros(M, k, dtype=torch.float32, device=dev())
+    L.check(lib.vispec_logsoftmax_topk(None, stream(), p(X), V, M, V, k, p(idx), p(lp)))
+    torch.cuda.synchronize()
+    want = o.log_softmax(x)
+    got_lp, got_idx = lp.cpu().numpy(), idx.cpu().numpy()
+    for r in range(M):
+        wv, wi = vo.topk_desc(want[r], k)
+        # the kernel's fp32 log-sum-exp uses fast exp/log: values may sit one bf16 ulp away, which can permute
+        # neighbours that the oracle separates by exactly that ulp; require set-equality on a 1-ulp-tolerant basis
+        assert_bf16_close(got_lp[r], wv, min_exact=0.0, ulps=1)
+        recomputed = want[r][got_idx[r]]
+        assert_bf16_close(recomputed, got_lp[r], min_exact=0.0, ulps=1)
+        assert len(set(got_idx[r].tolist())) == k
+        assert (np.diff(got_lp[r]) <= 0).all()
+    assert got_idx[0, :3].tolist() == [7, 900, 901]

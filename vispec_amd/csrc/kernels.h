@@ -1,0 +1,546 @@
+// Device kernels of libvispec_hip (gfx950 / CDNA4 only: wave64, MFMA bf16, 160 KiB LDS).
+// Numerics contract (matches oracle/vispec_oracle.py in bf16 mode): bf16 storage, fp32 accumulation,
+// round-to-nearest-even to bf16 wherever the reference's torch-bf16 graph materialises a tensor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define NEG_INF (-__builtin_huge_valf())
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rdbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return *reinterpret_cast<bf16x8*>(&v); }
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident round state: nothing here ever needs the host between rounds.
+// ------------------------------------------------------------------------------------------------
+struct DevState {
+  int n_ctx;        // committed context length n (tokens[0..n) are final; target KV rows [0,n) valid)
+  int n_prev;       // n before the last accept (base of the last verify's KV rows)
+  int accept_len;   // a of the last round
+  int best;         // best candidate row of the last round
+  int next_token;   // token sampled by the target after the accepted prefix (root of the next tree)
+  int new_token;    // generated tokens so far (spec_model_ours.py:476, utils.py:582)
+  int rounds;
+  int done;         // bit0: eos seen (spec_model_ours.py:544)  bit1: new_token > max_new_tokens (:546)
+  int max_new_tokens;
+  int eos_token_id;
+  int draft_len;    // n_c : rows of the draft's stable KV (cnets_ours.py:1108)
+  int draft_real_len; // position base of the next catch-up row (cnets_ours.py:416-418, 862-867)
+  int n_leaf, max_depth; // shape of the current tree's retrieve table
+  int tree_T;       // nodes in the current tree (total_token, or 1 for the AR baseline)
+  int pad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 64; weights streamed once from HBM, HBM-bound)
+//   one workgroup = 16 W rows (one 16x16x32 MFMA A-tile per 32 k) ; its 4 waves split K in 128-byte
+//   chunks and are reduced through LDS (deterministic, no atomics).  D[i=n][j=m]: lane holds 4
+//   consecutive n for one m -> 8-byte stores.
+// ------------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
+
+template <int MB, int EPI, int UNROLL>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, int ldx,
+                                                          const bf16_t* __restrict__ W,
+                                                          const bf16_t* __restrict__ bias, bf16_t* __restrict__ Y,
+                                                          int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N,
+                                                          int K) {
+  constexpr int NACC = (EPI == EPI_SWIGLU) ? 2 : 1;
+  __shared__ float red[4][NACC][MB][64][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nchunks = K >> 6;  // 64 k (=128 B per W row) per chunk
+  const bf16_t* w0 = W + (size_t)(n0 + i) * K + g * 8;
+  const bf16_t* w1 = (EPI == EPI_SWIGLU) ? W + (size_t)(N + n0 + i) * K + g * 8 : nullptr;
+  const bf16_t* xr[MB];
+  bool xv[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = mb * 16 + i;
+    xv[mb] = m < M;
+    xr[mb] = X + (size_t)(xv[mb] ? m : 0) * ldx + g * 8;
+  }
+  f32x4 acc[NACC][MB];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[a][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  int c = wave;
+  for (; c + 4 * (UNROLL - 1) < nchunks; c += 4 * UNROLL) {
+    uint4 a[NACC][UNROLL][2];
+    uint4 b[MB][UNROLL][2];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int k0 = (c + 4 * u) << 6;
+      a[0][u][0] = *reinterpret_cast<const uint4*>(w0 + k0);
+      a[0][u][1] = *reinterpret_cast<const uint4*>(w0 + k0 + 32);
+      if (EPI == EPI_SWIGLU) {
+        a[NACC - 1][u][0] = *reinterpret_cast<const uint4*>(w1 + k0);
+        a[NACC - 1][u][1] = *reinterpret_cast<const uint4*>(w1 + k0 + 32);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        b[mb][u][0] = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0) : zero4;
+        b[mb][u][1] = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0 + 32) : zero4;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int aa = 0; aa < NACC; ++aa)
+            acc[aa][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[aa][u][h]), as_bf16x8(b[mb][u][h]),
+                                                                  acc[aa][mb], 0, 0, 0);
+  }
+  for (; c < nchunks; c += 4) {
+    const int k0 = c << 6;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4 a0 = *reinterpret_cast<const uint4*>(w0 + k0 + 32 * h);
+      uint4 a1 = zero4;
+      if (EPI == EPI_SWIGLU) a1 = *reinterpret_cast<const uint4*>(w1 + k0 + 32 * h);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        uint4 bb = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0 + 32 * h) : zero4;
+        acc[0][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(bb), acc[0][mb], 0, 0, 0);
+        if (EPI == EPI_SWIGLU)
+          acc[NACC - 1][mb] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(bb), acc[NACC - 1][mb], 0, 0, 0);
+      }
+    }
+  }
+  // cross-wave (split-K) reduction through LDS, fixed order wave0+wave1+wave2+wave3
+#pragma unroll
+  for (int aa = 0; aa < NACC; ++aa)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][aa][mb][lane][r] = acc[aa][mb][r];
+  __syncthreads();
+  for (int mb = wave; mb < MB; mb += 4) {
+    const int m = mb * 16 + i;
+    float v[NACC][4];
+#pragma unroll
+    for (int aa = 0; aa < NACC; ++aa)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[aa][r] = ((red[0][aa][mb][lane][r] + red[1][aa][mb][lane][r]) + red[2][aa][mb][lane][r]) + red[3][aa][mb][lane][r];
+    if (m < M) {
+      const int n = n0 + g * 4;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = v[0][r];
+        if (bias) y += bf2f(bias[n + r]);
+        y = rdbf(y);
+        if (EPI == EPI_SWIGLU) {
+          float u = v[NACC - 1][r];
+          if (bias) u += bf2f(bias[N + n + r]);
+          u = rdbf(u);
+          float act = rdbf(y / (1.0f + __expf(-y)));
+          y = rdbf(act * u);
+        }
+        if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+        o[r] = y;
+      }
+      uint2 st = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+      *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = st;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm: y = w * bf16( x * rsqrt(mean(x^2) + eps) )     one workgroup per row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ Y, int D, float eps) {
+  __shared__ float part[4];
+  const bf16_t* x = X + (size_t)blockIdx.x * D;
+  bf16_t* y = Y + (size_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(x + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = bf2f(e[j]);
+      ss += f * f;
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = (part[0] + part[1]) + (part[2] + part[3]);
+  float inv = 1.0f / sqrtf(tot / (float)D + eps);
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(x + d);
+    uint4 wv = *reinterpret_cast<const uint4*>(w + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f(we[j]) * rdbf(bf2f(e[j]) * inv);
+    uint4 st = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+    *reinterpret_cast<uint4*>(y + d) = st;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree-masked attention, flash-decoding style.  hd = 128.
+//   grid (nsplit, H_kv), 256 threads.  A workgroup stages 128-key chunks of K and V of one KV head in LDS
+//   (coalesced 16-byte loads, XOR-swizzled rows), each wave owns one 32-key tile per chunk:
+//     S^T[key][q]  = K_tile · Q^T           8x mfma_32x32x16 (A = K from LDS, B = Q held in registers)
+//     online softmax per query column (the 16 scores a lane holds all belong to ONE query; the other 16 are in lane^32)
+//     O^T[hd][q]  += V_tile^T · P^T         8x mfma_32x32x16 (A = V^T gathered from LDS, B = P in registers)
+//   The 4 waves' partial (m, l, O) are merged through LDS and written as one partial per (q-tile, split).
+//   Visibility: key < prefix -> visible to all rows; prefix <= key < prefix+tail -> bit (key-prefix) of mask[row].
+// ------------------------------------------------------------------------------------------------
+#define ATT_CHUNK 128
+__device__ __forceinline__ int att_swz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 15) << 4)); }
+
+template <bool EAGER>
+__global__ __launch_bounds__(256) void tree_attn_partial_kernel(
+    const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vc, int s_max, int H,
+    int H_kv, int M, const int* __restrict__ prefix_dev, int tail, const unsigned long long* __restrict__ mask,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int keys_per_wg, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;                          // 32 KB (aliased by the merge buffer at the end)
+  unsigned char* sV = smem + ATT_CHUNK * 256;        // 32 KB
+  float* sM = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 256);  // [4][32] m, then [4][32] l
+  const int split = blockIdx.x, kvh = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, hi = lane >> 5;
+  const int n_prefix = prefix_dev ? *prefix_dev : 0;
+  const int n_total = n_prefix + tail;
+  const int key0 = split * keys_per_wg;
+  if (key0 >= n_total) return;
+  const int key_end = min(key0 + keys_per_wg, n_total);
+  const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
+  const bf16_t* Kh = Kc + (size_t)kvh * s_max * 128;
+  const bf16_t* Vh = Vc + (size_t)kvh * s_max * 128;
+  const int nchunk = (key_end - key0 + ATT_CHUNK - 1) / ATT_CHUNK;
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float sqrt_hd = 11.313708498984761f;
+
+  for (int qt = 0; qt < NQT; ++qt) {
+    const int head = kvh * G + qt / MT, m0 = (qt % MT) * 32;
+    const int mrow = m0 + j;
+    const bool qvalid = mrow < M;
+    uint4 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(Q + (size_t)mrow * ldq + head * 128 + ks * 16 + hi * 8)
+                      : make_uint4(0, 0, 0, 0);
+    const unsigned long long mbits = (qvalid && mask) ? mask[mrow] : 0ull;
+    float m_run = NEG_INF, l_run = 0.f;
+    f32x16 O[4];
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[hb][r] = 0.f;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int c0 = key0 + ch * ATT_CHUNK;
+      {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int s = p * 256 + threadIdx.x, row = s >> 4, c16 = s & 15;
+          const int key = c0 + row;
+          uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
+          if (key < key_end) {
+            kv4 = *reinterpret_cast<const uint4*>(Kh + (size_t)key * 128 + c16 * 8);
+            vv4 = *reinterpret_cast<const uint4*>(Vh + (size_t)key * 128 + c16 * 8);
+          }
+          *reinterpret_cast<uint4*>(sK + att_swz(row, c16 * 16)) = kv4;
+          *reinterpret_cast<uint4*>(sV + att_swz(row, c16 * 16)) = vv4;
+        }
+        __syncthreads();
+      }
+      const int kbase = c0 + wave * 32;
+      if (kbase < key_end) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        const int krow = wave * 32 + j;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
+          S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
+        }
+        float sc[16];
+        float mx = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          float s = EAGER ? rdbf(rdbf(S[r]) / sqrt_hd) : S[r] * scale;
+          bool vis = key < n_prefix;
+          if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
+          s = vis ? s : NEG_INF;
+          sc[r] = s;
+          mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
+        float psum = 0.f;
+        unsigned pb[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float p0 = (sc[r] == NEG_INF) ? 0.f : __expf(sc[r] - m_new);
+          float p1 = (sc[r + 1] == NEG_INF) ? 0.f : __expf(sc[r + 1] - m_new);
+          psum += p0 + p1;
+          pb[r >> 1] = pack2(p0, p1);
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[hb][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          uint4 pB = make_uint4(pb[kb * 4 + 0], pb[kb * 4 + 1], pb[kb * 4 + 2], pb[kb * 4 + 3]);
+#pragma unroll
+          for (int hb = 0; hb < 4; ++hb) {
+            unsigned va[4];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+              const int ta = 2 * t2, tb = 2 * t2 + 1;
+              const int ra = wave * 32 + (ta & 3) + 8 * (ta >> 2) + 4 * hi + 16 * kb;
+              const int rb = wave * 32 + (tb & 3) + 8 * (tb >> 2) + 4 * hi + 16 * kb;
+              const unsigned lo = *reinterpret_cast<const bf16_t*>(sV + att_swz(ra, (hb * 32 + j) * 2));
+              const unsigned hi16 = *reinterpret_cast<const bf16_t*>(sV + att_swz(rb, (hb * 32 + j) * 2));
+              va[t2] = lo | (hi16 << 16);
+            }
+            uint4 vA = make_uint4(va[0], va[1], va[2], va[3]);
+            O[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vA), as_bf16x8(pB), O[hb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- merge the 4 waves' (m, l, O) ----
+    __syncthreads();  // all waves done with sK/sV of the last chunk
+    if (hi == 0) {
+      sM[wave * 32 + j] = m_run;
+    }
+    __syncthreads();
+    float m_all = fmaxf(fmaxf(sM[j], sM[32 + j]), fmaxf(sM[64 + j], sM[96 + j]));
+    const float f = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_all);
+    if (hi == 0) sM[128 + wave * 32 + j] = l_run * f;
+    float* sO = reinterpret_cast<float*>(sK);  // [128 hd][32 q] fp32 = 16 KB
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int drow = hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float v = O[hb][r] * f;
+            if (w == 0) sO[drow * 32 + j] = v; else sO[drow * 32 + j] += v;
+          }
+      }
+      __syncthreads();
+    }
+    const size_t pidx = ((size_t)(kvh * NQT + qt) * nsplit + split);
+    float* po = part_o + pidx * (128 * 32);
+    for (int e = threadIdx.x; e < 128 * 32; e += 256) po[e] = sO[e];
+    if (threadIdx.x < 32) {
+      float l_all = (sM[128 + threadIdx.x] + sM[160 + threadIdx.x]) + (sM[192 + threadIdx.x] + sM[224 + threadIdx.x]);
+      part_ml[pidx * 64 + threadIdx.x] = m_all;  // every lane with the same j computed the same m_all
+      part_ml[pidx * 64 + 32 + threadIdx.x] = l_all;
+    }
+    __syncthreads();
+  }
+}
+
+// merge partials over splits: grid (H*MT), 256 threads
+__global__ __launch_bounds__(256) void tree_attn_reduce_kernel(const float* __restrict__ part_o,
+                                                               const float* __restrict__ part_ml, int H, int H_kv, int M,
+                                                               const int* __restrict__ prefix_dev, int tail,
+                                                               int keys_per_wg, int nsplit, bf16_t* __restrict__ out,
+                                                               int ldo) {
+  __shared__ float wgt[64][32];
+  __shared__ float linv[32];
+  const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
+  const int head = blockIdx.x / MT, mt = blockIdx.x % MT;
+  const int kvh = head / G, qt = (head % G) * MT + mt;
+  const int n_total = (prefix_dev ? *prefix_dev : 0) + tail;
+  const int ns = min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg);
+  const size_t base = (size_t)(kvh * NQT + qt) * nsplit;
+  if (threadIdx.x < 32) {
+    const int q = threadIdx.x;
+    float mm = NEG_INF;
+    for (int s = 0; s < ns; ++s) mm = fmaxf(mm, part_ml[(base + s) * 64 + q]);
+    float L = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      float ms = part_ml[(base + s) * 64 + q];
+      float w = (ms == NEG_INF) ? 0.f : __expf(ms - mm);
+      wgt[s][q] = w;
+      L += w * part_ml[(base + s) * 64 + 32 + q];
+    }
+    linv[q] = (L > 0.f) ? 1.0f / L : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 128 * 32; e += 256) {
+    const int d = e >> 5, q = e & 31;
+    float acc = 0.f;
+    for (int s = 0; s < ns; ++s) acc += wgt[s][q] * part_o[(base + s) * (128 * 32) + e];
+    const int m = mt * 32 + q;
+    if (m < M) out[(size_t)m * ldo + head * 128 + d] = f2bf(acc * linv[q]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row gathers / small elementwise helpers
+// ------------------------------------------------------------------------------------------------
+// out[i, col0 : col0+D] = table[idx(i)] ; idx from a device int array (+ optional device base offset)
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ table, int ld_t, const int* __restrict__ idx, int idx_off,
+                                   const int* __restrict__ idx_base_dev, bf16_t* __restrict__ out, int ld_o, int D) {
+  const int i = blockIdx.x;
+  int r = idx ? idx[(idx_base_dev ? *idx_base_dev : 0) + idx_off + i] : (idx_base_dev ? *idx_base_dev : 0) + idx_off + i;
+  const bf16_t* src = table + (size_t)r * ld_t;
+  bf16_t* dst = out + (size_t)i * ld_o;
+  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8)
+    *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(src + d);
+}
+// out[i, :] = vec (broadcast one row) ; used for the global image feature g (cnets_ours.py:984)
+__global__ void bcast_row_kernel(const bf16_t* __restrict__ vec, bf16_t* __restrict__ out, int ld_o, int D) {
+  bf16_t* dst = out + (size_t)blockIdx.x * ld_o;
+  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8)
+    *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(vec + d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-wise argmax (first max wins) and log-softmax + top-k (value desc, index asc) over bf16 logits
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+                                                          int* __restrict__ out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const bf16_t* x = logits + (size_t)blockIdx.x * ld;
+  float bv = NEG_INF;
+  int bi = 0x7fffffff;
+  for (int d = threadIdx.x * 8; d < V; d += 256 * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(x + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (d + j < V) {
+        float f = bf2f(e[j]);
+        if (better(f, d + j, bv, bi)) { bv = f; bi = d + j; }
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o);
+    int oi = __shfl_xor(bi, o);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
+#define TOPK_MAX 16
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k,
+                                                              int* __restrict__ out_idx, float* __restrict__ out_logp) {
+  __shared__ float s_red[4];
+  __shared__ float s_v[256 * TOPK_MAX];
+  __shared__ int s_i[256 * TOPK_MAX];
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4], s_bs[4];
+  const bf16_t* x = logits + (size_t)blockIdx.x * ld;
+  const int tid = threadIdx.x;
+  // pass 1: max ; pass 2: sum exp  (fp32, like torch's log_softmax on a bf16 tensor)
+  float mx = NEG_INF;
+  for (int d = tid; d < V; d += 256) mx = fmaxf(mx, bf2f(x[d]));
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int d = tid; d < V; d += 256) se += __expf(bf2f(x[d]) - mx);
+  se = wave_sum(se);
+  if ((tid & 63) == 0) s_red[tid >> 6] = se;
+  __syncthreads();
+  const float lse = mx + __logf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  // pass 3: per-thread top-k of bf16(x - lse) (sorted insertion), then k rounds of block-wide selection
+  float tv[TOPK_MAX];
+  int ti[TOPK_MAX];
+#pragma unroll
+  for (int q = 0; q < TOPK_MAX; ++q) { tv[q] = NEG_INF; ti[q] = 0x7fffffff; }
+  for (int d = tid; d < V; d += 256) {
+    float lp = rdbf(bf2f(x[d]) - lse);
+    if (better(lp, d, tv[TOPK_MAX - 1], ti[TOPK_MAX - 1])) {
+      tv[TOPK_MAX - 1] = lp; ti[TOPK_MAX - 1] = d;
+#pragma unroll
+      for (int q = TOPK_MAX - 1; q > 0; --q)
+        if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+          float a = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = a;
+          int b = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = b;
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < TOPK_MAX; ++q) { s_v[tid * TOPK_MAX + q] = tv[q]; s_i[tid * TOPK_MAX + q] = ti[q]; }
+  int head = 0;  // next unconsumed entry of this thread's sorted list
+  __syncthreads();
+  for (int sel = 0; sel < k; ++sel) {
+    float bv = (head < TOPK_MAX) ? s_v[tid * TOPK_MAX + head] : NEG_INF;
+    int bi = (head < TOPK_MAX) ? s_i[tid * TOPK_MAX + head] : 0x7fffffff;
+    int bs = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(bv, o);
+      int oi = __shfl_xor(bi, o);
+      int os = __shfl_xor(bs, o);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bs = os; }
+    }
+    if ((tid & 63) == 0) { s_bv[tid >> 6] = bv; s_bi[tid >> 6] = bi; s_bs[tid >> 6] = bs; }
+    __syncthreads();
+    float gv = s_bv[0]; int gi = s_bi[0], gs = s_bs[0];
+    for (int w = 1; w < 4; ++w)
+      if (better(s_bv[w], s_bi[w], gv, gi)) { gv = s_bv[w]; gi = s_bi[w]; gs = s_bs[w]; }
+    if (tid == gs) ++head;
+    if (tid == 0) { out_idx[blockIdx.x * k + sel] = gi; out_logp[blockIdx.x * k + sel] = gv; }
+    __syncthreads();
+  }
+}

@@ -1,0 +1,294 @@
+// Token-tree bookkeeping on the device (integer logic, exact restatement of the reference's host code):
+//   draft side  : cnets_ours.py:1109-1238  (level expansion, global re-rank, parents, mask, positions, retrieve table)
+//   target side : utils.py:415-451 (greedy evaluate_posterior) and utils.py:496-556 (update_inference_inputs)
+// Every kernel here is a single small workgroup; they exist so that a round never returns to the host.
+#pragma once
+#include "kernels.h"
+
+#define TREE_MAX_T 64      // nodes in the verify tree (total_token <= 64 -> one 64-bit mask word per row)
+#define TREE_MAX_K 16      // top_k
+#define TREE_MAX_DEPTH 8   // depth
+#define TREE_MAX_SCORES (TREE_MAX_K + TREE_MAX_DEPTH * TREE_MAX_K * TREE_MAX_K)
+#define TREE_RET_W (TREE_MAX_DEPTH + 2)  // width of a retrieve row (root + depth+1 levels)
+
+struct TreeBufs {
+  // growing lists (cnets_ours.py:1062-1064)
+  float* scores_all;   // [k + depth*k*k]   bf16-rounded cumulative log-probs
+  int* tokens_all;     // [k + depth*k*k]
+  int* parents_all;    // [1 + depth*k]
+  // frontier
+  float* cur_scores;   // [k]
+  int* cs_idx;         // [k]   topk_cs_index of the previous level
+  int* in_ids;         // [k]   tokens fed to the next level forward
+  unsigned long long* lvl_mask;  // [k]  visibility of the tail keys for the next level forward
+  // finished tree (what verify consumes)
+  int* tree_tokens;    // [T]
+  int* tree_pos;       // [T]   depth of each node (tree_position_ids)
+  unsigned long long* tree_mask;  // [T]
+  int* retrieve;       // [T][TREE_RET_W]  padded with -1
+  int* mask_index;     // [T]  parent row of node i+1 (scratch, kept for the tests)
+};
+
+// Level 1 (cnets_ours.py:1114-1123): the k children of the root come from the last hidden state's top-k.
+__global__ void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
+                                 const bf16_t* __restrict__ last_hidden, bf16_t* __restrict__ in_h, int D) {
+  const int tid = threadIdx.x;
+  if (tid < k) {
+    tb.scores_all[tid] = top_logp[tid];
+    tb.tokens_all[tid] = top_idx[tid];
+    tb.cur_scores[tid] = top_logp[tid];
+    tb.cs_idx[tid] = tid;
+    tb.in_ids[tid] = top_idx[tid];
+    tb.lvl_mask[tid] = 1ull << tid;  // tree_mask_init = eye(k)
+  }
+  if (tid == 0) tb.parents_all[0] = 0;
+  for (int e = tid * 8; e < k * D; e += blockDim.x * 8) {  // input_hidden = last_hidden.repeat(k)
+    const int d = e % D, r = e / D;
+    *reinterpret_cast<uint4*>(in_h + (size_t)r * D + d) = *reinterpret_cast<const uint4*>(last_hidden + d);
+  }
+}
+
+// One tree level (cnets_ours.py:1139-1165) after the level forward + LM head + per-row top-k.
+__global__ __launch_bounds__(256) void tree_level_kernel(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
+                                                         const float* __restrict__ top_logp,
+                                                         const bf16_t* __restrict__ out_hidden, bf16_t* __restrict__ in_h,
+                                                         int D) {
+  __shared__ float cu[TREE_MAX_K * TREE_MAX_K];
+  __shared__ int sel[TREE_MAX_K];
+  __shared__ unsigned long long newmask[TREE_MAX_K];
+  const int tid = threadIdx.x, kk = k * k;
+  const int base = k + level * kk;
+  if (tid < k) {
+    const int bias = 1 + kk * max(0, level - 1) + (level > 0 ? k : 0);
+    tb.parents_all[1 + level * k + tid] = tb.cs_idx[tid] + bias;
+  }
+  if (tid < kk) {
+    const float c = rdbf(top_logp[tid] + tb.cur_scores[tid / k]);  // cu_scores = topk_p + scores[:, None] (bf16 add)
+    cu[tid] = c;
+    tb.scores_all[base + tid] = c;
+    tb.tokens_all[base + tid] = top_idx[tid];
+  }
+  __syncthreads();
+  if (tid < kk) {  // rank by (value desc, index asc)
+    const float c = cu[tid];
+    int rank = 0;
+    for (int o = 0; o < kk; ++o) rank += (cu[o] > c) || (cu[o] == c && o < tid);
+    if (rank < k) sel[rank] = tid;
+  }
+  __syncthreads();
+  if (tid < k) {
+    const int s = sel[tid], parent_row = s / k;
+    newmask[tid] = tb.lvl_mask[parent_row] | (1ull << (k * (level + 1) + tid));
+  }
+  __syncthreads();
+  if (tid < k) {
+    const int s = sel[tid];
+    tb.cur_scores[tid] = cu[s];
+    tb.cs_idx[tid] = s;
+    tb.in_ids[tid] = top_idx[s];
+    tb.lvl_mask[tid] = newmask[tid];
+  }
+  for (int e = tid * 8; e < k * D; e += 256 * 8) {  // input_hidden = out_hidden[:, out_ids]
+    const int d = e % D, r = e / D;
+    *reinterpret_cast<uint4*>(in_h + (size_t)r * D + d) =
+        *reinterpret_cast<const uint4*>(out_hidden + (size_t)(sel[r] / k) * D + d);
+  }
+}
+
+// Global re-rank and tree construction (cnets_ours.py:1167-1213).  total = total_token-1.
+__global__ __launch_bounds__(256) void tree_finalize_kernel(TreeBufs tb, DevState* st, int k, int depth, int total,
+                                                            int sampling) {
+  __shared__ float sc[TREE_MAX_SCORES];
+  __shared__ unsigned char keep[TREE_MAX_SCORES];
+  __shared__ int top_idx[TREE_MAX_T];
+  __shared__ int midx[TREE_MAX_T];
+  __shared__ unsigned long long rows[TREE_MAX_T];
+  __shared__ unsigned char nonleaf[TREE_MAX_T];
+  const int tid = threadIdx.x;
+  const int n_all = k + depth * k * k, T = total + 1;
+  for (int e = tid; e < n_all; e += 256) sc[e] = tb.scores_all[e];
+  __syncthreads();
+  for (int e = tid; e < n_all; e += 256) {  // top-`total` by (value desc, index asc)   :1169
+    const float c = sc[e];
+    int rank = 0;
+    for (int o = 0; o < n_all; ++o) rank += (sc[o] > c) || (sc[o] == c && o < e);
+    keep[e] = rank < total;
+  }
+  __syncthreads();
+  for (int e = tid; e < n_all; e += 256)  // ascending flat index = torch.sort(top_scores_index)   :1171
+    if (keep[e]) {
+      int p = 0;
+      for (int o = 0; o < e; ++o) p += keep[o];
+      top_idx[p] = e;
+    }
+  __syncthreads();
+  if (tid < total) {
+    const int e = top_idx[tid];
+    tb.tree_tokens[1 + tid] = tb.tokens_all[e];  // :1173-1174
+    const int par = tb.parents_all[e / k];       // :1176
+    int mi;
+    if (par == 0) mi = 0;                        // :1180-1181
+    else {                                       // searchsorted(top_idx, par-1, right=False) + 1   :1177-1181
+      const int v = par - 1;
+      int lo = 0, hi2 = total;
+      while (lo < hi2) { int mid = (lo + hi2) >> 1; if (top_idx[mid] < v) lo = mid + 1; else hi2 = mid; }
+      mi = lo + 1;
+    }
+    midx[tid] = mi;
+    tb.mask_index[tid] = mi;
+  }
+  if (tid == 0) tb.tree_tokens[0] = st->next_token;  // sample_token is the root   :1060,1174
+  if (tid < T) nonleaf[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {  // ancestors-or-self, sequential like the reference loop   :1183-1186
+    rows[0] = 1ull;
+    for (int i = 0; i < total; ++i) {
+      const int mi = midx[i];
+      unsigned long long r = (1ull << (i + 1)) | 1ull;
+      if (mi <= i) r |= rows[mi];  // (mi == i+1 would be the row itself: no-op)
+      rows[i + 1] = r;
+    }
+  }
+  if (tid < total) {
+    const int mi = midx[tid];
+    if (mi < T) nonleaf[mi] = 1;  // noleaf_index = unique(mask_index)   :1196
+  }
+  __syncthreads();
+  if (tid < T) {
+    tb.tree_mask[tid] = rows[tid];
+    tb.tree_pos[tid] = __popcll(rows[tid]) - 1;  // :1188
+  }
+  for (int e = tid; e < TREE_MAX_T * TREE_RET_W; e += 256) tb.retrieve[e] = -1;
+  __syncthreads();
+  if (tid == 0) {  // leaf paths   :1195-1213
+    int rid = 0, maxd = 0;
+    for (int i = 0; i < T; ++i) maxd = max(maxd, __popcll(rows[i]) - 1);
+    for (int i = 0; i < T; ++i) {
+      if (nonleaf[i]) continue;
+      int cid = i;
+      const int d = __popcll(rows[i]) - 1;
+      for (int jj = d; jj >= 0; --jj) {
+        tb.retrieve[rid * TREE_RET_W + jj] = cid;
+        cid = (cid > 0) ? midx[cid - 1] : 0;
+      }
+      ++rid;
+    }
+    if (sampling && rid > 1) {  // :1215-1224 lexicographic row sort with -1 -> large (insertion sort, rid <= T)
+      const int big = total + 5;
+      for (int a = 1; a < rid; ++a) {
+        int row[TREE_RET_W];
+        for (int c = 0; c < TREE_RET_W; ++c) row[c] = tb.retrieve[a * TREE_RET_W + c];
+        int b = a - 1;
+        while (b >= 0) {
+          bool gt = false;
+          for (int c = 0; c < maxd + 1; ++c) {
+            int x = tb.retrieve[b * TREE_RET_W + c], y = row[c];
+            x = x >= 0 ? x : big; y = y >= 0 ? y : big;
+            if (x != y) { gt = x > y; break; }
+          }
+          if (!gt) break;
+          for (int c = 0; c < TREE_RET_W; ++c) tb.retrieve[(b + 1) * TREE_RET_W + c] = tb.retrieve[b * TREE_RET_W + c];
+          --b;
+        }
+        for (int c = 0; c < TREE_RET_W; ++c) tb.retrieve[(b + 1) * TREE_RET_W + c] = row[c];
+      }
+    }
+    st->n_leaf = rid;
+    st->max_depth = maxd + 1;
+    st->tree_T = T;
+  }
+}
+
+// A one-node "tree" = plain autoregressive decoding with the same verify kernels (baseline_forward).
+__global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
+  if (threadIdx.x == 0) {
+    tb.tree_tokens[0] = st->next_token;
+    tb.tree_pos[0] = 0;
+    tb.tree_mask[0] = 1ull;
+    for (int c = 0; c < TREE_RET_W; ++c) tb.retrieve[c] = c == 0 ? 0 : -1;
+    st->n_leaf = 1;
+    st->max_depth = 1;
+    st->tree_T = 1;
+  }
+}
+
+// Greedy evaluate_posterior (utils.py:438-451) + the integer part of update_inference_inputs (utils.py:514-526,541,554,582)
+// am[i] = argmax of the target logits at tree node i.  sel[j] = tree node accepted at depth j (j = 0..a).
+__global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __restrict__ am, int* __restrict__ tokens,
+                                     int tokens_cap, int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
+                                     int forced_accept, int* __restrict__ draft_ids) {
+  __shared__ int acc[TREE_MAX_T];
+  const int tid = threadIdx.x;
+  const int n_leaf = st->n_leaf, md = st->max_depth;
+  if (tid < n_leaf) {
+    const int* row = tb.retrieve + tid * TREE_RET_W;
+    int a = 0;
+    for (int jj = 0; jj + 1 < md; ++jj) {
+      const int nxt = row[jj + 1];
+      const int cand = nxt >= 0 ? tb.tree_tokens[nxt] : -1;  // draft_tokens padded with -1   spec_model_ours.py:503-504
+      if (cand == am[row[jj]]) ++a; else break;             // cumprod of the posterior mask
+    }
+    if (forced_accept >= 0) {  // bench-only scripted acceptance: pretend the first `forced` draft tokens of the path matched
+      int len = 0;
+      for (int jj = 0; jj < md; ++jj) len += row[jj] >= 0;
+      a = min(forced_accept, len - 1);
+    }
+    acc[tid] = a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0, a = 0;
+    for (int r = 0; r < n_leaf; ++r)
+      if (acc[r] > a) { a = acc[r]; best = r; }  // first max; 0 if none accepted
+    const int* row = tb.retrieve + best * TREE_RET_W;
+    const int n = st->n_ctx;
+    int done = st->done;
+    for (int jj = 0; jj <= a; ++jj) {
+      const int node = row[jj];
+      sel[jj] = node;
+      const int tok = tb.tree_tokens[node];
+      if (n + jj < tokens_cap) tokens[n + jj] = tok;
+      if (tok == st->eos_token_id) done |= 1;
+    }
+    for (int jj = a + 1; jj < TREE_RET_W; ++jj) sel[jj] = row[a];
+    const int next = am[row[a]];  // token = argmax(sample_p), sample_p = logits[best, accept_length]
+    // ids the draft's catch-up rows are paired with: accepted tokens 1..a then the new sample (cnets_ours.py:1084,1093)
+    for (int jj = 0; jj < TREE_RET_W; ++jj)
+      draft_ids[jj] = jj < a ? tb.tree_tokens[row[jj + 1]] : next;
+    st->n_prev = n;
+    st->n_ctx = n + a + 1;
+    st->accept_len = a;
+    st->best = best;
+    st->next_token = next;
+    st->new_token += a + 1;
+    if (st->new_token > st->max_new_tokens) done |= 2;
+    st->done = done;
+    if (st->rounds < log_cap) accept_log[st->rounds] = a;
+    st->rounds += 1;
+  }
+}
+
+// KV compaction (utils.py:529-538): rows n+sel[j] -> n+j for j=1..a, for every (layer, k|v, head).
+// One wave per (slab, head): all sources are read into registers before anything is written (rows may overlap).
+__global__ __launch_bounds__(64) void kv_compact_kernel(bf16_t* __restrict__ kv, int s_max, const DevState* __restrict__ st,
+                                                        const int* __restrict__ sel) {
+  constexpr int HD = 128;
+  const int a = st->accept_len, n = st->n_prev;
+  if (a == 0) return;
+  bf16_t* base = kv + ((size_t)blockIdx.x * s_max + n) * HD;  // blockIdx.x = slab*H_kv + head
+  unsigned v[TREE_RET_W];
+#pragma unroll
+  for (int jj = 1; jj < TREE_RET_W; ++jj)
+    if (jj <= a) v[jj] = *reinterpret_cast<const unsigned*>(base + (size_t)sel[jj] * HD + threadIdx.x * 2);
+#pragma unroll
+  for (int jj = 1; jj < TREE_RET_W; ++jj)
+    if (jj <= a) *reinterpret_cast<unsigned*>(base + (size_t)jj * HD + threadIdx.x * 2) = v[jj];
+}
+
+// Draft-side bookkeeping after the catch-up forward: the a+1 new rows become part of stable_kv (cnets_ours.py:1108).
+__global__ void draft_advance_kernel(DevState* st) {
+  if (threadIdx.x == 0) {
+    st->draft_len += st->accept_len + 1;
+    st->draft_real_len += st->accept_len + 1;
+  }
+}

@@ -1,0 +1,735 @@
+// libvispec_hip: C-ABI + stream-ordered orchestration of the ViSpec draft-and-verify round on MI355X.
+// See include/vispec_hip.h for the contract and the reference functions each entry point replaces.
+#include "../../include/vispec_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "tree_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& s) {
+  g_err = s;
+  return -1;
+}
+#define HIPCHK(x)                                                                                          \
+  do {                                                                                                     \
+    hipError_t e_ = (x);                                                                                   \
+    if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+struct vispec_ctx {
+  vispec_config c;
+  std::vector<vispec_layer_weights> layers;
+  vispec_target_misc tm{};
+  vispec_draft_weights dw{};
+  bf16_t* target_kv = nullptr;
+  bf16_t* draft_kv = nullptr;
+  // ---- workspace (device) ----
+  DevState* st = nullptr;
+  int* tokens = nullptr;  // committed token ids [tokens_cap]
+  int tokens_cap = 0;
+  int* accept_log = nullptr;
+  int log_cap = 0;
+  // target verify buffers (64 rows each)
+  bf16_t *xa, *xn, *qkv, *attn_o, *act, *hidden_new, *logits;
+  int *am, *sel, *draft_ids;
+  bf16_t* accept_hidden;  // [16, D]
+  // draft buffers
+  bf16_t *dx1, *dx2, *dx, *dqkv, *dattn, *dh, *dn, *dact, *dout, *dlast, *in_h, *dlogits, *dg;
+  bf16_t *xc, *emb_shift, *ad_kv, *ad_out, *ad_tmp;  // prefill-only scratch
+  int *top_idx, *pos_c, *idx_tmp, *idx_img, *scratch_int;
+  int* h_pin = nullptr;  // pinned host staging for the prefill's index lists [3 * draft_max_pos]
+  float* top_logp;
+  unsigned long long* causal_mask;  // [64] row i sees tail keys 0..i
+  TreeBufs tb{};
+  // attention partials
+  float *part_o, *part_ml;
+  size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
+  int n_hint = 0;             // upper bound of keys any attention call of this request can see
+  std::vector<void*> allocs;
+};
+
+template <class T>
+static int dalloc(vispec_ctx* ctx, T** p, size_t n) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, n * sizeof(T) + 256));
+  HIPCHK(hipMemset(q, 0, n * sizeof(T) + 256));
+  ctx->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+extern "C" const char* vispec_last_error(void) { return g_err.c_str(); }
+extern "C" int vispec_version(void) { return 1; }
+
+#define ROWS 64
+extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
+  if (!cfg || !out) return fail("null argument");
+  const vispec_config& c = *cfg;
+  if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
+  if (c.hidden_size % 64 || c.intermediate_size % 64 || c.draft_intermediate % 64 || c.vocab_size % 16)
+    return fail("GEMM dims: K %% 64 == 0 and N %% 16 == 0 required");
+  if (c.total_token < 1 || c.total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
+  if (c.top_k < 1 || c.top_k > TREE_MAX_K || c.depth < 1 || c.depth > TREE_MAX_DEPTH) return fail("top_k<=16, depth<=8");
+  if (c.top_k * (c.depth + 1) > 64) return fail("top_k*(depth+1) must be <= 64 (one mask word per draft row)");
+  if (c.total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
+  if (c.hidden_size != c.draft_heads * c.head_dim) return fail("draft must be MHA with head_dim 128 over hidden_size");
+  if (c.num_heads % c.num_kv_heads) return fail("num_heads %% num_kv_heads != 0");
+  vispec_ctx* ctx = new vispec_ctx();
+  ctx->c = c;
+  ctx->layers.resize(c.num_layers);
+  const size_t D = c.hidden_size, I = c.intermediate_size, Id = c.draft_intermediate, V = c.vocab_size;
+  const size_t QKV = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
+#define A(p, n)                                   \
+  if (dalloc(ctx, &ctx->p, (n))) {                \
+    vispec_ctx_destroy(ctx);                      \
+    return -1;                                    \
+  }
+  A(st, 1);
+  ctx->tokens_cap = c.max_pos + 64;
+  A(tokens, ctx->tokens_cap);
+  ctx->log_cap = c.max_pos;
+  A(accept_log, ctx->log_cap);
+  A(xa, ROWS * D); A(xn, ROWS * D); A(qkv, ROWS * QKV); A(attn_o, ROWS * (size_t)c.num_heads * c.head_dim);
+  A(act, ROWS * I); A(hidden_new, ROWS * D); A(logits, ROWS * V);
+  A(am, ROWS); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D);
+  A(dx1, ROWS * 2 * D); A(dx2, ROWS * 2 * D); A(dx, ROWS * D); A(dqkv, ROWS * 3 * D); A(dattn, ROWS * D);
+  A(dh, ROWS * D); A(dn, ROWS * D); A(dact, ROWS * Id); A(dout, ROWS * D); A(dlast, 16 * D); A(in_h, 16 * D);
+  A(dlogits, 16 * V); A(dg, D);
+  A(xc, (size_t)c.draft_max_pos * D); A(emb_shift, (size_t)c.draft_max_pos * D);
+  A(ad_kv, (size_t)2 * c.draft_max_pos * D); A(ad_out, 16 * D); A(ad_tmp, ROWS * 2 * D);
+  A(top_idx, TREE_MAX_K * TREE_MAX_K); A(top_logp, TREE_MAX_K * TREE_MAX_K); A(pos_c, c.draft_max_pos);
+  A(idx_tmp, c.draft_max_pos); A(idx_img, c.draft_max_pos); A(scratch_int, 4);
+  if (hipHostMalloc((void**)&ctx->h_pin, sizeof(int) * 3 * (size_t)c.draft_max_pos) != hipSuccess) {
+    vispec_ctx_destroy(ctx);
+    return fail("hipHostMalloc failed");
+  }
+  A(causal_mask, 64);
+  {
+    unsigned long long cm[64];
+    for (int i = 0; i < 64; ++i) cm[i] = (i == 63) ? ~0ull : ((2ull << i) - 1ull);
+    if (hipMemcpy(ctx->causal_mask, cm, sizeof(cm), hipMemcpyHostToDevice) != hipSuccess) {
+      vispec_ctx_destroy(ctx);
+      return fail("causal mask upload failed");
+    }
+  }
+  A(tb.scores_all, TREE_MAX_SCORES); A(tb.tokens_all, TREE_MAX_SCORES); A(tb.parents_all, 1 + TREE_MAX_DEPTH * TREE_MAX_K);
+  A(tb.cur_scores, TREE_MAX_K); A(tb.cs_idx, TREE_MAX_K); A(tb.in_ids, TREE_MAX_K); A(tb.lvl_mask, TREE_MAX_K);
+  A(tb.tree_tokens, TREE_MAX_T); A(tb.tree_pos, TREE_MAX_T); A(tb.tree_mask, TREE_MAX_T);
+  A(tb.retrieve, TREE_MAX_T * TREE_RET_W); A(tb.mask_index, TREE_MAX_T);
+  {
+    // partial tiles: (H * ceil(64/32)) q-tiles x up to 64 splits
+    int maxpos = c.max_pos > c.draft_max_pos ? c.max_pos : c.draft_max_pos;
+    if (maxpos < 4096) maxpos = 4096;  // the unit-level C-ABI entry may be used with caches larger than this model's
+    const size_t nsplit = (size_t)(maxpos + 64 + 127) / 128 + 1;
+    const int heads = c.num_heads > 16 ? c.num_heads : 16;
+    ctx->part_cap_tiles = (size_t)heads * 2 * (nsplit > 64 ? 64 : nsplit);
+    A(part_o, ctx->part_cap_tiles * 128 * 32);
+    A(part_ml, ctx->part_cap_tiles * 64);
+  }
+#undef A
+  ctx->n_hint = c.max_pos;
+  const int lds = 2 * ATT_CHUNK * 256 + 1024;
+  if (hipFuncSetAttribute((const void*)tree_attn_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+          hipSuccess ||
+      hipFuncSetAttribute((const void*)tree_attn_partial_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+          hipSuccess) {
+    (void)hipGetLastError();  // a device-less build/load check must still be able to create nothing; report lazily
+  }
+  *out = ctx;
+  return 0;
+}
+
+extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
+  if (!ctx) return;
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  delete ctx;
+}
+
+extern "C" int vispec_set_target_layer(vispec_ctx* ctx, int layer, const vispec_layer_weights* w) {
+  if (!ctx || !w || layer < 0 || layer >= ctx->c.num_layers) return fail("bad layer");
+  ctx->layers[layer] = *w;
+  return 0;
+}
+extern "C" int vispec_set_target_misc(vispec_ctx* ctx, const vispec_target_misc* m) {
+  if (!ctx || !m) return fail("null");
+  ctx->tm = *m;
+  return 0;
+}
+extern "C" int vispec_set_draft_weights(vispec_ctx* ctx, const vispec_draft_weights* w) {
+  if (!ctx || !w) return fail("null");
+  ctx->dw = *w;
+  return 0;
+}
+extern "C" int vispec_set_kv(vispec_ctx* ctx, void* target_kv, void* draft_kv) {
+  if (!ctx) return fail("null");
+  ctx->target_kv = (bf16_t*)target_kv;
+  ctx->draft_kv = (bf16_t*)draft_kv;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+static int launch_gemm(hipStream_t s, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy, const void* R,
+                       int ldr, int M, int N, int K, int epi) {
+  if (M < 1 || M > 64) return fail("gemm_skinny: M must be in [1,64]");
+  if (N % 16 || K % 64) return fail("gemm_skinny: N %% 16 == 0 and K %% 64 == 0 required");
+  if (epi == EPI_RESIDUAL && !R) return fail("gemm_skinny: residual epilogue without R");
+  const int MB = (M + 15) / 16;
+  dim3 grid(N / 16), block(256);
+  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)W, *b = (const bf16_t*)bias, *r = (const bf16_t*)R;
+  bf16_t* y = (bf16_t*)Y;
+#define GO(MBV, EPIV, UN) \
+  hipLaunchKernelGGL((gemm_skinny_kernel<MBV, EPIV, UN>), grid, block, 0, s, x, ldx, w, b, y, ldy, r, ldr, M, N, K)
+#define BYEPI(MBV, UN)                                  \
+  switch (epi) {                                        \
+    case EPI_NONE: GO(MBV, EPI_NONE, UN); break;        \
+    case EPI_RESIDUAL: GO(MBV, EPI_RESIDUAL, UN); break; \
+    case EPI_SWIGLU: GO(MBV, EPI_SWIGLU, UN); break;    \
+    default: return fail("gemm_skinny: bad epilogue");  \
+  }
+  if (MB == 1) { BYEPI(1, 4) }
+  else if (MB == 2) { BYEPI(2, 4) }
+  else { BYEPI(4, 2) }
+#undef BYEPI
+#undef GO
+  KCHK();
+  return 0;
+}
+
+static int launch_rmsnorm(hipStream_t s, const void* X, const void* w, void* Y, int M, int D, float eps) {
+  if (D % 8) return fail("rmsnorm: D %% 8");
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, s, (const bf16_t*)X, (const bf16_t*)w, (bf16_t*)Y, D, eps);
+  KCHK();
+  return 0;
+}
+
+struct PosSpec {  // position = *base + add + (off ? off[m] : (row ? m : 0)) ; kv row = *kv_base + kv_add + m
+  const int* base = nullptr;
+  int add = 0;
+  const int* off = nullptr;
+  int row = 1;
+  const int* kv_base = nullptr;
+  int kv_add = 0;
+};
+
+__global__ __launch_bounds__(64) void rope_append2_kernel(bf16_t* __restrict__ qkv, int H, int H_kv,
+                                                          const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                                                          PosSpec ps, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                          int s_max, int do_rope) {
+  constexpr int HD = 128, HALF = 64;
+  const int m = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+  const int ld = (H + 2 * H_kv) * HD;
+  bf16_t* x = qkv + (size_t)m * ld + (size_t)h * HD;
+  const int row = (ps.kv_base ? *ps.kv_base : 0) + ps.kv_add + m;
+  if (h >= H + H_kv) {
+    bf16_t* dst = vc + ((size_t)(h - H - H_kv) * s_max + row) * HD;
+    dst[d] = x[d];
+    dst[d + HALF] = x[d + HALF];
+    return;
+  }
+  float x1 = bf2f(x[d]), x2 = bf2f(x[d + HALF]);
+  float o1 = x1, o2 = x2;
+  if (do_rope) {
+    const int pos = (ps.base ? *ps.base : 0) + ps.add + (ps.off ? ps.off[m] : (ps.row ? m : 0));
+    const float c = bf2f(cosT[(size_t)pos * HD + d]), sn = bf2f(sinT[(size_t)pos * HD + d]);
+    o1 = rdbf(rdbf(x1 * c) + rdbf(-x2 * sn));
+    o2 = rdbf(rdbf(x2 * c) + rdbf(x1 * sn));
+  }
+  if (h < H) {
+    x[d] = f2bf(o1);
+    x[d + HALF] = f2bf(o2);
+  } else {
+    bf16_t* dst = kc + ((size_t)(h - H) * s_max + row) * HD;
+    dst[d] = f2bf(o1);
+    dst[d + HALF] = f2bf(o2);
+  }
+}
+
+static int launch_rope(hipStream_t s, void* qkv, int M, int H, int H_kv, const void* cosT, const void* sinT, PosSpec ps,
+                       void* kc, void* vc, int s_max, int do_rope) {
+  hipLaunchKernelGGL(rope_append2_kernel, dim3(M, H + 2 * H_kv), dim3(64), 0, s, (bf16_t*)qkv, H, H_kv, (const bf16_t*)cosT,
+                     (const bf16_t*)sinT, ps, (bf16_t*)kc, (bf16_t*)vc, s_max, do_rope);
+  KCHK();
+  return 0;
+}
+
+// prefix = (prefix_dev ? *prefix_dev : 0) + prefix_add is folded by a tiny helper kernel into a scratch int when needed
+__global__ void add_scalar_kernel(const int* src, int add, int* dst) { *dst = (src ? *src : 0) + add; }
+
+static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int ldq, const void* kc, const void* vc, int s_max,
+                            int H, int H_kv, int M, const int* prefix_dev, int tail, const unsigned long long* mask, void* out,
+                            int ldo, int eager, int max_keys) {
+  if (M < 1 || M > 64) return fail("tree_attention: M must be in [1,64]");
+  if (tail < 0 || tail > 64) return fail("tree_attention: tail must be in [0,64]");
+  const int MT = (M + 31) / 32, NQT = (H / H_kv) * MT;
+  int kpw = (NQT == 1) ? 256 : 128;
+  if (max_keys < 1) max_keys = 1;
+  while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
+  const int nsplit = (max_keys + kpw - 1) / kpw;
+  if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
+  const int lds = 2 * ATT_CHUNK * 256 + 1024;
+  dim3 grid(nsplit, H_kv), block(256);
+  if (eager)
+    hipLaunchKernelGGL(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
+                       (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
+  else
+    hipLaunchKernelGGL(tree_attn_partial_kernel<false>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
+                       (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
+  KCHK();
+  hipLaunchKernelGGL(tree_attn_reduce_kernel, dim3(H * MT), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
+                     tail, kpw, nsplit, (bf16_t*)out, ldo);
+  KCHK();
+  return 0;
+}
+
+static int launch_gather(hipStream_t s, const void* table, int ld_t, const int* idx, int idx_off, const int* idx_base_dev,
+                         void* out, int ld_o, int rows, int D) {
+  if (D % 8) return fail("gather: D %% 8");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)table, ld_t, idx, idx_off, idx_base_dev,
+                     (bf16_t*)out, ld_o, D);
+  KCHK();
+  return 0;
+}
+static int launch_bcast(hipStream_t s, const void* vec, void* out, int ld_o, int rows, int D) {
+  hipLaunchKernelGGL(bcast_row_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)vec, (bf16_t*)out, ld_o, D);
+  KCHK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ unit-level C-ABI
+extern "C" int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y,
+                                  int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
+  return launch_gemm((hipStream_t)stream, X, ldx, W, bias, Y, ldy, R, ldr, M, N, K, epilogue);
+}
+extern "C" int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps) {
+  return launch_rmsnorm((hipStream_t)stream, X, w, Y, M, D, eps);
+}
+extern "C" int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cosT,
+                                  const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache,
+                                  void* v_cache, int s_max, const int* kv_base_dev) {
+  if (hd != 128) return fail("rope_append: head_dim must be 128");
+  PosSpec ps;
+  ps.base = pos_base_dev;
+  ps.off = pos_off_dev;
+  ps.kv_base = kv_base_dev;
+  return launch_rope((hipStream_t)stream, qkv, M, H, H_kv, cosT, sinT, ps, k_cache, v_cache, s_max, 1);
+}
+extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* q, int ldq, const void* k_cache,
+                                     const void* v_cache, int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev,
+                                     int tail, const uint64_t* mask_dev, void* out, int ldo, int eager_scores) {
+  if (!ctx) return fail("null ctx");
+  if (hd != 128) return fail("tree_attention: head_dim must be 128");
+  return launch_attention(ctx, (hipStream_t)stream, q, ldq, k_cache, v_cache, s_max, H, H_kv, M, prefix_dev, tail,
+                          (const unsigned long long*)mask_dev, out, ldo, eager_scores, s_max);
+}
+extern "C" int vispec_argmax_rows(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int* out_idx) {
+  if (V % 8 || ld % 8) return fail("argmax_rows: V and ld must be multiples of 8");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, out_idx);
+  KCHK();
+  return 0;
+}
+extern "C" int vispec_logsoftmax_topk(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int k, int* out_idx,
+                                      float* out_logp) {
+  if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, k,
+                     out_idx, out_logp);
+  KCHK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the path
+__global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos) {
+  if (threadIdx.x == 0) {
+    DevState z{};
+    z.n_ctx = L;
+    z.n_prev = L;
+    z.max_new_tokens = max_new;
+    z.eos_token_id = eos;
+    z.tree_T = 0;
+    *st = z;
+  }
+}
+__global__ void set_first_token_kernel(DevState* st, const int* tok, int draft_len, int real_len) {
+  if (threadIdx.x == 0) {
+    st->next_token = *tok;
+    st->draft_len = draft_len;
+    st->draft_real_len = real_len;
+  }
+}
+
+extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* prompt_ids_host, int L, int max_new_tokens) {
+  if (!ctx) return fail("null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  const vispec_config& c = ctx->c;
+  if (L < 1 || L + c.total_token + 8 > c.max_pos) return fail("prompt does not fit the KV cache");
+  if (prompt_ids_host) HIPCHK(hipMemcpyAsync(ctx->tokens, prompt_ids_host, sizeof(int) * L, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(begin_request_kernel, dim3(1), dim3(64), 0, s, ctx->st, L, max_new_tokens, c.eos_token_id);
+  KCHK();
+  long hint = (long)L + max_new_tokens + 2 * (c.depth + 2) + c.total_token + 64;
+  ctx->n_hint = (int)(hint < c.max_pos ? hint : c.max_pos);
+  return 0;
+}
+
+// fc(cat(emb, img_fc(cat(h, g))))  for `rows` rows already gathered:  dx1 = [h | g], dx2[:, :D] = emb   (cnets_ours.py:918-922,982-988)
+static int draft_fuse(vispec_ctx* ctx, hipStream_t s, int rows, void* out, int ld_out) {
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size;
+  if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
+  if (launch_gemm(s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, rows, D, 2 * D, EPI_NONE))
+    return -1;
+  return launch_gemm(s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, rows, D, 2 * D, EPI_NONE);
+}
+
+// the draft's single decoder layer on `rows` rows of ctx->dx (cnets_ours.py:545-600); result in ctx->dout
+static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, const int* prefix_dev, int tail,
+                       const unsigned long long* mask) {
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, Hd = c.draft_heads;
+  bf16_t* kc = ctx->draft_kv;
+  bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
+  if (launch_gemm(s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE)) return -1;
+  if (launch_rope(s, ctx->dqkv, rows, Hd, Hd, ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos, 1)) return -1;
+  if (launch_attention(ctx, s, ctx->dqkv, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, rows, prefix_dev, tail, mask, ctx->dattn, D, 0,
+                       ctx->n_hint < c.draft_max_pos ? ctx->n_hint : c.draft_max_pos))
+    return -1;
+  if (launch_gemm(s, ctx->dattn, D, ctx->dw.wo, nullptr, ctx->dh, D, ctx->dx, D, rows, D, D, EPI_RESIDUAL)) return -1;
+  if (launch_rmsnorm(s, ctx->dh, ctx->dw.ln2, ctx->dn, rows, D, c.draft_rms_eps)) return -1;
+  if (launch_gemm(s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, rows, c.draft_intermediate, D,
+                  EPI_SWIGLU))
+    return -1;
+  return launch_gemm(s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dout, D, ctx->dh, D, rows, D,
+                     c.draft_intermediate, EPI_RESIDUAL);
+}
+
+// head(last) -> log-softmax -> top-k, then `depth` tree levels and the final re-rank (cnets_ours.py:1109-1238).
+// Expects ctx->dlast = last hidden row, draft_len/real_len already advanced.
+static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
+  if (launch_gemm(s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE)) return -1;
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(1), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
+  KCHK();
+  hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, ctx->in_h, D);
+  KCHK();
+  for (int lvl = 0; lvl < c.depth; ++lvl) {
+    if (launch_gather(s, ctx->in_h, D, nullptr, 0, nullptr, ctx->dx1, 2 * D, k, D)) return -1;  // dx1[:, :D] = input_hidden
+    if (launch_gather(s, ctx->dw.embed, D, ctx->tb.in_ids, 0, nullptr, ctx->dx2, 2 * D, k, D)) return -1;
+    if (draft_fuse(ctx, s, k, ctx->dx, D)) return -1;
+    PosSpec ps;  // position_ids = len_posi + i for all k rows (cnets_ours.py:1128,1137); KV rows appended after the stable KV
+    ps.base = &ctx->st->n_ctx;
+    ps.add = lvl;
+    ps.row = 0;
+    ps.kv_base = &ctx->st->draft_len;
+    ps.kv_add = lvl * k;
+    if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
+    if (launch_gemm(s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE)) return -1;
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(k), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
+    KCHK();
+    hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(256), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
+                       ctx->in_h, D);
+    KCHK();
+  }
+  hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1, 0);
+  KCHK();
+  return 0;
+}
+
+extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
+  if (!ctx) return fail("null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, MC = c.depth + 2;  // a+1 <= depth+2 catch-up rows; rows beyond a are scratch
+  // catch-up forward on the accepted hidden states (cnets_ours.py:1090-1097)
+  if (launch_gather(s, ctx->accept_hidden, D, nullptr, 0, nullptr, ctx->dx1, 2 * D, MC, D)) return -1;
+  if (launch_gather(s, ctx->dw.embed, D, ctx->draft_ids, 0, nullptr, ctx->dx2, 2 * D, MC, D)) return -1;
+  if (draft_fuse(ctx, s, MC, ctx->dx, D)) return -1;
+  PosSpec ps;  // positions continue from the REAL length, KV rows from the compressed length (cnets_ours.py:845-868)
+  ps.base = &ctx->st->draft_real_len;
+  ps.kv_base = &ctx->st->draft_len;
+  if (draft_layer(ctx, s, MC, ps, &ctx->st->draft_len, MC, ctx->causal_mask)) return -1;
+  if (launch_gather(s, ctx->dout, D, nullptr, 0, &ctx->st->accept_len, ctx->dlast, D, 1, D)) return -1;  // out_hidden[:, -1]
+  hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(64), 0, s, ctx->st);
+  KCHK();
+  return draft_grow_tree(ctx, s);
+}
+
+extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* hidden, const void* embeds,
+                                    const uint8_t* image_mask_host, int L, const int* first_token_dev) {
+  if (!ctx) return fail("null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
+  if (L < 1 || L > c.draft_max_pos) return fail("draft_prefill: L exceeds draft_max_pos");
+  // inputs_embeds shifted by one, last row = embed(sampled token)  (cnets_ours.py:1081-1082)
+  if (L > 1)
+    HIPCHK(hipMemcpyAsync(ctx->emb_shift, (const bf16_t*)embeds + D, (size_t)(L - 1) * D * sizeof(bf16_t),
+                          hipMemcpyDeviceToDevice, s));
+  if (launch_gather(s, ctx->dw.embed, D, first_token_dev, 0, nullptr, ctx->emb_shift + (size_t)(L - 1) * D, D, 1, D)) return -1;
+  HIPCHK(hipMemsetAsync(ctx->dg, 0, sizeof(bf16_t) * D, s));  // last_img_hidden = 0   (:914,978)
+  // ---- host-side segmentation of the shifted mask (cnets_ours.py:880-884, 915-950) ----
+  // Everything index-like is laid out in one pinned host block and uploaded once:
+  //   [0,L) source row of every compressed text row | [L,2L) image rows, run after run | [2L,3L) position ids
+  struct Op { int is_adapt, c_row, n, off; };
+  std::vector<Op> plan;
+  int* h_src = ctx->h_pin;
+  int* h_img = ctx->h_pin + c.draft_max_pos;
+  int* h_pos = ctx->h_pin + 2 * c.draft_max_pos;
+  int c_row = 0, img_off = 0;
+  {
+    int start = 0;
+    auto text_rows = [&](int lo, int hi_excl, const uint8_t* m1) {
+      const int c0 = c_row;
+      for (int r = lo; r < hi_excl; ++r)
+        if (!m1 || !m1[r]) { h_src[c_row] = r; h_pos[c_row] = r; ++c_row; }
+      if (c_row > c0) plan.push_back({0, c0, c_row - c0, 0});
+    };
+    if (image_mask_host && L > 1) {
+      const uint8_t* m1 = image_mask_host + 1;  // length L-1
+      for (int e = 0; e < L - 1; ++e) {
+        const bool is_end = m1[e] && (e == L - 2 || !m1[e + 1]);
+        if (!is_end) continue;
+        text_rows(start, e + 1, m1);  // text rows before the run use the previous g   (:918-922)
+        const int i0 = img_off;
+        for (int r = start; r <= e; ++r)
+          if (m1[r]) h_img[img_off++] = r;
+        plan.push_back({1, c_row, img_off - i0, i0});
+        for (int t = 0; t < q - 1; ++t) { h_src[c_row] = 0; h_pos[c_row] = (e + 1) - (q - 1) + t; ++c_row; }  // :932-937
+        start = e + 1;
+      }
+    }
+    text_rows(start, L, nullptr);  // :944-950 (the trailing segment is all text by construction)
+  }
+  const int Lc = c_row;
+  if (Lc < 1 || Lc > c.draft_max_pos) return fail("draft_prefill: bad compressed length");
+  HIPCHK(hipMemcpyAsync(ctx->idx_tmp, h_src, sizeof(int) * Lc, hipMemcpyHostToDevice, s));
+  if (img_off) HIPCHK(hipMemcpyAsync(ctx->idx_img, h_img, sizeof(int) * img_off, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->pos_c, h_pos, sizeof(int) * Lc, hipMemcpyHostToDevice, s));
+  bf16_t* akc = ctx->ad_kv;
+  bf16_t* avc = ctx->ad_kv + (size_t)Hd * c.draft_max_pos * 128;
+  for (const Op& op : plan) {
+    if (!op.is_adapt) {
+      for (int o = 0; o < op.n; o += ROWS) {
+        const int rows = std::min(ROWS, op.n - o), r0 = op.c_row + o;
+        if (launch_gather(s, hidden, D, ctx->idx_tmp, r0, nullptr, ctx->dx1, 2 * D, rows, D)) return -1;
+        if (launch_gather(s, ctx->emb_shift, D, ctx->idx_tmp, r0, nullptr, ctx->dx2, 2 * D, rows, D)) return -1;
+        if (draft_fuse(ctx, s, rows, ctx->xc + (size_t)r0 * D, D)) return -1;
+      }
+      continue;
+    }
+    // ImgAdaptor (cnets_ours.py:630-661): K/V projection of the image rows into a [2][H][cap][hd] scratch cache ...
+    const int N = op.n;
+    for (int o = 0; o < N; o += ROWS) {
+      const int rows = std::min(ROWS, N - o);
+      if (launch_gather(s, ctx->emb_shift, D, ctx->idx_img, op.off + o, nullptr, ctx->dx, D, rows, D)) return -1;
+      if (launch_gemm(s, ctx->dx, D, ctx->dw.ad_wkv, ctx->dw.ad_bkv, ctx->ad_tmp, 2 * D, nullptr, 0, rows, 2 * D, D, EPI_NONE))
+        return -1;
+      PosSpec ps;
+      ps.kv_add = o;
+      if (launch_rope(s, ctx->ad_tmp, rows, 0, Hd, nullptr, nullptr, ps, akc, avc, c.draft_max_pos, 0)) return -1;
+    }
+    // ... then num_q learned queries attend over all N rows (non-causal), o_proj
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, (const int*)nullptr, N, ctx->scratch_int);
+    KCHK();
+    if (launch_attention(ctx, s, ctx->dw.ad_q, D, akc, avc, c.draft_max_pos, Hd, Hd, q, ctx->scratch_int, 0, nullptr, ctx->dattn, D,
+                         0, N))
+      return -1;
+    if (launch_gemm(s, ctx->dattn, D, ctx->dw.ad_wo, nullptr, ctx->ad_out, D, nullptr, 0, q, D, D, EPI_NONE)) return -1;
+    // first q-1 outputs are the compressed tokens, the last is the new global feature g   (:928-930)
+    if (q > 1)
+      HIPCHK(hipMemcpyAsync(ctx->xc + (size_t)op.c_row * D, ctx->ad_out, (size_t)(q - 1) * D * sizeof(bf16_t),
+                            hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->dg, ctx->ad_out + (size_t)(q - 1) * D, (size_t)D * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+  }
+  // ---- decoder layer over the compressed sequence: K,V for every row, the rest only for the last row (:1109) ----
+  bf16_t* kc = ctx->draft_kv;
+  bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
+  int last_chunk_rows = 0;
+  for (int o = 0; o < Lc; o += ROWS) {
+    const int rows = std::min(ROWS, Lc - o);
+    if (launch_gemm(s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE))
+      return -1;
+    PosSpec ps;
+    ps.off = ctx->pos_c + o;
+    ps.kv_add = o;
+    if (launch_rope(s, ctx->dqkv, rows, Hd, Hd, ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos, 1)) return -1;
+    last_chunk_rows = rows;
+  }
+  const bf16_t* qlast = ctx->dqkv + (size_t)(last_chunk_rows - 1) * 3 * D;
+  const bf16_t* xlast = ctx->xc + (size_t)(Lc - 1) * D;
+  hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, (const int*)nullptr, Lc, ctx->scratch_int);
+  KCHK();
+  if (launch_attention(ctx, s, qlast, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, 1, ctx->scratch_int, 0, nullptr, ctx->dattn, D, 0, Lc))
+    return -1;
+  if (launch_gemm(s, ctx->dattn, D, ctx->dw.wo, nullptr, ctx->dh, D, xlast, D, 1, D, D, EPI_RESIDUAL)) return -1;
+  if (launch_rmsnorm(s, ctx->dh, ctx->dw.ln2, ctx->dn, 1, D, c.draft_rms_eps)) return -1;
+  if (launch_gemm(s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, 1, c.draft_intermediate, D,
+                  EPI_SWIGLU))
+    return -1;
+  if (launch_gemm(s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dlast, D, ctx->dh, D, 1, D, c.draft_intermediate,
+                  EPI_RESIDUAL))
+    return -1;
+  hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, s, ctx->st, first_token_dev, Lc, L);
+  KCHK();
+  return draft_grow_tree(ctx, s);
+}
+
+static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, H = c.num_heads, Hk = c.num_kv_heads, V = c.vocab_size, I = c.intermediate_size;
+  const int QKV = (H + 2 * Hk) * 128;
+  if (!ctx->target_kv) return fail("target KV not set");
+  // embed the tree tokens (modeling_llama_kv.py:985)
+  if (launch_gather(s, ctx->tm.embed, D, ctx->tb.tree_tokens, 0, nullptr, ctx->xa, D, T, D)) return -1;
+  PosSpec ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
+  ps.base = &ctx->st->n_ctx;
+  ps.off = ctx->tb.tree_pos;
+  ps.kv_base = &ctx->st->n_ctx;
+  const size_t slab = (size_t)Hk * c.max_pos * 128;
+  for (int l = 0; l < c.num_layers; ++l) {
+    const vispec_layer_weights& w = ctx->layers[l];
+    bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
+    bf16_t* vc = ctx->target_kv + (size_t)(2 * l + 1) * slab;
+    if (launch_rmsnorm(s, ctx->xa, w.ln1, ctx->xn, T, D, c.rms_eps)) return -1;
+    if (launch_gemm(s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE)) return -1;
+    if (launch_rope(s, ctx->qkv, T, H, Hk, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc, vc, c.max_pos, 1)) return -1;
+    if (launch_attention(ctx, s, ctx->qkv, QKV, kc, vc, c.max_pos, H, Hk, T, &ctx->st->n_ctx, T, ctx->tb.tree_mask, ctx->attn_o,
+                         H * 128, c.eager_scores, ctx->n_hint))
+      return -1;
+    if (launch_gemm(s, ctx->attn_o, H * 128, w.wo, nullptr, ctx->xa, D, ctx->xa, D, T, D, H * 128, EPI_RESIDUAL)) return -1;
+    if (launch_rmsnorm(s, ctx->xa, w.ln2, ctx->xn, T, D, c.rms_eps)) return -1;
+    if (launch_gemm(s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU)) return -1;
+    if (launch_gemm(s, ctx->act, I, w.wdown, nullptr, ctx->xa, D, ctx->xa, D, T, D, I, EPI_RESIDUAL)) return -1;
+  }
+  if (launch_rmsnorm(s, ctx->xa, ctx->tm.norm, ctx->hidden_new, T, D, c.rms_eps)) return -1;  // hidden_states[-1] is post-norm
+  if (launch_gemm(s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE)) return -1;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(256), 0, s, ctx->logits, V, V, ctx->am);
+  KCHK();
+  return 0;
+}
+
+static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accept) {
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, Hk = c.num_kv_heads;
+  hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
+                     ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
+  KCHK();
+  if (T > 1) {
+    hipLaunchKernelGGL(kv_compact_kernel, dim3(2 * c.num_layers * Hk), dim3(64), 0, s, ctx->target_kv, c.max_pos, ctx->st, ctx->sel);
+    KCHK();
+  }
+  // accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1]   (utils.py:543-546)
+  return launch_gather(s, ctx->hidden_new, D, ctx->sel, 0, nullptr, ctx->accept_hidden, D, TREE_RET_W, D);
+}
+
+extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
+  if (!ctx) return fail("null ctx");
+  if (target_forward(ctx, (hipStream_t)stream, ctx->c.total_token)) return -1;
+  return target_accept(ctx, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+}
+extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
+  if (!ctx) return fail("null ctx");
+  return target_forward(ctx, (hipStream_t)stream, ctx->c.total_token);
+}
+extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
+  if (!ctx) return fail("null ctx");
+  return target_accept(ctx, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+}
+__global__ void set_tree_meta_kernel(DevState* st, int n_leaf, int max_depth, int T) {
+  if (threadIdx.x == 0) { st->n_leaf = n_leaf; st->max_depth = max_depth; st->tree_T = T; }
+}
+extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* tokens_T, const int* pos_T, const uint64_t* mask_T,
+                                    const int* retrieve, int n_leaf, int max_depth) {
+  if (!ctx || !tokens_T || !pos_T || !mask_T || !retrieve) return fail("null");
+  if (n_leaf < 1 || n_leaf > TREE_MAX_T || max_depth < 1 || max_depth > TREE_RET_W) return fail("bad tree shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int T = ctx->c.total_token;
+  std::vector<int> ret(TREE_MAX_T * TREE_RET_W, -1);
+  for (int r = 0; r < n_leaf; ++r)
+    for (int j = 0; j < max_depth; ++j) ret[r * TREE_RET_W + j] = retrieve[r * max_depth + j];
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_tokens, tokens_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_pos, pos_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_mask, mask_T, sizeof(uint64_t) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tb.retrieve, ret.data(), sizeof(int) * ret.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // `ret` is a local
+  hipLaunchKernelGGL(set_tree_meta_kernel, dim3(1), dim3(64), 0, s, ctx->st, n_leaf, max_depth, T);
+  KCHK();
+  return 0;
+}
+
+extern "C" int vispec_set_next_token(vispec_ctx* ctx, void* stream, const int* token_dev) {
+  if (!ctx || !token_dev) return fail("null");
+  hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, token_dev, 0, 0);
+  KCHK();
+  return 0;
+}
+
+extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
+  if (!ctx) return fail("null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
+  KCHK();
+  if (target_forward(ctx, s, 1)) return -1;
+  return target_accept(ctx, s, 1, -1);
+}
+
+// ------------------------------------------------------------------------------------------------ read-back
+extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
+  if (!ctx || !out) return fail("null");
+  DevState h;
+  HIPCHK(hipMemcpyAsync(&h, ctx->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  out[0] = h.n_ctx; out[1] = h.new_token; out[2] = h.rounds; out[3] = h.done; out[4] = h.accept_len;
+  out[5] = h.next_token; out[6] = h.draft_len; out[7] = h.n_leaf;
+  return 0;
+}
+extern "C" int vispec_get_tokens_host(vispec_ctx* ctx, void* stream, int* out, int n) {
+  if (!ctx || !out || n < 0 || n > ctx->tokens_cap) return fail("bad args");
+  HIPCHK(hipMemcpyAsync(out, ctx->tokens, sizeof(int) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int vispec_get_accept_log_host(vispec_ctx* ctx, void* stream, int* out, int n) {
+  if (!ctx || !out || n < 0 || n > ctx->log_cap) return fail("bad args");
+  HIPCHK(hipMemcpyAsync(out, ctx->accept_log, sizeof(int) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int vispec_get_tree_host(vispec_ctx* ctx, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve,
+                                    int* n_leaf, int* max_depth) {
+  if (!ctx) return fail("null");
+  hipStream_t s = (hipStream_t)stream;
+  DevState h;
+  HIPCHK(hipMemcpyAsync(&h, ctx->st, sizeof(h), hipMemcpyDeviceToHost, s));
+  if (tokens_T) HIPCHK(hipMemcpyAsync(tokens_T, ctx->tb.tree_tokens, sizeof(int) * TREE_MAX_T, hipMemcpyDeviceToHost, s));
+  if (pos_T) HIPCHK(hipMemcpyAsync(pos_T, ctx->tb.tree_pos, sizeof(int) * TREE_MAX_T, hipMemcpyDeviceToHost, s));
+  if (mask_T) HIPCHK(hipMemcpyAsync(mask_T, ctx->tb.tree_mask, sizeof(uint64_t) * TREE_MAX_T, hipMemcpyDeviceToHost, s));
+  if (retrieve) HIPCHK(hipMemcpyAsync(retrieve, ctx->tb.retrieve, sizeof(int) * TREE_MAX_T * TREE_RET_W, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (n_leaf) *n_leaf = h.n_leaf;
+  if (max_depth) *max_depth = h.max_depth;
+  return 0;
+}
+
+extern "C" void* vispec_buffer(vispec_ctx* ctx, const char* name) {
+  if (!ctx || !name) return nullptr;
+  struct E { const char* n; void* p; };
+  const E tab[] = {{"state", ctx->st}, {"tokens", ctx->tokens}, {"hidden_new", ctx->hidden_new}, {"logits", ctx->logits},
+                   {"am", ctx->am}, {"sel", ctx->sel}, {"draft_ids", ctx->draft_ids}, {"accept_hidden", ctx->accept_hidden},
+                   {"draft_last", ctx->dlast}, {"draft_out", ctx->dout}, {"draft_logits", ctx->dlogits}, {"draft_g", ctx->dg},
+                   {"draft_xc", ctx->xc}, {"tree_tokens", ctx->tb.tree_tokens}, {"tree_pos", ctx->tb.tree_pos},
+                   {"tree_mask", ctx->tb.tree_mask}, {"retrieve", ctx->tb.retrieve}, {"scores_all", ctx->tb.scores_all},
+                   {"tokens_all", ctx->tb.tokens_all}, {"parents_all", ctx->tb.parents_all}, {"accept_log", ctx->accept_log},
+                   {"lvl_mask", ctx->tb.lvl_mask}, {"in_ids", ctx->tb.in_ids}, {"in_h", ctx->in_h}};
+  for (const E& e : tab)
+    if (!strcmp(e.n, name)) return e.p;
+  return nullptr;
+}

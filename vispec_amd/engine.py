@@ -1,0 +1,287 @@
+"""Engine: owns one `vispec_ctx` (one per process/GPU), the device weights in the layout the HIP kernels stream
+(q|k|v and gate|up fused once at load) and the KV buffers.  PyTorch is used here for device memory, streams and
+the target's prefill GEMMs only; every decode-round op is a call into libvispec_hip."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+@dataclass
+class TargetConfig:
+    hidden_size: int
+    num_heads: int
+    num_kv_heads: int
+    intermediate_size: int
+    vocab_size: int
+    num_layers: int
+    max_position_embeddings: int = 8192  # modeling_llava_next_kv.py:10 forces 8192 for the LLaVA family
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    qkv_bias: bool = False
+    architectures: tuple = ("LlavaNextForConditionalGeneration",)
+    image_token_index: int = 32000
+    eos_token_id: int = 2
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+
+@dataclass
+class DraftConfig:
+    hidden_size: int
+    num_heads: int
+    intermediate_size: int
+    vocab_size: int
+    max_position_embeddings: int = 4096  # vispec/train/llava_1.6_7B_config.json
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    qkv_bias: bool = False
+    bias: bool = True  # fc / img_fc bias (spec_model_ours.py:59-64)
+
+
+LLAVA_16_7B = dict(hidden_size=4096, num_heads=32, num_kv_heads=32, intermediate_size=11008, vocab_size=32064, num_layers=32)
+
+
+def rope_tables(head_dim: int, max_pos: int, theta: float, device, dtype=torch.bfloat16):
+    """cos/sin caches exactly as the reference builds them (cnets_ours.py:122-155, modeling_llama_kv.py:147-181):
+    fp32 on the host, then cast to the model dtype."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype).to(device).contiguous(), emb.sin().to(dtype).to(device).contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class TargetWeights:
+    """Target language-model weights on the device, fused for streaming: wqkv [ (H+2Hkv)*hd, D ], wgu [2I, D]."""
+
+    def __init__(self, cfg: TargetConfig, device):
+        self.cfg, self.device = cfg, device
+        self.embed = self.norm = self.lm_head = None
+        self.layers = []  # dicts: wqkv, bqkv, wo, wgu, wdown, ln1, ln2
+
+    @classmethod
+    def from_state_dict(cls, cfg: TargetConfig, sd: Dict[str, "np.ndarray | torch.Tensor"], device, prefix="model."):
+        self = cls(cfg, device)
+        g = lambda k: (torch.from_numpy(np.ascontiguousarray(sd[k])) if isinstance(sd[k], np.ndarray) else sd[k]).to(
+            device=device, dtype=torch.bfloat16).contiguous()
+        has = lambda k: k in sd
+        self.embed = g(prefix + "embed_tokens.weight")
+        self.norm = g(prefix + "norm.weight")
+        self.lm_head = g("lm_head.weight")
+        for i in range(cfg.num_layers):
+            p = f"{prefix}layers.{i}."
+            lw = dict(
+                wqkv=torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")], 0).contiguous(),
+                bqkv=(torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"), g(p + "self_attn.v_proj.bias")], 0).contiguous()
+                      if has(p + "self_attn.q_proj.bias") else None),
+                wo=g(p + "self_attn.o_proj.weight"),
+                wgu=torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).contiguous(),
+                wdown=g(p + "mlp.down_proj.weight"),
+                ln1=g(p + "input_layernorm.weight"),
+                ln2=g(p + "post_attention_layernorm.weight"),
+            )
+            self.layers.append(lw)
+        return self
+
+    def tensors(self):
+        yield self.embed
+        yield self.norm
+        yield self.lm_head
+        for lw in self.layers:
+            for v in lw.values():
+                if v is not None:
+                    yield v
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.tensors())
+
+
+class DraftWeightsDev:
+    """Draft weights on the device (SURVEY §8 A0 names), fused like the target's."""
+
+    def __init__(self, cfg: DraftConfig, num_q: int, device):
+        self.cfg, self.num_q, self.device = cfg, num_q, device
+        self.t: Dict[str, Optional[torch.Tensor]] = {}
+
+    @classmethod
+    def from_state_dict(cls, cfg: DraftConfig, sd, num_q: int, device):
+        self = cls(cfg, num_q, device)
+        g = lambda k: (torch.from_numpy(np.ascontiguousarray(sd[k])) if isinstance(sd[k], np.ndarray) else sd[k]).to(
+            device=device, dtype=torch.bfloat16).contiguous()
+        has = lambda k: k in sd
+        p = "layers.0."
+        t = self.t
+        t["embed"] = g("embed_tokens.weight")
+        t["fc_w"], t["fc_b"] = g("fc.weight"), (g("fc.bias") if has("fc.bias") else None)
+        t["imgfc_w"], t["imgfc_b"] = g("img_fc.weight"), (g("img_fc.bias") if has("img_fc.bias") else None)
+        t["wqkv"] = torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in "qkv"], 0).contiguous()
+        t["bqkv"] = torch.cat([g(p + f"self_attn.{n}_proj.bias") for n in "qkv"], 0).contiguous() if has(p + "self_attn.q_proj.bias") else None
+        t["wo"] = g(p + "self_attn.o_proj.weight")
+        t["wgu"] = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).contiguous()
+        t["wdown"] = g(p + "mlp.down_proj.weight")
+        t["ln2"] = g(p + "post_attention_layernorm.weight")
+        t["ad_q"] = g("imadpt.q").reshape(num_q, -1).contiguous()
+        t["ad_wkv"] = torch.cat([g("imadpt.k_proj.weight"), g("imadpt.v_proj.weight")], 0).contiguous()
+        t["ad_bkv"] = torch.cat([g("imadpt.k_proj.bias"), g("imadpt.v_proj.bias")], 0).contiguous() if has("imadpt.k_proj.bias") else None
+        t["ad_wo"] = g("imadpt.o_proj.weight")
+        if t["ad_q"].shape[0] != num_q:
+            raise ValueError("imadpt.q does not match num_q")
+        return self
+
+    def tensors(self):
+        for v in self.t.values():
+            if v is not None:
+                yield v
+
+
+class Engine:
+    """One per (process, GPU).  Not re-entrant."""
+
+    def __init__(self, tcfg: TargetConfig, dcfg: DraftConfig, tw: TargetWeights, dw: DraftWeightsDev, total_token=30, depth=3,
+                 top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=True):
+        if not torch.cuda.is_available():
+            raise L.VispecError("no GPU visible: the ViSpec hot path only exists as HIP kernels (no CPU fallback)")
+        self.lib = L.load()
+        self.tcfg, self.dcfg, self.tw, self.dw = tcfg, dcfg, tw, dw
+        self.device = tw.device
+        self.total_token, self.depth, self.top_k, self.num_q = total_token, depth, top_k, num_q
+        self.kv_max_pos = kv_max_pos or tcfg.max_position_embeddings
+        self.draft_max_pos = draft_max_pos or dcfg.max_position_embeddings
+        cfg = L.VispecConfig(
+            hidden_size=tcfg.hidden_size, num_heads=tcfg.num_heads, num_kv_heads=tcfg.num_kv_heads, head_dim=tcfg.head_dim,
+            intermediate_size=tcfg.intermediate_size, vocab_size=tcfg.vocab_size, num_layers=tcfg.num_layers,
+            max_pos=self.kv_max_pos, rms_eps=tcfg.rms_norm_eps, qkv_bias=int(tcfg.qkv_bias),
+            draft_heads=dcfg.num_heads, draft_intermediate=dcfg.intermediate_size, draft_max_pos=self.draft_max_pos,
+            draft_qkv_bias=int(dcfg.qkv_bias), draft_fc_bias=int(dcfg.bias), draft_rms_eps=dcfg.rms_norm_eps,
+            total_token=total_token, depth=depth, top_k=top_k, num_q=num_q, eos_token_id=tcfg.eos_token_id,
+            eager_scores=int(eager_scores),
+        )
+        with torch.cuda.device(self.device):
+            h = C.c_void_p()
+            L.check(self.lib.vispec_ctx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.t_cos, self.t_sin = rope_tables(tcfg.head_dim, self.kv_max_pos, tcfg.rope_theta, self.device)
+        self.d_cos, self.d_sin = rope_tables(dcfg.hidden_size // dcfg.num_heads, self.draft_max_pos, dcfg.rope_theta, self.device)
+        for i, lw in enumerate(tw.layers):
+            s = L.LayerWeights(**{k: _p(v) for k, v in lw.items()})
+            L.check(self.lib.vispec_set_target_layer(self.h, i, C.byref(s)))
+        m = L.TargetMisc(embed=_p(tw.embed), norm=_p(tw.norm), lm_head=_p(tw.lm_head), rope_cos=_p(self.t_cos), rope_sin=_p(self.t_sin))
+        L.check(self.lib.vispec_set_target_misc(self.h, C.byref(m)))
+        d = L.DraftWeights(rope_cos=_p(self.d_cos), rope_sin=_p(self.d_sin), **{k: _p(v) for k, v in dw.t.items()})
+        L.check(self.lib.vispec_set_draft_weights(self.h, C.byref(d)))
+        # KV buffers: target exactly in the reference layout (kv_cache.py:105-126); draft [2, H, max_pos, hd]
+        self.target_kv = torch.zeros(2 * tcfg.num_layers, 1, tcfg.num_kv_heads, self.kv_max_pos, tcfg.head_dim,
+                                     dtype=torch.bfloat16, device=self.device)
+        self.draft_kv = torch.zeros(2, dcfg.num_heads, self.draft_max_pos, dcfg.hidden_size // dcfg.num_heads,
+                                    dtype=torch.bfloat16, device=self.device)
+        L.check(self.lib.vispec_set_kv(self.h, _p(self.target_kv), _p(self.draft_kv)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.vispec_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- stream plumbing ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- the path ------------------------------------------------------------------------------------
+    def begin_request(self, prompt_ids, max_new_tokens: int):
+        ids = np.ascontiguousarray(np.asarray(prompt_ids, dtype=np.int32))
+        self._keep = ids
+        L.check(self.lib.vispec_begin_request(self.h, self._stream(), ids.ctypes.data_as(C.c_void_p), int(ids.shape[0]), int(max_new_tokens)))
+
+    def draft_prefill(self, hidden: torch.Tensor, embeds: torch.Tensor, image_mask: Optional[np.ndarray], first_token: torch.Tensor):
+        assert hidden.dtype == torch.bfloat16 and embeds.dtype == torch.bfloat16 and hidden.is_contiguous() and embeds.is_contiguous()
+        assert first_token.dtype == torch.int32
+        Ln = hidden.shape[0]
+        m = None
+        if image_mask is not None:
+            m = np.ascontiguousarray(np.asarray(image_mask, dtype=np.uint8))
+            self._keep_mask = m
+        L.check(self.lib.vispec_draft_prefill(self.h, self._stream(), _p(hidden), _p(embeds),
+                                              None if m is None else m.ctypes.data_as(C.c_void_p), int(Ln), _p(first_token)))
+
+    def verify_accept(self, forced_accept: int = -1):
+        L.check(self.lib.vispec_verify_accept(self.h, self._stream(), int(forced_accept)))
+
+    def target_forward(self):
+        L.check(self.lib.vispec_target_forward(self.h, self._stream()))
+
+    def accept(self, forced_accept: int = -1):
+        L.check(self.lib.vispec_accept(self.h, self._stream(), int(forced_accept)))
+
+    def set_tree(self, tokens: np.ndarray, pos: np.ndarray, mask_bits: np.ndarray, retrieve: np.ndarray):
+        tokens, pos = np.ascontiguousarray(tokens, np.int32), np.ascontiguousarray(pos, np.int32)
+        mask_bits, retrieve = np.ascontiguousarray(mask_bits, np.uint64), np.ascontiguousarray(retrieve, np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(self.lib.vispec_set_tree_host(self.h, self._stream(), vp(tokens), vp(pos), vp(mask_bits), vp(retrieve),
+                                              int(retrieve.shape[0]), int(retrieve.shape[1])))
+
+    def draft_round(self):
+        L.check(self.lib.vispec_draft_round(self.h, self._stream()))
+
+    def set_next_token(self, token: torch.Tensor):
+        assert token.dtype == torch.int32 and token.is_cuda
+        self._keep_tok = token
+        L.check(self.lib.vispec_set_next_token(self.h, self._stream(), _p(token)))
+
+    def ar_step(self):
+        L.check(self.lib.vispec_ar_step(self.h, self._stream()))
+
+    # -- blocking read-backs ---------------------------------------------------------------------------
+    def state(self) -> Dict[str, int]:
+        out = (C.c_int * 8)()
+        L.check(self.lib.vispec_get_state_host(self.h, self._stream(), out))
+        k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
+        return dict(zip(k, list(out)))
+
+    def tokens(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int32)
+        L.check(self.lib.vispec_get_tokens_host(self.h, self._stream(), out.ctypes.data_as(C.c_void_p), int(n)))
+        return out
+
+    def accept_log(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int32)
+        L.check(self.lib.vispec_get_accept_log_host(self.h, self._stream(), out.ctypes.data_as(C.c_void_p), int(n)))
+        return out
+
+    def tree(self):
+        """-> draft_tokens [T], tree_position_ids [T], tree_mask [T,T] bool, retrieve_indices [n_leaf, max_depth] (host)."""
+        T = self.total_token
+        tok = np.zeros(L.TREE_MAX_T, np.int32)
+        pos = np.zeros(L.TREE_MAX_T, np.int32)
+        mask = np.zeros(L.TREE_MAX_T, np.uint64)
+        ret = np.zeros((L.TREE_MAX_T, L.TREE_RET_W), np.int32)
+        nl, md = C.c_int(), C.c_int()
+        L.check(self.lib.vispec_get_tree_host(self.h, self._stream(), tok.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                                              mask.ctypes.data_as(C.c_void_p), ret.ctypes.data_as(C.c_void_p), C.byref(nl), C.byref(md)))
+        bits = ((mask[:T, None] >> np.arange(T, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        return tok[:T].astype(np.int64), pos[:T].astype(np.int64), bits, ret[: nl.value, : md.value].astype(np.int64)
+
+    def buffer(self, name: str, shape, dtype=torch.bfloat16) -> torch.Tensor:
+        """Zero-copy torch view of an internal device buffer (tests / API mirror)."""
+        ptr = self.lib.vispec_buffer(self.h, name.encode())
+        if not ptr:
+            raise KeyError(name)
+        # build a tensor from the raw device pointer through the __cuda_array_interface__ protocol
+        typestr = {torch.bfloat16: "<i2", torch.int32: "<i4", torch.float32: "<f4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+        holder = type("DevBuf", (), {"__cuda_array_interface__": {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}})()
+        t = torch.as_tensor(holder, device=self.device)
+        return t.view(torch.bfloat16) if dtype == torch.bfloat16 else t

@@ -1,0 +1,226 @@
+"""SpecModel — the reference's spec-decoding API (vispec/model/spec_model_ours.py): from_pretrained (:109-203),
+forward (:205-245), specgenerate (:247-582), get_tokenizer (:101-107), and the attributes the harness reads
+(base_model, spec_layer, past_key_values, past_key_values_data, current_length_data, tokenizer).
+
+MI355X design: one SpecModel = one process = one GPU = one `vispec_ctx`.  specgenerate() runs the target prefill in
+PyTorch, then each draft-and-verify round is three stream-ordered C calls (verify+accept, draft round, state read-back)
+with exactly one host sync per round (the reference has >= 10)."""
+from __future__ import annotations
+
+import json
+import os
+import time
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import lib as L
+from ..engine import DraftConfig, DraftWeightsDev, Engine, TargetConfig, TargetWeights
+from .cnets_ours import Model
+from .kv_cache import initialize_past_key_values
+from .target import TargetLM
+from .utils import initialize_tree, reset_tree_mode
+
+
+class SpecModel:
+    def __init__(self, base_model: TargetLM, spec_layer: Model, tokenizer=None, total_token=30, depth=3, top_k=8, num_q=2,
+                 kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None):
+        self.base_model = base_model
+        self.config = base_model.config
+        self.hidden_size = base_model.cfg.hidden_size
+        self.vocab_size = base_model.cfg.vocab_size
+        self.tokenizer = tokenizer or SimpleNamespace(eos_token_id=base_model.cfg.eos_token_id, vocab_size=base_model.cfg.vocab_size)
+        self.spec_layer = spec_layer
+        self.engine = Engine(base_model.cfg, spec_layer.config, base_model.w, spec_layer.w, total_token=total_token, depth=depth,
+                             top_k=top_k, num_q=num_q, kv_max_pos=kv_max_pos, draft_max_pos=draft_max_pos)
+        base_model.engine = self.engine
+        spec_layer.engine = self.engine
+        spec_layer.init_tree()
+        self.training = False
+        self._last_embeds = None
+
+    def eval(self):
+        return self
+
+    def get_tokenizer(self):
+        return self.tokenizer
+
+    # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_weights(cls, tcfg: TargetConfig, dcfg: DraftConfig, target_sd, draft_sd, device="cuda:0", **kw):
+        """Build from in-memory state dicts (numpy / torch) with the reference's names."""
+        device = torch.device(device)
+        num_q = kw.get("num_q", 2)
+        tw = TargetWeights.from_state_dict(tcfg, target_sd, device)
+        dw = DraftWeightsDev.from_state_dict(dcfg, draft_sd, num_q, device)
+        base = TargetLM(tcfg, tw)
+        draft = Model(dcfg, dw, total_tokens=kw.get("total_token", 30), depth=kw.get("depth", 3), top_k=kw.get("top_k", 8),
+                      num_q=num_q)
+        return cls(base, draft, **kw)
+
+    @classmethod
+    def from_pretrained(cls, Type="LLaMA", base_model_path=None, spec_model_path=None, total_token=30, depth=3, top_k=8,
+                        threshold=1.0, num_q=2, device="cuda:0", **kwargs):
+        """spec_model_ours.py:109-203.  Local directories only (there is no network on the GPU box):
+        base_model_path = HF checkpoint dir of the target (config.json + *.safetensors [+ index]),
+        spec_model_path = ViSpec draft dir (config.json + model.safetensors | pytorch_model.bin)."""
+        from ..weights_io import load_draft_dir, load_target_dir  # imported lazily: safetensors is optional at import time
+        if total_token == -1:
+            raise NotImplementedError("total_token=-1 autotune (spec_model_ours.py:179-201) is not implemented; pass a value")
+        tcfg, target_sd, tokenizer = load_target_dir(base_model_path)
+        dcfg, draft_sd = load_draft_dir(spec_model_path, tcfg)
+        return cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=total_token, depth=depth, top_k=top_k,
+                                num_q=num_q, tokenizer=tokenizer)
+
+    # ------------------------------------------------------------------------------------------------
+    def _first_token(self, orig: torch.Tensor) -> torch.Tensor:
+        """argmax(orig[:, -1]) (utils.py:290) via the HIP argmax kernel on the bf16-rounded logits (first max wins)."""
+        import ctypes as C
+        row = orig.reshape(-1, orig.shape[-1])[-1:].to(torch.bfloat16).contiguous()
+        out = torch.zeros(1, dtype=torch.int32, device=row.device)
+        L.check(self.engine.lib.vispec_argmax_rows(self.engine.h, self.engine._stream(), C.c_void_p(row.data_ptr()), row.shape[-1], 1,
+                                                   row.shape[-1], C.c_void_p(out.data_ptr())))
+        return out
+
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, output_orig=False, position_ids=None,
+                inputs_embeds=None, output_real_hidden=False, **kwargs):
+        """spec_model_ours.py:205-245 — the PREFILL form (empty KV).  Returns (None[, logits fp32 [1,S,V]], hidden [1,S,D]).
+        The tree-verify form is utils.tree_decoding (HIP)."""
+        if inputs_embeds is None:
+            inputs_embeds = self.base_model.get_input_embeddings()(input_ids.to(self.engine.device))
+        emb = inputs_embeds.reshape(-1, inputs_embeds.shape[-1]).to(torch.bfloat16).contiguous()
+        self._last_embeds = None if input_ids is not None and kwargs.get("_draft_embeds_from_ids") else emb[None]
+        logits, hidden = self.base_model.prefill(emb, all_logits=bool(kwargs.get("all_logits", False)))
+        if past_key_values is not None:
+            for kv in past_key_values:
+                kv[0].current_length.fill_(emb.shape[0])
+                kv[1].current_length.fill_(emb.shape[0])
+        if output_orig:
+            return None, logits[None], hidden[None]
+        return None, hidden[None]
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def specgenerate(self, input_ids, temperature=0.0, top_p=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, log=False,
+                     is_llama3=False, inputs_embeds=None, return_acceptance_len=False, return_decode_time=False,
+                     forced_accept=None, **kwargs):
+        """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length."""
+        if (input_ids is None) ^ (inputs_embeds is not None):  # :263-266 (sic: exactly the reference's condition)
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if temperature > 1e-5:
+            raise NotImplementedError("sampling (temperature > 0) is a later row of SURVEY.md §8(f)")
+        eng = self.engine
+        dev = eng.device
+        max_length = max_length - self.spec_layer.total_tokens - 10  # :270
+        input_ids = input_ids.clone().to(dev)
+        self.spec_layer.reset_kv()  # :283
+        if not hasattr(self, "past_key_values"):  # :286-307
+            self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
+        self.current_length_data.zero_()
+        special_image_mask = None
+        arch = self.base_model.config.architectures[0]
+        draft_embeds = None
+        if arch == "LlavaNextForConditionalGeneration":  # :311-378
+            pixel_values = kwargs.get("pixel_values")
+            image_sizes = kwargs.get("image_sizes")
+            if pixel_values is not None and inputs_embeds is not None:
+                raise ValueError("You cannot specify both pixel_values and inputs_embeds at the same time, and must specify either one")
+            if inputs_embeds is None:
+                inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
+            if pixel_values is not None:
+                image_features = self.base_model.get_image_features(pixel_values, image_sizes)
+                image_features, _ = self.base_model.pack_image_features(image_features, image_sizes)
+                mask = input_ids == self.base_model.config.image_token_index
+                n_tok = int(mask.sum())
+                if n_tok != image_features.shape[0]:  # :363-370
+                    raise ValueError(f"Image features and image tokens do not match: tokens: {n_tok}, features {image_features.shape[0]}")
+                inputs_embeds = inputs_embeds.clone()
+                inputs_embeds[mask] = image_features.to(inputs_embeds.dtype)
+                special_image_mask = mask
+            draft_embeds = inputs_embeds
+        elif arch == "LlamaForCausalLM":
+            pass  # text target: the draft embeds the ids itself (cnets_ours.py:1099-1107)
+        else:
+            raise NotImplementedError(f"target architecture {arch} (Qwen2.5-VL is a later row of SURVEY.md §8)")
+        input_len = input_ids.shape[1]
+        reset_tree_mode(self)  # :456
+        # initialize_tree (:458-475): prefill + first token + draft prefill with image-token compression
+        emb = (inputs_embeds if inputs_embeds is not None else self.base_model.get_input_embeddings()(input_ids))
+        emb = emb.reshape(-1, emb.shape[-1]).to(torch.bfloat16).contiguous()
+        logits, hidden = self.base_model.prefill(emb)
+        first = self._first_token(logits)
+        eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
+        if draft_embeds is None:
+            ids1 = torch.cat([input_ids[0], first.long()])
+            demb = torch.nn.functional.embedding(ids1[:-1], self.spec_layer.w.t["embed"]).contiguous()
+        else:
+            demb = emb
+        mask_np = None if special_image_mask is None else special_image_mask.reshape(-1).cpu().numpy()
+        eng.draft_prefill(hidden, demb, mask_np, first)
+        self.spec_layer.stable_kv = ("device", eng)
+        acceptance_len = []
+        if return_decode_time:
+            torch.cuda.synchronize()
+            start_time = time.time()
+        idx = 0
+        st = None
+        for idx in range(max_length):  # :484
+            fa = -1 if forced_accept is None else int(forced_accept(idx))
+            eng.verify_accept(fa)   # tree_decoding + evaluate_posterior + accept half of update_inference_inputs
+            eng.draft_round()       # topK_genrate half of update_inference_inputs
+            st = eng.state()        # the round's single host sync
+            if return_acceptance_len:
+                acceptance_len.append(int(st["accept_len"]))
+            if st["done"] & 1:      # :544 eos in generated ids
+                break
+            if st["new_token"] > max_new_tokens:  # :546
+                break
+        n_ctx, new_token = st["n_ctx"], st["new_token"]
+        self.current_length_data.fill_(n_ctx)
+        toks = torch.from_numpy(eng.tokens(n_ctx).astype(np.int64)).to(dev)[None]
+        outputs = (toks,)
+        if log:
+            outputs += (new_token, idx)
+        if return_acceptance_len:
+            outputs += (acceptance_len,)
+        if return_decode_time:
+            torch.cuda.synchronize()
+            outputs += (time.time() - start_time,)
+        return outputs[0] if len(outputs) == 1 else outputs
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def baseline_generate(self, input_ids, inputs_embeds=None, max_new_tokens=512, max_steps=2048, **kwargs):
+        """Greedy AR with the same KV cache and kernels — evaluation/gen_baseline_answer_coco_caption.py:34-133."""
+        eng = self.engine
+        dev = eng.device
+        input_ids = input_ids.clone().to(dev)
+        if inputs_embeds is None:
+            inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
+        emb = inputs_embeds.reshape(-1, inputs_embeds.shape[-1]).to(torch.bfloat16).contiguous()
+        logits, _ = self.base_model.prefill(emb)
+        first = self._first_token(logits)
+        eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
+        eng.set_next_token(first)
+        n = 0
+        sync_every = 16
+        for n in range(1, max_steps + 1):
+            eng.ar_step()
+            if n % sync_every == 0 or n == max_steps:
+                st = eng.state()
+                if st["done"]:
+                    break
+        st = eng.state()
+        toks = eng.tokens(st["n_ctx"]).astype(np.int64)
+        eos = self.base_model.cfg.eos_token_id
+        gen = toks[input_ids.shape[1]:]
+        cut = np.nonzero(gen == eos)[0]
+        if cut.size:
+            toks = toks[: input_ids.shape[1] + int(cut[0]) + 1]
+        elif len(gen) > max_new_tokens + 1:
+            toks = toks[: input_ids.shape[1] + max_new_tokens + 1]
+        return torch.from_numpy(toks).to(dev)[None]

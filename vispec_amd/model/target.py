@@ -1,0 +1,120 @@
+"""Target VLM wrapper (`base_model` of the reference's SpecModel).
+
+What lives where (BASELINE.json north_star): vision tower / projector and the PREFILL forward stay on PyTorch-ROCm
+(plain torch ops below: hipBLASLt GEMMs + SDPA), writing K/V straight into the engine's KV buffer; every forward
+that happens inside the draft-and-verify loop (tree verify, AR decode step) runs as HIP kernels via the Engine.
+This module owns its Llama decode path instead of subclassing HF (transformers 5.x no longer lets
+`language_model` be swapped — SURVEY.md §7.2); reference semantics followed: modeling_llama_kv.py:527-653
+(attention), :104-133 (RMSNorm), :927-1080 (model), lm_head + .float() (:1190-1197)."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..engine import Engine, TargetConfig, TargetWeights
+
+
+def _rmsnorm(x, w, eps):
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(x.dtype)
+
+
+def _rope(x, cos, sin):
+    # x [S, H, hd]; cos/sin [S, hd] in the model dtype: (x*cos) + (rotate_half(x)*sin), every op rounding to bf16
+    half = x.shape[-1] // 2
+    rot = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+    return (x * cos[:, None, :]) + (rot * sin[:, None, :])
+
+
+class _Head:
+    """stand-in for nn.Linear lm_head: the reference passes `base_model.lm_head` into topK_genrate (utils.py:300)."""
+
+    def __init__(self, weight):
+        self.weight = weight
+
+    def __call__(self, x):
+        return F.linear(x, self.weight)
+
+
+class SyntheticVision:
+    """Vision front-end used when no vision tower weights exist on the box (no network): deterministic features
+    with the statistics of SURVEY.md §8(d) — N(0,1)*0.05 — one row per image placeholder token."""
+
+    def __init__(self, hidden_size: int, std: float = 0.05):
+        self.hidden_size, self.std = hidden_size, std
+
+    def features(self, n_tokens: int, seed: int, device, dtype):
+        g = torch.Generator(device="cpu").manual_seed(1000 + int(seed))
+        return (torch.randn(n_tokens, self.hidden_size, generator=g) * self.std).to(device=device, dtype=dtype)
+
+
+class TargetLM:
+    """`base_model`: config + weights + PyTorch prefill + handles the reference code touches."""
+
+    def __init__(self, cfg: TargetConfig, weights: TargetWeights, vision=None):
+        self.cfg, self.w = cfg, weights
+        self.device, self.dtype = weights.device, torch.bfloat16
+        self.config = SimpleNamespace(
+            architectures=list(cfg.architectures), num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+            num_key_value_heads=cfg.num_kv_heads, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+            vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+            image_token_index=cfg.image_token_index, image_token_id=cfg.image_token_index, eos_token_id=cfg.eos_token_id,
+            vision_feature_layer=-2, vision_feature_select_strategy="default")
+        self.lm_head = _Head(weights.lm_head)
+        self.vision = vision or SyntheticVision(cfg.hidden_size)
+        self.engine: Optional[Engine] = None  # attached by SpecModel
+        self.tree_mask = None  # reference stores it on base_model.model (spec_model_ours.py:486-489); kept for API parity
+        self.model = self  # `base_model.model.tree_mask = ...` (utils.py:334)
+
+    # ---- handles used by spec_model_ours.py:339-376 -------------------------------------------------
+    def get_input_embeddings(self):
+        return lambda ids: F.embedding(ids, self.w.embed)
+
+    def get_image_features(self, pixel_values, image_sizes=None, **kw):
+        """Synthetic front-end: `pixel_values` is (n_image_tokens, seed) or a ready [N, D] feature tensor."""
+        if torch.is_tensor(pixel_values) and pixel_values.dim() == 2 and pixel_values.shape[-1] == self.cfg.hidden_size:
+            return pixel_values.to(self.device, self.dtype)
+        n, seed = pixel_values
+        return self.vision.features(int(n), int(seed), self.device, self.dtype)
+
+    def pack_image_features(self, image_features, image_sizes=None, **kw):
+        return image_features, torch.tensor([image_features.shape[0]])
+
+    image_newline = None
+
+    # ---- PyTorch prefill -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def prefill(self, inputs_embeds: torch.Tensor, all_logits: bool = False):
+        """inputs_embeds [L, D] bf16 -> (logits fp32 [L or 1, V], hidden [L, D] post-final-norm); K/V rows [0, L)
+        of every layer are written into the engine's KV buffer (KVCache.cat semantics, modeling_llama_kv.py:583-594)."""
+        c, eng = self.cfg, self.engine
+        x = inputs_embeds.to(self.dtype)
+        Ln = x.shape[0]
+        H, Hk, hd = c.num_heads, c.num_kv_heads, c.head_dim
+        cos, sin = eng.t_cos[:Ln], eng.t_sin[:Ln]
+        kv = eng.target_kv
+        for i, lw in enumerate(self.w.layers):
+            h = _rmsnorm(x, lw["ln1"], c.rms_norm_eps)
+            qkv = F.linear(h, lw["wqkv"], lw["bqkv"])
+            q, k, v = qkv.split([H * hd, Hk * hd, Hk * hd], dim=-1)
+            q = _rope(q.view(Ln, H, hd), cos, sin).transpose(0, 1)  # [H, L, hd]
+            k = _rope(k.view(Ln, Hk, hd), cos, sin).transpose(0, 1)
+            v = v.view(Ln, Hk, hd).transpose(0, 1)
+            kv[2 * i, 0, :, :Ln] = k
+            kv[2 * i + 1, 0, :, :Ln] = v
+            a = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True, enable_gqa=(H != Hk))[0]
+            x = x + F.linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"])
+            h = _rmsnorm(x, lw["ln2"], c.rms_norm_eps)
+            g, u = F.linear(h, lw["wgu"]).chunk(2, dim=-1)
+            x = x + F.linear(F.silu(g) * u, lw["wdown"])
+        hidden = _rmsnorm(x, self.w.norm, c.rms_norm_eps)
+        logits = F.linear(hidden if all_logits else hidden[-1:], self.w.lm_head).float()
+        return logits, hidden.contiguous()
+
+    def eval(self):
+        return self

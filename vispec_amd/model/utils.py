@@ -1,0 +1,92 @@
+"""Loop helpers with the names and argument meaning of reference vispec/model/utils.py, implemented over the
+device-resident round state of libvispec_hip.  The fused fast path used by SpecModel.specgenerate is
+`Engine.verify_accept()` + `Engine.draft_round()`; the functions here expose the same stages one at a time so code
+written against the reference (and the parity tests) can drive them individually."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def prepare_logits_processor(temperature=0.0, repetition_penalty=0.0, top_p=0.0, top_k=0):
+    raise NotImplementedError("sampling path (utils.py:39-55, 453-493) is a later row of SURVEY.md §8(f); use temperature=0")
+
+
+def reset_tree_mode(model):  # utils.py:330-338
+    model.base_model.tree_mask = None
+    model.base_model.tree_mode = None
+
+
+def reset_past_key_values(passed_key_values):  # utils.py:341-358
+    for i in range(len(passed_key_values)):
+        for j in range(2):
+            passed_key_values[i][j].current_length.fill_(0)
+    return passed_key_values
+
+
+def initialize_tree(input_ids, model, past_key_values, logits_processor, inputs_embeds=None, embed_weights=None,
+                    image_mask=None, **kwargs):
+    """utils.py:266-327: target prefill -> first token -> first topK_genrate."""
+    if logits_processor is not None:
+        prepare_logits_processor()
+    outputs, orig, hidden_states = model(input_ids, past_key_values=past_key_values, output_orig=True, inputs_embeds=inputs_embeds)
+    token = model._first_token(orig)  # argmax(orig[:, -1]) on the device, first max wins
+    input_ids = torch.cat((input_ids, token.to(input_ids.device).long()[None]), dim=1)
+    embeds = inputs_embeds if inputs_embeds is not None else model._last_embeds
+    draft_tokens, retrieve_indices, tree_mask, tree_position_ids = model.spec_layer.topK_genrate(
+        hidden_states, input_ids, model.base_model.lm_head, logits_processor, inputs_embeds=embeds, image_mask=image_mask)
+    return draft_tokens, retrieve_indices, tree_mask, tree_position_ids, orig, hidden_states, token.long()[None]
+
+
+def tree_decoding(model, tree_candidates, past_key_values, tree_position_ids, input_ids, retrieve_indices):
+    """utils.py:389-412: target forward of the T tree tokens with the tree mask installed on the target.
+    Returns (logits [n_leaf, m, V] fp32, hidden_state_new [1,T,D], None)."""
+    eng = model.engine
+    T = eng.total_token
+    tm = model.base_model.tree_mask
+    if tm is None:
+        raise ValueError("tree_mask must be installed on the target before tree_decoding (spec_model_ours.py:486-489)")
+    bits = np.zeros(64, np.uint64)
+    m = (tm.reshape(T, T).cpu().numpy() > 0)
+    for i in range(T):
+        bits[i] = np.uint64(int("".join("1" if b else "0" for b in m[i][::-1]), 2))
+    ri = retrieve_indices.cpu().numpy().astype(np.int32)
+    eng.set_tree(tree_candidates.reshape(-1).cpu().numpy().astype(np.int32), tree_position_ids.cpu().numpy().astype(np.int32), bits, ri)
+    eng.target_forward()
+    V, D = eng.tcfg.vocab_size, eng.tcfg.hidden_size
+    tree_logits = eng.buffer("logits", (64, V))[:T].float()
+    hidden = eng.buffer("hidden_new", (64, D))[:T]
+    logits = tree_logits[retrieve_indices.to(tree_logits.device)]
+    return logits, hidden[None], None
+
+
+def evaluate_posterior(logits, candidates, logits_processor):
+    """utils.py:415-451 (greedy).  Pure function of its arguments, evaluated with torch integer ops on the device the
+    logits live on; the fused loop uses the HIP verify_accept kernel instead."""
+    if logits_processor is not None:
+        prepare_logits_processor()
+    posterior_mask = (candidates[:, 1:].to(logits.device) == torch.argmax(logits[:, :-1], dim=-1)).int()
+    cal = torch.cumprod(posterior_mask, dim=1).sum(dim=1)
+    accept_length = cal.max()
+    best = torch.tensor(0, dtype=torch.long, device=candidates.device) if accept_length == 0 else torch.argmax(cal).to(torch.long)
+    return best, accept_length, logits[best, accept_length]
+
+
+@torch.no_grad()
+def update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices, logits_processor,
+                            new_token, past_key_values_data_list, current_length_data, model, hidden_state_new, sample_p):
+    """utils.py:496-593: commit the accepted path (tokens, KV compaction, lengths), sample the next token and run the
+    next topK_genrate — on the device (vispec_accept + vispec_draft_round)."""
+    eng = model.engine
+    eng.accept()
+    eng.draft_round()
+    st = eng.state()
+    a = int(st["accept_len"])
+    if a != int(accept_length):
+        raise RuntimeError("device accept length differs from the caller's evaluate_posterior")
+    input_ids = torch.cat([input_ids, candidates[None, int(best_candidate), : a + 1].to(input_ids.device)], dim=-1)
+    current_length_data.fill_(st["n_ctx"])
+    token = torch.tensor([[st["next_token"]]], dtype=torch.long, device=input_ids.device)
+    draft_tokens, retrieve_indices, tree_mask, tree_position_ids = model.spec_layer._tree_tuple(input_ids.device)
+    new_token += a + 1
+    return input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, None, token
