@@ -143,6 +143,11 @@ int vispec_get_tokens_host(vispec_ctx*, void* stream, int* out_host, int n);    
 int vispec_get_accept_log_host(vispec_ctx*, void* stream, int* out_host, int n_rounds);
 int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve_Txd2,
                          int* n_leaf, int* max_depth);
+/* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
+   HIP events on its own stream.  kinds 0..8 = gemm (M-blocks {1,2,4}) x epilogue {none,residual,swiglu}, 9 = attention
+   partial, 10 = attention reduce.  report: out[kind*3+{0,1,2}] = {launches, total ms, total algorithmic bytes}. Blocking. */
+int vispec_prof_enable(vispec_ctx*, int on);
+int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, int n_kinds);
 /* device pointers of internal buffers (hidden_state_new [T,D], verify logits [T,V] bf16, draft last hidden ...) */
 void* vispec_buffer(vispec_ctx*, const char* name);
 

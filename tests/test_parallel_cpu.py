@@ -1,0 +1,44 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: weight replication (scatter + all-gather) and request sharding."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vispec_amd import parallel
+    g = torch.Generator().manual_seed(100 + rank)  # different values per rank before replication
+    tensors = [torch.randn(1 << 19, generator=g).to(torch.bfloat16), torch.randn(333, 777, generator=g).to(torch.bfloat16),
+               torch.randn(17, generator=g), torch.randn((1 << 19) + 3, generator=g)]
+    before = parallel.checksum(tensors)
+    same_before = parallel.all_equal(before)
+    nbytes = parallel.replicate_weights(tensors, src=0)
+    after = parallel.checksum(tensors)
+    ok = parallel.all_equal(after)
+    ref = torch.Generator().manual_seed(100)
+    want0 = torch.randn(1 << 19, generator=ref).to(torch.bfloat16)
+    q.put((rank, same_before, ok, bool(torch.equal(tensors[0], want0)), nbytes, parallel.shard_requests(7, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_replicate_weights_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for rank, same_before, ok, eq0, nbytes, shard in res:
+        assert not same_before and ok and eq0 and nbytes > 0
+    assert sorted(res[0][5] + res[1][5]) == list(range(7)) and not set(res[0][5]) & set(res[1][5])

@@ -177,6 +177,56 @@ extern "C" int vispec_set_kv(vispec_ctx* ctx, void* target_kv, void* draft_kv) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ in-library profiling
+// HIP-event pairs recorded on the launch stream around each kernel of a "kind"; used by bench.py for the roofline
+// object (per-launch duration of the dominant kernel measured on the stream it runs on).  Off by default.
+enum { PROF_KINDS = 16, PROF_ATT_PARTIAL = 9, PROF_ATT_REDUCE = 10, PROF_OTHER = 11 };
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // 2 per record
+  std::vector<int> kind;
+  std::vector<double> bytes;
+  size_t used = 0;
+} g_prof;
+static void prof_begin(hipStream_t s, int kind, double bytes) {
+  if (!g_prof.on) return;
+  if (g_prof.used * 2 + 2 > g_prof.ev.size()) {
+    for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; g_prof.ev.push_back(e); }
+  }
+  g_prof.kind.resize(g_prof.used + 1);
+  g_prof.bytes.resize(g_prof.used + 1);
+  g_prof.kind[g_prof.used] = kind;
+  g_prof.bytes[g_prof.used] = bytes;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+}
+static void prof_end(hipStream_t s) {
+  if (!g_prof.on) return;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+  ++g_prof.used;
+}
+extern "C" int vispec_prof_enable(vispec_ctx*, int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return 0;
+}
+// out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic bytes}; blocking.
+extern "C" int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, int n_kinds) {
+  if (!out || n_kinds < 1) return fail("bad args");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < n_kinds * 3; ++i) out[i] = 0.0;
+  for (size_t r = 0; r < g_prof.used; ++r) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * r], g_prof.ev[2 * r + 1]));
+    const int k = g_prof.kind[r];
+    if (k < 0 || k >= n_kinds) continue;
+    out[k * 3 + 0] += 1.0;
+    out[k * 3 + 1] += ms;
+    out[k * 3 + 2] += g_prof.bytes[r];
+  }
+  g_prof.used = 0;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ launch helpers
 static int launch_gemm(hipStream_t s, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy, const void* R,
                        int ldr, int M, int N, int K, int epi) {
@@ -196,9 +246,12 @@ static int launch_gemm(hipStream_t s, const void* X, int ldx, const void* W, con
     case EPI_SWIGLU: GO(MBV, EPI_SWIGLU, UN); break;    \
     default: return fail("gemm_skinny: bad epilogue");  \
   }
+  // algorithmic bytes of one launch = the weight rows it streams (SURVEY.md §8d counts weights once per pass)
+  prof_begin(s, (MB == 1 ? 0 : MB == 2 ? 1 : 2) * 3 + epi, (double)N * K * 2.0 * (epi == EPI_SWIGLU ? 2.0 : 1.0));
   if (MB == 1) { BYEPI(1, 4) }
   else if (MB == 2) { BYEPI(2, 4) }
   else { BYEPI(4, 2) }
+  prof_end(s);
 #undef BYEPI
 #undef GO
   KCHK();
@@ -278,6 +331,7 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
   const int lds = 2 * ATT_CHUNK * 256 + 1024;
   dim3 grid(nsplit, H_kv), block(256);
+  prof_begin(s, PROF_ATT_PARTIAL, 0.0);
   if (eager)
     hipLaunchKernelGGL(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
                        (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
@@ -285,9 +339,12 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
     hipLaunchKernelGGL(tree_attn_partial_kernel<false>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
                        (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
   KCHK();
+  prof_end(s);
+  prof_begin(s, PROF_ATT_REDUCE, 0.0);
   hipLaunchKernelGGL(tree_attn_reduce_kernel, dim3(H * MT), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
                      tail, kpw, nsplit, (bf16_t*)out, ldo);
   KCHK();
+  prof_end(s);
   return 0;
 }
 

@@ -245,6 +245,22 @@ class Engine:
     def ar_step(self):
         L.check(self.lib.vispec_ar_step(self.h, self._stream()))
 
+    PROF_KINDS = ["gemm_m16_none", "gemm_m16_residual", "gemm_m16_swiglu", "gemm_m32_none", "gemm_m32_residual", "gemm_m32_swiglu",
+                  "gemm_m64_none", "gemm_m64_residual", "gemm_m64_swiglu", "attn_partial", "attn_reduce"]
+
+    def prof_enable(self, on: bool):
+        L.check(self.lib.vispec_prof_enable(self.h, int(on)))
+
+    def prof_report(self) -> Dict[str, Dict[str, float]]:
+        n = 16
+        out = (C.c_double * (3 * n))()
+        L.check(self.lib.vispec_prof_report_host(self.h, self._stream(), out, n))
+        rep = {}
+        for i, name in enumerate(self.PROF_KINDS):
+            if out[3 * i] > 0:
+                rep[name] = dict(launches=out[3 * i], ms=out[3 * i + 1], bytes=out[3 * i + 2])
+        return rep
+
     # -- blocking read-backs ---------------------------------------------------------------------------
     def state(self) -> Dict[str, int]:
         out = (C.c_int * 8)()

@@ -103,24 +103,9 @@ class SpecModel:
 
     __call__ = forward
 
-    # ------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def specgenerate(self, input_ids, temperature=0.0, top_p=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, log=False,
-                     is_llama3=False, inputs_embeds=None, return_acceptance_len=False, return_decode_time=False,
-                     forced_accept=None, **kwargs):
-        """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length."""
-        if (input_ids is None) ^ (inputs_embeds is not None):  # :263-266 (sic: exactly the reference's condition)
-            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
-        if temperature > 1e-5:
-            raise NotImplementedError("sampling (temperature > 0) is a later row of SURVEY.md §8(f)")
-        eng = self.engine
-        dev = eng.device
-        max_length = max_length - self.spec_layer.total_tokens - 10  # :270
-        input_ids = input_ids.clone().to(dev)
-        self.spec_layer.reset_kv()  # :283
-        if not hasattr(self, "past_key_values"):  # :286-307
-            self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
-        self.current_length_data.zero_()
+    def _merge_vision(self, input_ids, inputs_embeds, kwargs):
+        """spec_model_ours.py:309-453: token embeddings, image features scattered over the placeholder tokens, and the
+        image mask the draft compresses with.  -> (inputs_embeds | None, special_image_mask | None, draft_embeds | None)."""
         special_image_mask = None
         arch = self.base_model.config.architectures[0]
         draft_embeds = None
@@ -142,10 +127,33 @@ class SpecModel:
                 inputs_embeds[mask] = image_features.to(inputs_embeds.dtype)
                 special_image_mask = mask
             draft_embeds = inputs_embeds
-        elif arch == "LlamaForCausalLM":
-            pass  # text target: the draft embeds the ids itself (cnets_ours.py:1099-1107)
+        elif arch in ("LlamaForCausalLM", "LlavaForConditionalGeneration"):
+            # text target, and LLaVA-1.5: the reference has no vision branch for it -> no compression,
+            # the draft embeds the ids itself (cnets_ours.py:1099-1107)
+            pass
         else:
             raise NotImplementedError(f"target architecture {arch} (Qwen2.5-VL is a later row of SURVEY.md §8)")
+        return inputs_embeds, special_image_mask, draft_embeds
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def specgenerate(self, input_ids, temperature=0.0, top_p=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, log=False,
+                     is_llama3=False, inputs_embeds=None, return_acceptance_len=False, return_decode_time=False,
+                     forced_accept=None, **kwargs):
+        """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length."""
+        if (input_ids is None) ^ (inputs_embeds is not None):  # :263-266 (sic: exactly the reference's condition)
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if temperature > 1e-5:
+            raise NotImplementedError("sampling (temperature > 0) is a later row of SURVEY.md §8(f)")
+        eng = self.engine
+        dev = eng.device
+        max_length = max_length - self.spec_layer.total_tokens - 10  # :270
+        input_ids = input_ids.clone().to(dev)
+        self.spec_layer.reset_kv()  # :283
+        if not hasattr(self, "past_key_values"):  # :286-307
+            self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
+        self.current_length_data.zero_()
+        inputs_embeds, special_image_mask, draft_embeds = self._merge_vision(input_ids, inputs_embeds, kwargs)
         input_len = input_ids.shape[1]
         reset_tree_mode(self)  # :456
         # initialize_tree (:458-475): prefill + first token + draft prefill with image-token compression
@@ -199,6 +207,7 @@ class SpecModel:
         eng = self.engine
         dev = eng.device
         input_ids = input_ids.clone().to(dev)
+        inputs_embeds, _, _ = self._merge_vision(input_ids, inputs_embeds, kwargs)
         if inputs_embeds is None:
             inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
         emb = inputs_embeds.reshape(-1, inputs_embeds.shape[-1]).to(torch.bfloat16).contiguous()

@@ -1,0 +1,70 @@
+"""Multi-GPU: one process per GPU, independent (image, prompt) requests per replica, NO data-path collective
+(SURVEY.md §8e — "replicas only").  The only communication is the one-time replication of the weights from rank 0:
+scatter (each peer link carries 1/G of the payload) followed by all-gather, so that every xGMI link of every GPU is
+busy instead of the root's egress alone (xGMI is point-to-point, a flat broadcast is root-egress bound)."""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+
+SMALL = 1 << 20
+
+
+def replicate_weights(tensors: Iterable[torch.Tensor], src: int = 0, group=None) -> int:
+    """In-place: after the call every rank holds rank `src`'s values.  Returns the number of bytes replicated."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    total = 0
+    for t in tensors:
+        assert t.is_contiguous()
+        total += t.numel() * t.element_size()
+        if world == 1:
+            continue
+        flat = t.view(-1)
+        n = flat.numel()
+        shard = n // world
+        if n * t.element_size() < SMALL or shard == 0:
+            dist.broadcast(t, src, group=group)
+            continue
+        body = flat[: shard * world]
+        mine = torch.empty(shard, dtype=t.dtype, device=t.device)
+        dist.scatter(mine, list(body.split(shard)) if rank == src else None, src=src, group=group)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        if rank != src:
+            torch.cat(parts, out=body)
+        if shard * world < n:
+            tail = flat[shard * world :].clone()
+            dist.broadcast(tail, src, group=group)
+            if rank != src:
+                flat[shard * world :] = tail
+    return total
+
+
+def checksum(tensors: Iterable[torch.Tensor]) -> torch.Tensor:
+    """Order-sensitive 64-bit checksum of the raw bits (exact, integer arithmetic)."""
+    acc = None
+    for i, t in enumerate(tensors):
+        b = t.contiguous().view(torch.uint8).view(-1)
+        pad = (-b.numel()) % 8
+        if pad:
+            b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
+        w = b.view(torch.int64)
+        s = (w * (2 * i + 1)).sum() + w[:: max(1, w.numel() // 1024)].sum() * 31
+        acc = s if acc is None else acc * 1000003 + s
+    return acc
+
+
+def all_equal(value: torch.Tensor, group=None) -> bool:
+    if dist.get_world_size(group) == 1:
+        return True
+    lo, hi = value.clone(), value.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool((lo == hi).all())
+
+
+def shard_requests(n_requests: int, rank: int, world: int):
+    """request i -> replica i mod G (static round-robin; the reference chunks contiguously, gen_spec_answer_coco_caption.py:63-80)."""
+    return list(range(rank, n_requests, world))
