@@ -40,7 +40,7 @@ typedef struct {
   int eager_scores;       /* 1: target attention rounds scores to bf16 like modeling_llama_kv.py:602-604 */
 } vispec_config;
 
-/* per-layer target weights; wqkv = rows [q | k | v] fused, wgu = rows [gate | up] fused (done once at load) */
+/* per-layer target weights; wqkv = rows [q | k | v] fused, wgu = rows [gate | up] fused, all W32-packed (done once at load) */
 typedef struct {
   const void *wqkv, *bqkv, *wo, *wgu, *wdown, *ln1, *ln2;
 } vispec_layer_weights;
@@ -76,10 +76,24 @@ int  vispec_set_draft_weights(vispec_ctx*, const vispec_draft_weights*);
 int  vispec_set_kv(vispec_ctx*, void* target_kv, void* draft_kv);
 
 /* ---- single kernels (unit-testable building blocks) ------------------------------------------------ */
+/* Every GEMM weight the library streams (all pointers in the three weight structs above except embed / norm vectors /
+   ad_q / rope tables) is in the "W32" layout: 32-row x 16-k tiles stored as the 1 KiB A-operand image of
+   v_mfma_f32_32x32x16_bf16, tiles of a row block contiguous along k (csrc/kernels.h).  vispec_pack_weight converts a
+   row-major nn.Linear weight [N, K] once at load; P must hold vispec_packed_elems(N, K) bf16 elements. */
+int vispec_pack_weight(vispec_ctx*, void* stream, const void* W_rowmajor, int N, int K, void* P);
+long long vispec_packed_elems(int N, int K);
 /* Y[M,N] = X[M,K] · W[N,K]^T (+bias) ; epilogue: 0 none, 1 += residual R (bf16 add of two bf16 tensors),
-   2 SwiGLU: W holds [gate rows | up rows] (2N rows), Y = silu(g)*u.  M <= 64.   nn.Linear in every module above. */
+   2 SwiGLU: W holds [gate rows | up rows] (2N rows), Y = silu(g)*u.  M <= 32.   nn.Linear in every module above.
+   W is W32-packed.  Small N is split over K across workgroups (needs ctx for the partial workspace). */
 int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias,
                        void* Y, int ldy, const void* R, int ldr, int M, int N, int K, int epilogue);
+/* same with the RMSNorm that follows fused: Y = bf16(R + bf16(X·W^T + b)) (R may be NULL), normed = norm_w * rms_norm(Y)
+   (modeling_llama_kv.py: o_proj -> +residual -> post_attention_layernorm ; down_proj -> +residual -> next input_layernorm) */
+int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
+                            const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M, int N, int K);
+/* tuning hook for tools/gemm_bench.py: explicit decomposition, variant = S*100 + {0:4,1:8 waves}*10 + {0:4,1:8,2:16 unroll} */
+int vispec_gemm_skinny_tune(vispec_ctx*, int variant, void* stream, const void* X, int ldx, const void* W, void* Y, int ldy,
+                            int M, int N, int K);
 /* LlamaRMSNorm (cnets_ours.py:513-527, modeling_llama_kv.py:104-133) */
 int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps);
 /* rotary (cnets_ours.py:104-119) on fused qkv rows + append K,V to a [H_kv, S_max, hd] cache at rows
@@ -144,7 +158,7 @@ int vispec_get_accept_log_host(vispec_ctx*, void* stream, int* out_host, int n_r
 int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve_Txd2,
                          int* n_leaf, int* max_depth);
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
-   HIP events on its own stream.  kinds 0..8 = gemm (M-blocks {1,2,4}) x epilogue {none,residual,swiglu}, 9 = attention
+   HIP events on its own stream.  kinds 0..4 = skinny GEMM {none, residual, swiglu, split-K partial, split-K reduce(+norm)}, 9 = attention
    partial, 10 = attention reduce.  report: out[kind*3+{0,1,2}] = {launches, total ms, total algorithmic bytes}. Blocking. */
 int vispec_prof_enable(vispec_ctx*, int on);
 int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, int n_kinds);

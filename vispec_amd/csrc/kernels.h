@@ -22,6 +22,17 @@ __device__ __forceinline__ float rdbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return *reinterpret_cast<bf16x8*>(&v); }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Device-resident round state: nothing here ever needs the host between rounds.
 // ------------------------------------------------------------------------------------------------
@@ -44,142 +55,240 @@ struct DevState {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 64; weights streamed once from HBM, HBM-bound)
-//   one workgroup = 16 W rows (one 16x16x32 MFMA A-tile per 32 k) ; its 4 waves split K in 128-byte
-//   chunks and are reduced through LDS (deterministic, no atomics).  D[i=n][j=m]: lane holds 4
-//   consecutive n for one m -> 8-byte stores.
+// Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 32; every weight byte is streamed from HBM exactly once per call)
+//
+// Weight layout "W32" (built once at load by pack_w32_kernel): the matrix is cut into tiles of 32 rows x 16 k; a tile is
+// stored as the 1 KiB image of the A operand of v_mfma_f32_32x32x16_bf16 — lane l holds W[32t + (l&31)][16c + 8(l>>5) .. +8] —
+// and the tiles of one 32-row block follow each other along k.  A wave therefore streams its share of K with one fully
+// coalesced 1 KiB global_load_dwordx4 per MFMA straight into registers (no LDS round trip: nothing is reused across waves).
+//   grid  = (row blocks, S)   S = split-K over workgroups (small N would otherwise leave most of the 256 CUs idle)
+//   block = NW waves, each owning a contiguous K range of the workgroup's split; register double-buffering keeps UNROLL
+//           loads per operand in flight behind the MFMAs; waves are reduced through LDS in a fixed order (deterministic).
+//   X (activations, L2-resident) is read as the B operand directly: lane (m = l&31, hi) loads X[m][16c + 8hi .. +8].
+//   D[i = n][j = m]: a lane ends with 4 groups of 4 consecutive n for its m -> 8-byte bf16 / 16-byte fp32 stores.
+// Epilogues: NONE / RESIDUAL / SWIGLU (second stream = the matching `up` block) write bf16 with the reference's rounding
+// points; PARTIAL writes fp32 partial sums [S][32][N] that splitk_reduce_kernel finishes (bias, residual, RMSNorm fused).
 // ------------------------------------------------------------------------------------------------
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_PARTIAL = 3 };
 
-template <int MB, int EPI, int UNROLL>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, int ldx,
-                                                          const bf16_t* __restrict__ W,
-                                                          const bf16_t* __restrict__ bias, bf16_t* __restrict__ Y,
-                                                          int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N,
-                                                          int K) {
-  constexpr int NACC = (EPI == EPI_SWIGLU) ? 2 : 1;
-  __shared__ float red[4][NACC][MB][64][4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const int nchunks = K >> 6;  // 64 k (=128 B per W row) per chunk
-  const bf16_t* w0 = W + (size_t)(n0 + i) * K + g * 8;
-  const bf16_t* w1 = (EPI == EPI_SWIGLU) ? W + (size_t)(N + n0 + i) * K + g * 8 : nullptr;
-  const bf16_t* xr[MB];
-  bool xv[MB];
+__global__ __launch_bounds__(64) void pack_w32_kernel(const bf16_t* __restrict__ W, int N, int K, bf16_t* __restrict__ P) {
+  const int ks = blockIdx.x, tile = blockIdx.y, l = threadIdx.x;
+  const int row = tile * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < N) v = *reinterpret_cast<const uint4*>(W + (size_t)row * K + k);
+  *reinterpret_cast<uint4*>(P + (((size_t)tile * (K >> 4) + ks) * 64 + l) * 8) = v;
+}
+
+// bytes of LDS one staged X group takes: UNROLL k-step images of 1 KiB, padded so that both the staging writes
+// (8 lanes = one 128-B row segment -> 8 different 16-B bank groups) and the fragment reads are conflict-free
+#define XS_STEP 1056
+#define XS_HALF 528
+template <int NT, int UNROLL, int NW>
+constexpr int gemm_w32_lds_bytes() {
+  return (NW * 2 * UNROLL * XS_STEP) > (NW * NT * 4096) ? (NW * 2 * UNROLL * XS_STEP) : (NW * NT * 4096);
+}
+
+template <int NT, int EPI, int UNROLL, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+                                                           int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
+                                                           int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
+                                                           int S) {
+  static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
+  const int j = lane & 31, hi = lane >> 5;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int KS = K >> 4;
+  const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
+  const int len = ks_hi - ks_lo;
+  const int w_lo = ks_lo + (int)((long)len * wave / NW), w_hi = ks_lo + (int)((long)len * (wave + 1) / NW);
+  const uint4* pa0 = reinterpret_cast<const uint4*>(P + (size_t)tile * KS * 512) + lane + (size_t)w_lo * 64;
+  const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P + (size_t)(tile + tile2_off) * KS * 512) + lane + (size_t)w_lo * 64 : pa0;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    int m = mb * 16 + i;
-    xv[mb] = m < M;
-    xr[mb] = X + (size_t)(xv[mb] ? m : 0) * ldx + g * 8;
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- X staging map: one instruction = (64 / (2*UNROLL)) rows x (UNROLL*32) contiguous bytes -> whole 128/256-B lines.
+  // The activations are re-read by every workgroup from L2; fetching them fragment-shaped (32 rows x 32 B per instruction)
+  // costs twice the L1/TA requests of the weight stream and was measured to cap the kernel at ~3.7 TB/s (tools/stream_probe).
+  constexpr int SEGS = 2 * UNROLL, RPI = 64 / SEGS, NINST = 32 / RPI;
+  const int seg = lane % SEGS, srow0 = lane / SEGS;
+  unsigned char* xs = smem_g + wave * (2 * UNROLL * XS_STEP);
+  const bf16_t* sx[NINST];
+  int woff[NINST];
+#pragma unroll
+  for (int i = 0; i < NINST; ++i) {
+    const int row = srow0 + i * RPI;
+    sx[i] = X + (size_t)(row < M ? row : 0) * ldx + (size_t)w_lo * 16 + seg * 8;  // rows >= M read row 0, never stored
+    woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
-  f32x4 acc[NACC][MB];
-#pragma unroll
-  for (int a = 0; a < NACC; ++a)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[a][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int roff = hi * XS_HALF + j * 16;
 
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  int c = wave;
-  for (; c + 4 * (UNROLL - 1) < nchunks; c += 4 * UNROLL) {
-    uint4 a[NACC][UNROLL][2];
-    uint4 b[MB][UNROLL][2];
+  struct Regs {
+    uint4 a[NT][UNROLL];
+    uint4 x[NINST];
+  };
+  auto load = [&](Regs& g) {  // all loads unconditional plain global loads (see the note in the commit history / DESIGN.md)
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int k0 = (c + 4 * u) << 6;
-      a[0][u][0] = *reinterpret_cast<const uint4*>(w0 + k0);
-      a[0][u][1] = *reinterpret_cast<const uint4*>(w0 + k0 + 32);
-      if (EPI == EPI_SWIGLU) {
-        a[NACC - 1][u][0] = *reinterpret_cast<const uint4*>(w1 + k0);
-        a[NACC - 1][u][1] = *reinterpret_cast<const uint4*>(w1 + k0 + 32);
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        b[mb][u][0] = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0) : zero4;
-        b[mb][u][1] = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0 + 32) : zero4;
-      }
+      g.a[0][u] = pa0[u * 64];
+      if (NT == 2) g.a[NT - 1][u] = pa1[u * 64];
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
+    for (int i = 0; i < NINST; ++i) g.x[i] = *reinterpret_cast<const uint4*>(sx[i]);
+    pa0 += 64 * UNROLL;
+    pa1 += 64 * UNROLL;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < NINST; ++i) sx[i] += 16 * UNROLL;
+  };
+  auto compute = [&](const Regs& g, int buf) {
+    unsigned char* xb = xs + buf * (UNROLL * XS_STEP);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+    for (int i = 0; i < NINST; ++i) *reinterpret_cast<uint4*>(xb + woff[i]) = g.x[i];
+    // same-wave LDS traffic is processed in issue order: the fragment reads below see the writes above
 #pragma unroll
-          for (int aa = 0; aa < NACC; ++aa)
-            acc[aa][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[aa][u][h]), as_bf16x8(b[mb][u][h]),
-                                                                  acc[aa][mb], 0, 0, 0);
-  }
-  for (; c < nchunks; c += 4) {
-    const int k0 = c << 6;
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint4 bv = *reinterpret_cast<const uint4*>(xb + u * XS_STEP + roff);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint4 a0 = *reinterpret_cast<const uint4*>(w0 + k0 + 32 * h);
-      uint4 a1 = zero4;
-      if (EPI == EPI_SWIGLU) a1 = *reinterpret_cast<const uint4*>(w1 + k0 + 32 * h);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        uint4 bb = xv[mb] ? *reinterpret_cast<const uint4*>(xr[mb] + k0 + 32 * h) : zero4;
-        acc[0][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(bb), acc[0][mb], 0, 0, 0);
-        if (EPI == EPI_SWIGLU)
-          acc[NACC - 1][mb] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(bb), acc[NACC - 1][mb], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t], 0, 0, 0);
+    }
+  };
+  const int n_steps = w_hi - w_lo;
+  const int n_groups = n_steps / UNROLL;  // wave-uniform
+  if (n_groups > 0) {  // register double-buffering: group g+1 is in flight while group g feeds the matrix core
+    Regs r0, r1;
+    load(r0);
+    int gi = 1;
+    while (true) {
+      if (gi < n_groups) load(r1);
+      compute(r0, 0);
+      if (++gi > n_groups) break;
+      if (gi < n_groups) load(r0);
+      compute(r1, 1);
+      if (++gi > n_groups) break;
     }
   }
-  // cross-wave (split-K) reduction through LDS, fixed order wave0+wave1+wave2+wave3
-#pragma unroll
-  for (int aa = 0; aa < NACC; ++aa)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][aa][mb][lane][r] = acc[aa][mb][r];
+  {  // < UNROLL leftover k-steps: fragment-shaped X loads straight from global
+    const bf16_t* px = X + (size_t)(j < M ? j : 0) * ldx + hi * 8 + (size_t)(w_lo + n_groups * UNROLL) * 16;
+    for (int rstep = n_groups * UNROLL; rstep < n_steps; ++rstep) {
+      const uint4 av = pa0[0];
+      const uint4 bv = *reinterpret_cast<const uint4*>(px);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0], 0, 0, 0);
+      if (NT == 2) {
+        const uint4 av1 = pa1[0];
+        acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
+      }
+      pa0 += 64;
+      pa1 += 64;
+      px += 16;
+    }
+  }
+  // cross-wave reduction through LDS (aliases the X staging area), fixed order wave 0 + 1 + ... (deterministic)
+  float(*red)[NT][64][16] = reinterpret_cast<float(*)[NT][64][16]>(smem_g);
   __syncthreads();
-  for (int mb = wave; mb < MB; mb += 4) {
-    const int m = mb * 16 + i;
-    float v[NACC][4];
 #pragma unroll
-    for (int aa = 0; aa < NACC; ++aa)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        v[aa][r] = ((red[0][aa][mb][lane][r] + red[1][aa][mb][lane][r]) + red[2][aa][mb][lane][r]) + red[3][aa][mb][lane][r];
-    if (m < M) {
-      const int n = n0 + g * 4;
-      float o[4];
+    for (int r = 0; r < 16; ++r) red[wave][t][lane][r] = acc[t][r];
+  __syncthreads();
+  constexpr int NGROUPS = (EPI == EPI_SWIGLU) ? 4 : 4 * NT;
+  for (int idx = wave; idx < NGROUPS; idx += NW) {
+    const int tt = (EPI == EPI_SWIGLU) ? 0 : idx >> 2, q = idx & 3;
+    float v[4], u2[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y = v[0][r];
-        if (bias) y += bf2f(bias[n + r]);
-        y = rdbf(y);
-        if (EPI == EPI_SWIGLU) {
-          float u = v[NACC - 1][r];
-          if (bias) u += bf2f(bias[N + n + r]);
-          u = rdbf(u);
-          float act = rdbf(y / (1.0f + __expf(-y)));
-          y = rdbf(act * u);
-        }
-        if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
-        o[r] = y;
+    for (int r = 0; r < 4; ++r) {
+      float sum = red[0][tt][lane][4 * q + r];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sum += red[w][tt][lane][4 * q + r];
+      v[r] = sum;
+      if (EPI == EPI_SWIGLU) {
+        float su = red[0][NT - 1][lane][4 * q + r];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) su += red[w][NT - 1][lane][4 * q + r];
+        u2[r] = su;
       }
-      uint2 st = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-      *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = st;
     }
+    const int n = (tile + (tt ? tile2_off : 0)) * 32 + 8 * q + 4 * hi;
+    if (j < M && n < N) {
+      if (EPI == EPI_PARTIAL) {
+        float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * 32 + j) * N + n;
+        *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = v[r];
+          if (bias) y += bf2f(bias[n + r]);
+          y = rdbf(y);
+          if (EPI == EPI_SWIGLU) {
+            float u = u2[r];
+            if (bias) u += bf2f(bias[tile2_off * 32 + n + r]);
+            u = rdbf(u);
+            float act = rdbf(y / (1.0f + __expf(-y)));
+            y = rdbf(act * u);
+          }
+          if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)j * ldr + n + r]) + y);
+          o[r] = y;
+        }
+        *reinterpret_cast<uint2*>(Y + (size_t)j * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+      }
+    }
+  }
+}
+
+// Finishes a split-K GEMM: y = bf16(sum_s part[s] + bias) ; h = bf16(R + y) if R ; optional fused RMSNorm of h
+// (cnets_ours.py:513-527) written to `normed`.  One workgroup per row m; every stage rounds where the reference's graph does.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int N,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
+                                                            bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
+                                                            bf16_t* __restrict__ normed, int ldn, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+  float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable) when a norm follows
+  __shared__ float partsum[4];
+  const int m = blockIdx.x;
+  float ss = 0.f;
+  for (int n = threadIdx.x * 4; n < N; n += 256 * 4) {
+    float4 a = *reinterpret_cast<const float4*>(part + (size_t)m * N + n);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(part + ((size_t)s * 32 + m) * N + n);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float o[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = o[r];
+      if (bias) y += bf2f(bias[n + r]);
+      y = rdbf(y);
+      if (R) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+      o[r] = y;
+      ss += y * y;
+    }
+    if (Y) *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+    if (normed) *reinterpret_cast<float4*>(hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (!normed) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) partsum[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (partsum[0] + partsum[1]) + (partsum[2] + partsum[3]);
+  const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+  for (int n = threadIdx.x * 4; n < N; n += 256 * 4) {
+    const float4 h = *reinterpret_cast<const float4*>(hrow + n);
+    const uint2 wv = *reinterpret_cast<const uint2*>(norm_w + n);
+    const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+    const float o0 = bf2f(we[0]) * rdbf(h.x * inv), o1 = bf2f(we[1]) * rdbf(h.y * inv);
+    const float o2 = bf2f(we[2]) * rdbf(h.z * inv), o3 = bf2f(we[3]) * rdbf(h.w * inv);
+    *reinterpret_cast<uint2*>(normed + (size_t)m * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // RMSNorm: y = w * bf16( x * rsqrt(mean(x^2) + eps) )     one workgroup per row
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
 
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ Y, int D, float eps) {

@@ -52,6 +52,8 @@ struct vispec_ctx {
   TreeBufs tb{};
   // attention partials
   float *part_o, *part_ml;
+  float* gemm_part = nullptr;  // split-K partial sums [S<=8][32][N]
+  size_t gemm_part_elems = 0;
   size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
   int n_hint = 0;             // upper bound of keys any attention call of this request can see
   std::vector<void*> allocs;
@@ -70,7 +72,8 @@ static int dalloc(vispec_ctx* ctx, T** p, size_t n) {
 extern "C" const char* vispec_last_error(void) { return g_err.c_str(); }
 extern "C" int vispec_version(void) { return 1; }
 
-#define ROWS 64
+#define ROWS 64   /* rows of the activation workspaces */
+#define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
 extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
   const vispec_config& c = *cfg;
@@ -135,6 +138,13 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
     A(part_o, ctx->part_cap_tiles * 128 * 32);
     A(part_ml, ctx->part_cap_tiles * 64);
   }
+  {
+    size_t nmax = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
+    if (nmax < (size_t)3 * c.hidden_size) nmax = (size_t)3 * c.hidden_size;
+    if (nmax < 16384) nmax = 16384;
+    ctx->gemm_part_elems = (size_t)8 * 32 * nmax;
+    A(gemm_part, ctx->gemm_part_elems);
+  }
 #undef A
   ctx->n_hint = c.max_pos;
   const int lds = 2 * ATT_CHUNK * 256 + 1024;
@@ -180,7 +190,7 @@ extern "C" int vispec_set_kv(vispec_ctx* ctx, void* target_kv, void* draft_kv) {
 // ------------------------------------------------------------------------------------------------ in-library profiling
 // HIP-event pairs recorded on the launch stream around each kernel of a "kind"; used by bench.py for the roofline
 // object (per-launch duration of the dominant kernel measured on the stream it runs on).  Off by default.
-enum { PROF_KINDS = 16, PROF_ATT_PARTIAL = 9, PROF_ATT_REDUCE = 10, PROF_OTHER = 11 };
+enum { PROF_KINDS = 16, PROF_ATT_PARTIAL = 9, PROF_ATT_REDUCE = 10, PROF_OTHER = 11 };  // 0..4: gemm none/residual/swiglu/splitK-partial/splitK-reduce
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> ev;  // 2 per record
@@ -228,34 +238,85 @@ extern "C" int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, i
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
-static int launch_gemm(hipStream_t s, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy, const void* R,
-                       int ldr, int M, int N, int K, int epi) {
-  if (M < 1 || M > 64) return fail("gemm_skinny: M must be in [1,64]");
-  if (N % 16 || K % 64) return fail("gemm_skinny: N %% 16 == 0 and K %% 64 == 0 required");
-  if (epi == EPI_RESIDUAL && !R) return fail("gemm_skinny: residual epilogue without R");
-  const int MB = (M + 15) / 16;
-  dim3 grid(N / 16), block(256);
-  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)W, *b = (const bf16_t*)bias, *r = (const bf16_t*)R;
-  bf16_t* y = (bf16_t*)Y;
-#define GO(MBV, EPIV, UN) \
-  hipLaunchKernelGGL((gemm_skinny_kernel<MBV, EPIV, UN>), grid, block, 0, s, x, ldx, w, b, y, ldy, r, ldr, M, N, K)
-#define BYEPI(MBV, UN)                                  \
-  switch (epi) {                                        \
-    case EPI_NONE: GO(MBV, EPI_NONE, UN); break;        \
-    case EPI_RESIDUAL: GO(MBV, EPI_RESIDUAL, UN); break; \
-    case EPI_SWIGLU: GO(MBV, EPI_SWIGLU, UN); break;    \
-    default: return fail("gemm_skinny: bad epilogue");  \
-  }
-  // algorithmic bytes of one launch = the weight rows it streams (SURVEY.md §8d counts weights once per pass)
-  prof_begin(s, (MB == 1 ? 0 : MB == 2 ? 1 : 2) * 3 + epi, (double)N * K * 2.0 * (epi == EPI_SWIGLU ? 2.0 : 1.0));
-  if (MB == 1) { BYEPI(1, 4) }
-  else if (MB == 2) { BYEPI(2, 4) }
-  else { BYEPI(4, 2) }
-  prof_end(s);
-#undef BYEPI
-#undef GO
+// packed size in bf16 elements of an [N, K] weight in the W32 layout (rows padded to a multiple of 32)
+static size_t packed_elems(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
+
+static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
+  if (K % 16) return fail("pack: K %% 16");
+  hipLaunchKernelGGL(pack_w32_kernel, dim3(K / 16, (N + 31) / 32), dim3(64), 0, s, (const bf16_t*)W, N, K, (bf16_t*)P);
   KCHK();
   return 0;
+}
+
+// One skinny GEMM on a W32-packed weight.  Small-N problems are split over K across workgroups (fp32 partials in
+// ctx->gemm_part) and finished by splitk_reduce_kernel, which also applies bias / residual and, when `norm_w` is given, the
+// RMSNorm that follows in the layer (one kernel boundary and one activation round trip less).
+//   Y (bf16, ld ldy) may be null when only the normed output is wanted.  M <= 32.
+struct GemmOut {
+  void* Y = nullptr; int ldy = 0;
+  const void* R = nullptr; int ldr = 0;
+  const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
+};
+static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
+                          int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
+  if (M < 1 || M > 32) return fail("gemm_skinny: M must be in [1,32]");
+  if (N % 8 || K % 16) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 == 0 required");
+  if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
+  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
+  const int tiles = (N + 31) / 32, KS = K / 16;
+  if (epi == EPI_SWIGLU) {
+    if (N % 32) return fail("gemm_skinny: SwiGLU needs N %% 32 == 0");
+    if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
+    prof_begin(s, 2, (double)N * K * 4.0);
+    hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x, ldx, w,
+                       tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  // split-K when the row blocks alone cannot fill the chip, or when a fused norm is requested (the reduce kernel owns it)
+  int S = 1;
+  if (tiles < 256 || o.norm_w) {
+    S = (512 + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+    while (S > 1 && KS / S < 8) --S;
+    if (!ctx) S = 1;
+  }
+  if (force_split > 0) S = force_split;
+  if (S == 1 && !o.norm_w) {
+    prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * 2.0);
+    if (epi == EPI_RESIDUAL)
+      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w,
+                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+    else
+      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
+                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  if (!ctx) return fail("gemm_skinny: split-K needs a ctx (partial workspace)");
+  if ((size_t)S * 32 * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
+  prof_begin(s, 3, (double)N * K * 2.0);
+  hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
+                     nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+  KCHK();
+  prof_end(s);
+  prof_begin(s, 4, 0.0);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
+                     epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn,
+                     o.eps);
+  KCHK();
+  prof_end(s);
+  return 0;
+}
+
+// legacy-shaped helper used by most call sites
+static int launch_gemm(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, void* Y, int ldy,
+                       const void* R, int ldr, int M, int N, int K, int epi) {
+  GemmOut o;
+  o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr;
+  return launch_gemm_ex(ctx, s, X, ldx, P, bias, M, N, K, epi, o);
 }
 
 static int launch_rmsnorm(hipStream_t s, const void* X, const void* w, void* Y, int M, int D, float eps) {
@@ -363,10 +424,52 @@ static int launch_bcast(hipStream_t s, const void* vec, void* out, int ld_o, int
 }
 
 // ------------------------------------------------------------------------------------------------ unit-level C-ABI
-extern "C" int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y,
-                                  int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
-  return launch_gemm((hipStream_t)stream, X, ldx, W, bias, Y, ldy, R, ldr, M, N, K, epilogue);
+extern "C" int vispec_pack_weight(vispec_ctx*, void* stream, const void* W, int N, int K, void* P) {
+  return launch_pack((hipStream_t)stream, W, N, K, P);
 }
+extern "C" long long vispec_packed_elems(int N, int K) { return (long long)packed_elems(N, K); }
+extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
+                                  int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
+  if (epilogue < 0 || epilogue > 2) return fail("gemm_skinny: bad epilogue");
+  return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, M, N, K, epilogue);
+}
+// skinny GEMM (+bias, +residual R) with the following RMSNorm fused: Y = bf16(R + bf16(X·W^T + b)), normed = norm_w * rms(Y)
+extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
+                                       int ldy, const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M,
+                                       int N, int K) {
+  GemmOut o;
+  o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr; o.norm_w = norm_w; o.normed = normed; o.ldn = ldn; o.eps = eps;
+  return launch_gemm_ex(ctx, (hipStream_t)stream, X, ldx, P, bias, M, N, K, R ? EPI_RESIDUAL : EPI_NONE, o);
+}
+// Tuning hook (tools/gemm_bench.py): packed-weight GEMM (no bias / epilogue) with explicit decomposition
+//   variant = S*100 + NW_code*10 + UNROLL_code ; NW_code 0/1 = 4/8 waves ; UNROLL_code 0/1/2 = 4/8/16 ; S = split-K (>=1 -> partial path)
+extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* stream, const void* X, int ldx, const void* P, void* Y, int ldy,
+                                       int M, int N, int K) {
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P;
+  const int tiles = (N + 31) / 32;
+  const int S = variant / 100, nwc = (variant / 10) % 10, unc = variant % 10;
+  if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
+#define V(NWV, UN)                                                                                                              \
+  hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S)
+  switch (nwc * 10 + unc) {
+    case 0: V(4, 4); break;
+    case 1: V(4, 8); break;
+    case 10: V(8, 4); break;
+    case 11: V(8, 8); break;
+    case 20: V(2, 4); break;
+    case 21: V(2, 8); break;
+    default: return fail("tune: unknown variant");
+  }
+#undef V
+  KCHK();
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), 0, s, ctx->gemm_part, S, N, nullptr, nullptr, 0, (bf16_t*)Y, ldy, nullptr,
+                     nullptr, 0, 0.f);
+  KCHK();
+  return 0;
+}
+
 extern "C" int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps) {
   return launch_rmsnorm((hipStream_t)stream, X, w, Y, M, D, eps);
 }
@@ -441,9 +544,9 @@ static int draft_fuse(vispec_ctx* ctx, hipStream_t s, int rows, void* out, int l
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size;
   if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
-  if (launch_gemm(s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, rows, D, 2 * D, EPI_NONE))
+  if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, rows, D, 2 * D, EPI_NONE))
     return -1;
-  return launch_gemm(s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, rows, D, 2 * D, EPI_NONE);
+  return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, rows, D, 2 * D, EPI_NONE);
 }
 
 // the draft's single decoder layer on `rows` rows of ctx->dx (cnets_ours.py:545-600); result in ctx->dout
@@ -453,17 +556,20 @@ static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, con
   const int D = c.hidden_size, Hd = c.draft_heads;
   bf16_t* kc = ctx->draft_kv;
   bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
-  if (launch_gemm(s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE)) return -1;
+  if (launch_gemm(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE)) return -1;
   if (launch_rope(s, ctx->dqkv, rows, Hd, Hd, ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos, 1)) return -1;
   if (launch_attention(ctx, s, ctx->dqkv, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, rows, prefix_dev, tail, mask, ctx->dattn, D, 0,
                        ctx->n_hint < c.draft_max_pos ? ctx->n_hint : c.draft_max_pos))
     return -1;
-  if (launch_gemm(s, ctx->dattn, D, ctx->dw.wo, nullptr, ctx->dh, D, ctx->dx, D, rows, D, D, EPI_RESIDUAL)) return -1;
-  if (launch_rmsnorm(s, ctx->dh, ctx->dw.ln2, ctx->dn, rows, D, c.draft_rms_eps)) return -1;
-  if (launch_gemm(s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, rows, c.draft_intermediate, D,
+  {
+    GemmOut o;  // o_proj + residual, post_attention_layernorm fused into the split-K reduce
+    o.Y = ctx->dh; o.ldy = D; o.R = ctx->dx; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
+    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, rows, D, D, EPI_RESIDUAL, o)) return -1;
+  }
+  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, rows, c.draft_intermediate, D,
                   EPI_SWIGLU))
     return -1;
-  return launch_gemm(s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dout, D, ctx->dh, D, rows, D,
+  return launch_gemm(ctx, s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dout, D, ctx->dh, D, rows, D,
                      c.draft_intermediate, EPI_RESIDUAL);
 }
 
@@ -472,7 +578,7 @@ static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, con
 static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
-  if (launch_gemm(s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE)) return -1;
+  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE)) return -1;
   hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(1), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
   KCHK();
   hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, ctx->in_h, D);
@@ -488,7 +594,7 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
     ps.kv_base = &ctx->st->draft_len;
     ps.kv_add = lvl * k;
     if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
-    if (launch_gemm(s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE)) return -1;
+    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE)) return -1;
     hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(k), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
     KCHK();
     hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(256), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
@@ -574,8 +680,8 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   bf16_t* avc = ctx->ad_kv + (size_t)Hd * c.draft_max_pos * 128;
   for (const Op& op : plan) {
     if (!op.is_adapt) {
-      for (int o = 0; o < op.n; o += ROWS) {
-        const int rows = std::min(ROWS, op.n - o), r0 = op.c_row + o;
+      for (int o = 0; o < op.n; o += CHUNK) {
+        const int rows = std::min(CHUNK, op.n - o), r0 = op.c_row + o;
         if (launch_gather(s, hidden, D, ctx->idx_tmp, r0, nullptr, ctx->dx1, 2 * D, rows, D)) return -1;
         if (launch_gather(s, ctx->emb_shift, D, ctx->idx_tmp, r0, nullptr, ctx->dx2, 2 * D, rows, D)) return -1;
         if (draft_fuse(ctx, s, rows, ctx->xc + (size_t)r0 * D, D)) return -1;
@@ -584,10 +690,10 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     }
     // ImgAdaptor (cnets_ours.py:630-661): K/V projection of the image rows into a [2][H][cap][hd] scratch cache ...
     const int N = op.n;
-    for (int o = 0; o < N; o += ROWS) {
-      const int rows = std::min(ROWS, N - o);
+    for (int o = 0; o < N; o += CHUNK) {
+      const int rows = std::min(CHUNK, N - o);
       if (launch_gather(s, ctx->emb_shift, D, ctx->idx_img, op.off + o, nullptr, ctx->dx, D, rows, D)) return -1;
-      if (launch_gemm(s, ctx->dx, D, ctx->dw.ad_wkv, ctx->dw.ad_bkv, ctx->ad_tmp, 2 * D, nullptr, 0, rows, 2 * D, D, EPI_NONE))
+      if (launch_gemm(ctx, s, ctx->dx, D, ctx->dw.ad_wkv, ctx->dw.ad_bkv, ctx->ad_tmp, 2 * D, nullptr, 0, rows, 2 * D, D, EPI_NONE))
         return -1;
       PosSpec ps;
       ps.kv_add = o;
@@ -599,7 +705,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     if (launch_attention(ctx, s, ctx->dw.ad_q, D, akc, avc, c.draft_max_pos, Hd, Hd, q, ctx->scratch_int, 0, nullptr, ctx->dattn, D,
                          0, N))
       return -1;
-    if (launch_gemm(s, ctx->dattn, D, ctx->dw.ad_wo, nullptr, ctx->ad_out, D, nullptr, 0, q, D, D, EPI_NONE)) return -1;
+    if (launch_gemm(ctx, s, ctx->dattn, D, ctx->dw.ad_wo, nullptr, ctx->ad_out, D, nullptr, 0, q, D, D, EPI_NONE)) return -1;
     // first q-1 outputs are the compressed tokens, the last is the new global feature g   (:928-930)
     if (q > 1)
       HIPCHK(hipMemcpyAsync(ctx->xc + (size_t)op.c_row * D, ctx->ad_out, (size_t)(q - 1) * D * sizeof(bf16_t),
@@ -610,9 +716,9 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   bf16_t* kc = ctx->draft_kv;
   bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
   int last_chunk_rows = 0;
-  for (int o = 0; o < Lc; o += ROWS) {
-    const int rows = std::min(ROWS, Lc - o);
-    if (launch_gemm(s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE))
+  for (int o = 0; o < Lc; o += CHUNK) {
+    const int rows = std::min(CHUNK, Lc - o);
+    if (launch_gemm(ctx, s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE))
       return -1;
     PosSpec ps;
     ps.off = ctx->pos_c + o;
@@ -626,12 +732,15 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   KCHK();
   if (launch_attention(ctx, s, qlast, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, 1, ctx->scratch_int, 0, nullptr, ctx->dattn, D, 0, Lc))
     return -1;
-  if (launch_gemm(s, ctx->dattn, D, ctx->dw.wo, nullptr, ctx->dh, D, xlast, D, 1, D, D, EPI_RESIDUAL)) return -1;
-  if (launch_rmsnorm(s, ctx->dh, ctx->dw.ln2, ctx->dn, 1, D, c.draft_rms_eps)) return -1;
-  if (launch_gemm(s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, 1, c.draft_intermediate, D,
+  {
+    GemmOut o;
+    o.Y = ctx->dh; o.ldy = D; o.R = xlast; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
+    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, 1, D, D, EPI_RESIDUAL, o)) return -1;
+  }
+  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, 1, c.draft_intermediate, D,
                   EPI_SWIGLU))
     return -1;
-  if (launch_gemm(s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dlast, D, ctx->dh, D, 1, D, c.draft_intermediate,
+  if (launch_gemm(ctx, s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dlast, D, ctx->dh, D, 1, D, c.draft_intermediate,
                   EPI_RESIDUAL))
     return -1;
   hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, s, ctx->st, first_token_dev, Lc, L);
@@ -651,23 +760,32 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
   ps.off = ctx->tb.tree_pos;
   ps.kv_base = &ctx->st->n_ctx;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
+  if (launch_rmsnorm(s, ctx->xa, ctx->layers[0].ln1, ctx->xn, T, D, c.rms_eps)) return -1;
   for (int l = 0; l < c.num_layers; ++l) {
     const vispec_layer_weights& w = ctx->layers[l];
     bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
     bf16_t* vc = ctx->target_kv + (size_t)(2 * l + 1) * slab;
-    if (launch_rmsnorm(s, ctx->xa, w.ln1, ctx->xn, T, D, c.rms_eps)) return -1;
-    if (launch_gemm(s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE)) return -1;
+    if (launch_gemm(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE)) return -1;
     if (launch_rope(s, ctx->qkv, T, H, Hk, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc, vc, c.max_pos, 1)) return -1;
     if (launch_attention(ctx, s, ctx->qkv, QKV, kc, vc, c.max_pos, H, Hk, T, &ctx->st->n_ctx, T, ctx->tb.tree_mask, ctx->attn_o,
                          H * 128, c.eager_scores, ctx->n_hint))
       return -1;
-    if (launch_gemm(s, ctx->attn_o, H * 128, w.wo, nullptr, ctx->xa, D, ctx->xa, D, T, D, H * 128, EPI_RESIDUAL)) return -1;
-    if (launch_rmsnorm(s, ctx->xa, w.ln2, ctx->xn, T, D, c.rms_eps)) return -1;
-    if (launch_gemm(s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU)) return -1;
-    if (launch_gemm(s, ctx->act, I, w.wdown, nullptr, ctx->xa, D, ctx->xa, D, T, D, I, EPI_RESIDUAL)) return -1;
+    {
+      GemmOut o;  // x += o_proj(attn) ; xn = post_attention_layernorm(x)   — one split-K GEMM + one reduce
+      o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.norm_w = w.ln2; o.normed = ctx->xn; o.ldn = D; o.eps = c.rms_eps;
+      if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, T, D, H * 128, EPI_RESIDUAL, o)) return -1;
+    }
+    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU)) return -1;
+    {
+      GemmOut o;  // x += down(act) ; then the NEXT layer's input_layernorm, or the final model.norm (hidden_states[-1] is post-norm)
+      const bool last = l + 1 == c.num_layers;
+      o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.eps = c.rms_eps; o.ldn = D;
+      o.norm_w = last ? ctx->tm.norm : ctx->layers[l + 1].ln1;
+      o.normed = last ? ctx->hidden_new : ctx->xn;
+      if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, T, D, I, EPI_RESIDUAL, o)) return -1;
+    }
   }
-  if (launch_rmsnorm(s, ctx->xa, ctx->tm.norm, ctx->hidden_new, T, D, c.rms_eps)) return -1;  // hidden_states[-1] is post-norm
-  if (launch_gemm(s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE)) return -1;
+  if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE)) return -1;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(256), 0, s, ctx->logits, V, V, ctx->am);
   KCHK();
   return 0;

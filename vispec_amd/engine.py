@@ -64,6 +64,18 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """Row-major nn.Linear weight [N, K] (bf16, on the GPU) -> the W32 tile layout the skinny GEMM streams
+    (include/vispec_hip.h: vispec_pack_weight).  One-time, at load."""
+    lib = L.load()
+    assert w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.is_contiguous()
+    N, K = w.shape
+    out = torch.empty(int(lib.vispec_packed_elems(N, K)), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(lib.vispec_pack_weight(None, C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream), _p(w), N, K, _p(out)))
+    return out
+
+
 class TargetWeights:
     """Target language-model weights on the device, fused for streaming: wqkv [ (H+2Hkv)*hd, D ], wgu [2I, D]."""
 
@@ -175,12 +187,21 @@ class Engine:
         self.h = h
         self.t_cos, self.t_sin = rope_tables(tcfg.head_dim, self.kv_max_pos, tcfg.rope_theta, self.device)
         self.d_cos, self.d_sin = rope_tables(dcfg.hidden_size // dcfg.num_heads, self.draft_max_pos, dcfg.rope_theta, self.device)
+        # W32-packed copies of every streamed GEMM weight (the row-major originals stay for the PyTorch prefill)
+        GEMM_T = ("wqkv", "wo", "wgu", "wdown")
+        if not hasattr(tw, "packed"):
+            tw.packed = [{k: pack_weight(lw[k]) for k in GEMM_T} for lw in tw.layers]
+            tw.p_lm_head = pack_weight(tw.lm_head)
+        GEMM_D = ("fc_w", "imgfc_w", "wqkv", "wo", "wgu", "wdown", "ad_wkv", "ad_wo")
+        if not hasattr(dw, "packed"):
+            dw.packed = {k: pack_weight(dw.t[k]) for k in GEMM_D}
         for i, lw in enumerate(tw.layers):
-            s = L.LayerWeights(**{k: _p(v) for k, v in lw.items()})
+            s = L.LayerWeights(**{k: _p(tw.packed[i][k] if k in GEMM_T else v) for k, v in lw.items()})
             L.check(self.lib.vispec_set_target_layer(self.h, i, C.byref(s)))
-        m = L.TargetMisc(embed=_p(tw.embed), norm=_p(tw.norm), lm_head=_p(tw.lm_head), rope_cos=_p(self.t_cos), rope_sin=_p(self.t_sin))
+        m = L.TargetMisc(embed=_p(tw.embed), norm=_p(tw.norm), lm_head=_p(tw.p_lm_head), rope_cos=_p(self.t_cos), rope_sin=_p(self.t_sin))
         L.check(self.lib.vispec_set_target_misc(self.h, C.byref(m)))
-        d = L.DraftWeights(rope_cos=_p(self.d_cos), rope_sin=_p(self.d_sin), **{k: _p(v) for k, v in dw.t.items()})
+        d = L.DraftWeights(rope_cos=_p(self.d_cos), rope_sin=_p(self.d_sin),
+                           **{k: _p(dw.packed[k] if k in GEMM_D else v) for k, v in dw.t.items()})
         L.check(self.lib.vispec_set_draft_weights(self.h, C.byref(d)))
         # KV buffers: target exactly in the reference layout (kv_cache.py:105-126); draft [2, H, max_pos, hd]
         self.target_kv = torch.zeros(2 * tcfg.num_layers, 1, tcfg.num_kv_heads, self.kv_max_pos, tcfg.head_dim,
@@ -245,8 +266,8 @@ class Engine:
     def ar_step(self):
         L.check(self.lib.vispec_ar_step(self.h, self._stream()))
 
-    PROF_KINDS = ["gemm_m16_none", "gemm_m16_residual", "gemm_m16_swiglu", "gemm_m32_none", "gemm_m32_residual", "gemm_m32_swiglu",
-                  "gemm_m64_none", "gemm_m64_residual", "gemm_m64_swiglu", "attn_partial", "attn_reduce"]
+    PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "k5", "k6", "k7", "k8",
+                  "attn_partial", "attn_reduce"]
 
     def prof_enable(self, on: bool):
         L.check(self.lib.vispec_prof_enable(self.h, int(on)))

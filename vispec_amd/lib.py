@@ -48,6 +48,10 @@ SIGNATURES = {
     "vispec_set_draft_weights": (c_int, [P, C.POINTER(DraftWeights)]),
     "vispec_set_kv": (c_int, [P, P, P]),
     "vispec_gemm_skinny": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int]),
+    "vispec_pack_weight": (c_int, [P, P, P, c_int, c_int, P]),
+    "vispec_packed_elems": (C.c_longlong, [c_int, c_int]),
+    "vispec_gemm_skinny_norm": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int, P, P, c_int, c_float, c_int, c_int, c_int]),
+    "vispec_gemm_skinny_tune": (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int]),
     "vispec_rmsnorm": (c_int, [P, P, P, P, P, c_int, c_int, c_float]),
     "vispec_rope_append": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P]),
     "vispec_tree_attention": (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int]),
@@ -86,6 +90,8 @@ def load(build_if_missing: bool = False) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64; loading ours before it would bring up a second, device-less HIP runtime
+    import torch  # noqa: F401
     if build_if_missing:
         from . import build as _b
         _b.build(verbose=False)
