@@ -274,7 +274,7 @@ def test_argmax_rows_first_max_wins(lib):
 
 
 @pytest.mark.parametrize("M,V,k", [(1, 32064, 8), (8, 1008, 8), (8, 152064, 8), (3, 1008, 16)])
-def test_logsoftmax_topk(lib, M, V, k):
+def test_logsoftmax_topk(lib, engine, M, V, k):
     rng = np.random.default_rng(V + M)
     o = vo.Ops(True)
     x = synth.bf16_grid(rng.standard_normal((M, V), dtype=np.float32) * 3)
@@ -282,7 +282,7 @@ def test_logsoftmax_topk(lib, M, V, k):
     X = tb(x)
     idx = torch.zeros(M, k, dtype=torch.int32, device=dev())
     lp = torch.zeros(M, k, dtype=torch.float32, device=dev())
-    L.check(lib.vispec_logsoftmax_topk(None, stream(), p(X), V, M, V, k, p(idx), p(lp)))
+    L.check(lib.vispec_logsoftmax_topk(engine.h, stream(), p(X), V, M, V, k, p(idx), p(lp)))
     torch.cuda.synchronize()
     want = o.log_softmax(x)
     got_lp, got_idx = lp.cpu().numpy(), idx.cpu().numpy()

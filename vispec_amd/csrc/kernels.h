@@ -242,16 +242,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
 
 // Finishes a split-K GEMM: y = bf16(sum_s part[s] + bias) ; h = bf16(R + y) if R ; optional fused RMSNorm of h
 // (cnets_ours.py:513-527) written to `normed`.  One workgroup per row m; every stage rounds where the reference's graph does.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int N,
+__global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int N,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                             bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
                                                             bf16_t* __restrict__ normed, int ldn, float eps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
   float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable) when a norm follows
-  __shared__ float partsum[4];
+  __shared__ float partsum[16];
   const int m = blockIdx.x;
+  const int nthreads = blockDim.x;
   float ss = 0.f;
-  for (int n = threadIdx.x * 4; n < N; n += 256 * 4) {
+  for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     float4 a = *reinterpret_cast<const float4*>(part + (size_t)m * N + n);
     for (int s = 1; s < S; ++s) {
       const float4 b = *reinterpret_cast<const float4*>(part + ((size_t)s * 32 + m) * N + n);
@@ -274,9 +275,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) partsum[threadIdx.x >> 6] = ss;
   __syncthreads();
-  const float tot = (partsum[0] + partsum[1]) + (partsum[2] + partsum[3]);
+  float tot = 0.f;
+  for (int w = 0; w < (nthreads >> 6); ++w) tot += partsum[w];
   const float inv = 1.0f / sqrtf(tot / (float)N + eps);
-  for (int n = threadIdx.x * 4; n < N; n += 256 * 4) {
+  for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     const float4 h = *reinterpret_cast<const float4*>(hrow + n);
     const uint2 wv = *reinterpret_cast<const uint2*>(norm_w + n);
     const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
@@ -504,24 +506,37 @@ __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(const float* __re
   const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
   const int head = blockIdx.x / MT, mt = blockIdx.x % MT;
   const int kvh = head / G, qt = (head % G) * MT + mt;
+  const int dpart = blockIdx.y;  // 4 blocks per (head, m-tile): 32 d-rows each
   const int n_total = (prefix_dev ? *prefix_dev : 0) + tail;
   const int ns = min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg);
   const size_t base = (size_t)(kvh * NQT + qt) * nsplit;
-  if (threadIdx.x < 32) {
-    const int q = threadIdx.x;
+  {
+    __shared__ float smax[8][32], ssum[8][32];
+    const int q = threadIdx.x & 31, s8 = threadIdx.x >> 5;
     float mm = NEG_INF;
-    for (int s = 0; s < ns; ++s) mm = fmaxf(mm, part_ml[(base + s) * 64 + q]);
+    for (int s = s8; s < ns; s += 8) mm = fmaxf(mm, part_ml[(base + s) * 64 + q]);
+    smax[s8][q] = mm;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mm = fmaxf(mm, smax[t][q]);
     float L = 0.f;
-    for (int s = 0; s < ns; ++s) {
-      float ms = part_ml[(base + s) * 64 + q];
-      float w = (ms == NEG_INF) ? 0.f : __expf(ms - mm);
+    for (int s = s8; s < ns; s += 8) {
+      const float ms = part_ml[(base + s) * 64 + q];
+      const float w = (ms == NEG_INF) ? 0.f : __expf(ms - mm);
       wgt[s][q] = w;
       L += w * part_ml[(base + s) * 64 + 32 + q];
     }
-    linv[q] = (L > 0.f) ? 1.0f / L : 0.f;
+    ssum[s8][q] = L;
+    __syncthreads();
+    if (s8 == 0) {
+      float Lt = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Lt += ssum[t][q];
+      linv[q] = (Lt > 0.f) ? 1.0f / Lt : 0.f;
+    }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 128 * 32; e += 256) {
+  for (int e = dpart * 1024 + threadIdx.x; e < (dpart + 1) * 1024; e += 256) {
     const int d = e >> 5, q = e & 31;
     float acc = 0.f;
     for (int s = 0; s < ns; ++s) acc += wgt[s][q] * part_o[(base + s) * (128 * 32) + e];
@@ -588,68 +603,133 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restri
 }
 
 #define TOPK_MAX 16
-__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k,
-                                                              int* __restrict__ out_idx, float* __restrict__ out_logp) {
+#define LSTK_CHUNKS 64
+// log-softmax + top-k of bf16 logit rows, three small multi-workgroup passes (a single workgroup per 32k-wide row took 255 us):
+//   1. per-chunk max / sum-exp                         grid (rows, LSTK_CHUNKS)
+//   2. per-chunk top-k under the exact key (bf16(x - lse) desc, index asc)   grid (rows, LSTK_CHUNKS)
+//   3. merge of the LSTK_CHUNKS*k candidates            grid (rows)
+__device__ __forceinline__ void lstk_chunk_range(int V, int chunk, int& lo, int& hi) {
+  const int per = ((V + LSTK_CHUNKS - 1) / LSTK_CHUNKS + 7) & ~7;
+  lo = chunk * per;
+  hi = min(V, lo + per);
+}
+
+__global__ __launch_bounds__(256) void lstk_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, float* __restrict__ stats) {
   __shared__ float s_red[4];
-  __shared__ float s_v[256 * TOPK_MAX];
-  __shared__ int s_i[256 * TOPK_MAX];
-  __shared__ float s_bv[4];
-  __shared__ int s_bi[4], s_bs[4];
   const bf16_t* x = logits + (size_t)blockIdx.x * ld;
+  int lo, hi;
+  lstk_chunk_range(V, blockIdx.y, lo, hi);
   const int tid = threadIdx.x;
-  // pass 1: max ; pass 2: sum exp  (fp32, like torch's log_softmax on a bf16 tensor)
   float mx = NEG_INF;
-  for (int d = tid; d < V; d += 256) mx = fmaxf(mx, bf2f(x[d]));
+  for (int d = lo + tid; d < hi; d += 256) mx = fmaxf(mx, bf2f(x[d]));
   mx = wave_max(mx);
   if ((tid & 63) == 0) s_red[tid >> 6] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   __syncthreads();
   float se = 0.f;
-  for (int d = tid; d < V; d += 256) se += __expf(bf2f(x[d]) - mx);
+  for (int d = lo + tid; d < hi; d += 256) se += __expf(bf2f(x[d]) - mx);
   se = wave_sum(se);
   if ((tid & 63) == 0) s_red[tid >> 6] = se;
   __syncthreads();
-  const float lse = mx + __logf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
-  // pass 3: per-thread top-k of bf16(x - lse) (sorted insertion), then k rounds of block-wide selection
-  float tv[TOPK_MAX];
-  int ti[TOPK_MAX];
-#pragma unroll
-  for (int q = 0; q < TOPK_MAX; ++q) { tv[q] = NEG_INF; ti[q] = 0x7fffffff; }
-  for (int d = tid; d < V; d += 256) {
-    float lp = rdbf(bf2f(x[d]) - lse);
-    if (better(lp, d, tv[TOPK_MAX - 1], ti[TOPK_MAX - 1])) {
-      tv[TOPK_MAX - 1] = lp; ti[TOPK_MAX - 1] = d;
-#pragma unroll
-      for (int q = TOPK_MAX - 1; q > 0; --q)
-        if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
-          float a = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = a;
-          int b = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = b;
-        }
-    }
+  if (tid == 0) {
+    float* o = stats + ((size_t)blockIdx.x * LSTK_CHUNKS + blockIdx.y) * 2;
+    o[0] = mx;
+    o[1] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
-#pragma unroll
-  for (int q = 0; q < TOPK_MAX; ++q) { s_v[tid * TOPK_MAX + q] = tv[q]; s_i[tid * TOPK_MAX + q] = ti[q]; }
-  int head = 0;  // next unconsumed entry of this thread's sorted list
-  __syncthreads();
+}
+
+__device__ __forceinline__ float lstk_lse(const float* __restrict__ st) {  // fixed-order combine of the chunk stats
+  float mx = NEG_INF;
+  for (int c = 0; c < LSTK_CHUNKS; ++c) mx = fmaxf(mx, st[2 * c]);
+  float se = 0.f;
+  for (int c = 0; c < LSTK_CHUNKS; ++c) se += (st[2 * c] == NEG_INF) ? 0.f : st[2 * c + 1] * __expf(st[2 * c] - mx);
+  return mx + __logf(se);
+}
+
+// block-wide selection of the k best (value desc, index asc) among per-thread candidate pairs held in LDS
+__device__ __forceinline__ void block_select_topk(float* s_v, int* s_i, int n_cand, int k, float* out_v, int* out_i) {
+  __shared__ float w_v[4];
+  __shared__ int w_i[4], w_s[4];
+  const int tid = threadIdx.x;
   for (int sel = 0; sel < k; ++sel) {
-    float bv = (head < TOPK_MAX) ? s_v[tid * TOPK_MAX + head] : NEG_INF;
-    int bi = (head < TOPK_MAX) ? s_i[tid * TOPK_MAX + head] : 0x7fffffff;
-    int bs = tid;
+    float bv = NEG_INF;
+    int bi = 0x7fffffff, bs = -1;
+    for (int c = tid; c < n_cand; c += 256) {
+      const float v = s_v[c];
+      const int ix = s_i[c];
+      if (better(v, ix, bv, bi)) { bv = v; bi = ix; bs = c; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      float ov = __shfl_xor(bv, o);
-      int oi = __shfl_xor(bi, o);
-      int os = __shfl_xor(bs, o);
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o), os = __shfl_xor(bs, o);
       if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bs = os; }
     }
-    if ((tid & 63) == 0) { s_bv[tid >> 6] = bv; s_bi[tid >> 6] = bi; s_bs[tid >> 6] = bs; }
+    if ((tid & 63) == 0) { w_v[tid >> 6] = bv; w_i[tid >> 6] = bi; w_s[tid >> 6] = bs; }
     __syncthreads();
-    float gv = s_bv[0]; int gi = s_bi[0], gs = s_bs[0];
+    float gv = w_v[0];
+    int gi = w_i[0], gs = w_s[0];
     for (int w = 1; w < 4; ++w)
-      if (better(s_bv[w], s_bi[w], gv, gi)) { gv = s_bv[w]; gi = s_bi[w]; gs = s_bs[w]; }
-    if (tid == gs) ++head;
-    if (tid == 0) { out_idx[blockIdx.x * k + sel] = gi; out_logp[blockIdx.x * k + sel] = gv; }
+      if (better(w_v[w], w_i[w], gv, gi)) { gv = w_v[w]; gi = w_i[w]; gs = w_s[w]; }
+    if (tid == 0) {
+      out_v[sel] = gv;
+      out_i[sel] = gi;
+      if (gs >= 0) { s_v[gs] = NEG_INF; s_i[gs] = 0x7fffffff; }
+    }
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void lstk_select_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k,
+                                                          const float* __restrict__ stats, float* __restrict__ cand_v,
+                                                          int* __restrict__ cand_i) {
+  __shared__ float s_v[1024];
+  __shared__ int s_i[1024];
+  __shared__ float s_lse;
+  const bf16_t* x = logits + (size_t)blockIdx.x * ld;
+  int lo, hi;
+  lstk_chunk_range(V, blockIdx.y, lo, hi);
+  if (threadIdx.x == 0) s_lse = lstk_lse(stats + (size_t)blockIdx.x * LSTK_CHUNKS * 2);
+  __syncthreads();
+  const float lse = s_lse;
+  const int n = max(0, hi - lo);
+  float* ov = cand_v + ((size_t)blockIdx.x * LSTK_CHUNKS + blockIdx.y) * TOPK_MAX;
+  int* oi = cand_i + ((size_t)blockIdx.x * LSTK_CHUNKS + blockIdx.y) * TOPK_MAX;
+  for (int base = 0; base == 0 || base < n; base += 1024 - TOPK_MAX) {
+    // (chunks are <= 1024 wide for every vocabulary up to 64k; wider chunks are folded in rounds that keep the running best)
+    const int m = min(n - base, 1024 - (base ? TOPK_MAX : 0));
+    const int off = base ? TOPK_MAX : 0;
+    if (base) {
+      if (threadIdx.x < TOPK_MAX) { s_v[threadIdx.x] = threadIdx.x < k ? ov[threadIdx.x] : NEG_INF; s_i[threadIdx.x] = threadIdx.x < k ? oi[threadIdx.x] : 0x7fffffff; }
+    }
+    for (int c = threadIdx.x; c < m; c += 256) {
+      s_v[off + c] = rdbf(bf2f(x[lo + base + c]) - lse);
+      s_i[off + c] = lo + base + c;
+    }
+    __syncthreads();
+    block_select_topk(s_v, s_i, off + max(m, 0), k, ov, oi);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void lstk_merge_kernel(int k, const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                         int* __restrict__ out_idx, float* __restrict__ out_logp) {
+  __shared__ float s_v[LSTK_CHUNKS * TOPK_MAX];
+  __shared__ int s_i[LSTK_CHUNKS * TOPK_MAX];
+  __shared__ float o_v[TOPK_MAX];
+  __shared__ int o_i[TOPK_MAX];
+  const float* cv = cand_v + (size_t)blockIdx.x * LSTK_CHUNKS * TOPK_MAX;
+  const int* ci = cand_i + (size_t)blockIdx.x * LSTK_CHUNKS * TOPK_MAX;
+  for (int c = threadIdx.x; c < LSTK_CHUNKS * TOPK_MAX; c += 256) {
+    const bool valid = (c % TOPK_MAX) < k;
+    s_v[c] = valid ? cv[c] : NEG_INF;
+    s_i[c] = valid ? ci[c] : 0x7fffffff;
+  }
+  __syncthreads();
+  block_select_topk(s_v, s_i, LSTK_CHUNKS * TOPK_MAX, k, o_v, o_i);
+  if (threadIdx.x < k) {
+    out_idx[blockIdx.x * k + threadIdx.x] = o_i[threadIdx.x];
+    out_logp[blockIdx.x * k + threadIdx.x] = o_v[threadIdx.x];
   }
 }

@@ -52,6 +52,8 @@ struct vispec_ctx {
   TreeBufs tb{};
   // attention partials
   float *part_o, *part_ml;
+  float *lstk_stats = nullptr, *lstk_cv = nullptr;  // log-softmax/top-k scratch [64 rows][LSTK_CHUNKS]...
+  int* lstk_ci = nullptr;
   float* gemm_part = nullptr;  // split-K partial sums [S<=8][32][N]
   size_t gemm_part_elems = 0;
   size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
@@ -144,6 +146,7 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
     if (nmax < 16384) nmax = 16384;
     ctx->gemm_part_elems = (size_t)8 * 32 * nmax;
     A(gemm_part, ctx->gemm_part_elems);
+    A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
   }
 #undef A
   ctx->n_hint = c.max_pos;
@@ -303,7 +306,7 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 4096 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
                      epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn,
                      o.eps);
   KCHK();
@@ -402,7 +405,7 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   KCHK();
   prof_end(s);
   prof_begin(s, PROF_ATT_REDUCE, 0.0);
-  hipLaunchKernelGGL(tree_attn_reduce_kernel, dim3(H * MT), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
+  hipLaunchKernelGGL(tree_attn_reduce_kernel, dim3(H * MT, 4), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
                      tail, kpw, nsplit, (bf16_t*)out, ldo);
   KCHK();
   prof_end(s);
@@ -419,6 +422,20 @@ static int launch_gather(hipStream_t s, const void* table, int ld_t, const int* 
 }
 static int launch_bcast(hipStream_t s, const void* vec, void* out, int ld_o, int rows, int D) {
   hipLaunchKernelGGL(bcast_row_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)vec, (bf16_t*)out, ld_o, D);
+  KCHK();
+  return 0;
+}
+
+static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int ld, int M, int V, int k, int* out_idx, float* out_logp) {
+  if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
+  if (M < 1 || M > 64) return fail("logsoftmax_topk: M must be in [1,64]");
+  if (!ctx) return fail("logsoftmax_topk: needs a ctx (scratch)");
+  hipLaunchKernelGGL(lstk_stats_kernel, dim3(M, LSTK_CHUNKS), dim3(256), 0, s, (const bf16_t*)logits, ld, V, ctx->lstk_stats);
+  KCHK();
+  hipLaunchKernelGGL(lstk_select_kernel, dim3(M, LSTK_CHUNKS), dim3(256), 0, s, (const bf16_t*)logits, ld, V, k, ctx->lstk_stats,
+                     ctx->lstk_cv, ctx->lstk_ci);
+  KCHK();
+  hipLaunchKernelGGL(lstk_merge_kernel, dim3(M), dim3(256), 0, s, k, ctx->lstk_cv, ctx->lstk_ci, out_idx, out_logp);
   KCHK();
   return 0;
 }
@@ -497,13 +514,9 @@ extern "C" int vispec_argmax_rows(vispec_ctx*, void* stream, const void* logits,
   KCHK();
   return 0;
 }
-extern "C" int vispec_logsoftmax_topk(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int k, int* out_idx,
+extern "C" int vispec_logsoftmax_topk(vispec_ctx* ctx, void* stream, const void* logits, int ld, int M, int V, int k, int* out_idx,
                                       float* out_logp) {
-  if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
-  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, k,
-                     out_idx, out_logp);
-  KCHK();
-  return 0;
+  return launch_lstopk(ctx, (hipStream_t)stream, logits, ld, M, V, k, out_idx, out_logp);
 }
 
 // ------------------------------------------------------------------------------------------------ the path
@@ -579,8 +592,7 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
   if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE)) return -1;
-  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(1), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
-  KCHK();
+  if (launch_lstopk(ctx, s, ctx->dlogits, V, 1, V, k, ctx->top_idx, ctx->top_logp)) return -1;
   hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, ctx->in_h, D);
   KCHK();
   for (int lvl = 0; lvl < c.depth; ++lvl) {
@@ -595,8 +607,7 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
     ps.kv_add = lvl * k;
     if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
     if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE)) return -1;
-    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(k), dim3(256), 0, s, ctx->dlogits, V, V, k, ctx->top_idx, ctx->top_logp);
-    KCHK();
+    if (launch_lstopk(ctx, s, ctx->dlogits, V, k, V, k, ctx->top_idx, ctx->top_logp)) return -1;
     hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(256), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
                        ctx->in_h, D);
     KCHK();
