@@ -335,20 +335,23 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 //   The 4 waves' partial (m, l, O) are merged through LDS and written as one partial per (q-tile, split).
 //   Visibility: key < prefix -> visible to all rows; prefix <= key < prefix+tail -> bit (key-prefix) of mask[row].
 // ------------------------------------------------------------------------------------------------
-#define ATT_CHUNK 128
+#define ATT_CHUNK 64
 __device__ __forceinline__ int att_swz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 15) << 4)); }
+// LDS: two 64-key buffers of K (16 KB) + V (16 KB) each; the merge area aliases buffer 0 after the last chunk
+#define ATT_LDS_BYTES (2 * 2 * ATT_CHUNK * 256 + 1024)
 
 template <bool EAGER>
-__global__ __launch_bounds__(256) void tree_attn_partial_kernel(
+__global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
     const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vc, int s_max, int H,
     int H_kv, int M, const int* __restrict__ prefix_dev, int tail, const unsigned long long* __restrict__ mask,
     float* __restrict__ part_o, float* __restrict__ part_ml, int keys_per_wg, int nsplit) {
+  // grid (nsplit, H_kv), 256 threads = 4 waves arranged 2 (key tiles of a 64-key chunk) x 2 (halves of head_dim for P·V).
+  // Chunks stream HBM -> registers -> LDS with the NEXT chunk's loads in flight while the current one is on the matrix
+  // cores (one barrier per chunk); two workgroups per CU overlap each other's barriers.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sK = smem;                          // 32 KB (aliased by the merge buffer at the end)
-  unsigned char* sV = smem + ATT_CHUNK * 256;        // 32 KB
-  float* sM = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 256);  // [4][32] m, then [4][32] l
   const int split = blockIdx.x, kvh = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int kt = wave & 1, dh = wave >> 1;  // key tile / head_dim half owned by this wave
   const int j = lane & 31, hi = lane >> 5;
   const int n_prefix = prefix_dev ? *prefix_dev : 0;
   const int n_total = n_prefix + tail;
@@ -361,6 +364,9 @@ __global__ __launch_bounds__(256) void tree_attn_partial_kernel(
   const int nchunk = (key_end - key0 + ATT_CHUNK - 1) / ATT_CHUNK;
   const float scale = 0.08838834764831845f;  // 1/sqrt(128)
   const float sqrt_hd = 11.313708498984761f;
+  // staging map: thread -> 4 x 16 B of K and of V per chunk (row = s>>4, 16-B column = s&15), rows past the end are
+  // clamped to the last valid key (never visible: masked by key >= n_total) so every load stays unconditional
+  const int last_key = n_total - 1;
 
   for (int qt = 0; qt < NQT; ++qt) {
     const int head = kvh * G + qt / MT, m0 = (qt % MT) * 32;
@@ -369,56 +375,65 @@ __global__ __launch_bounds__(256) void tree_attn_partial_kernel(
     uint4 qf[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-      qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(Q + (size_t)mrow * ldq + head * 128 + ks * 16 + hi * 8)
-                      : make_uint4(0, 0, 0, 0);
+      qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)(qvalid ? mrow : 0) * ldq + head * 128 + ks * 16 + hi * 8);
     const unsigned long long mbits = (qvalid && mask) ? mask[mrow] : 0ull;
     float m_run = NEG_INF, l_run = 0.f;
-    f32x16 O[4];
+    f32x16 O[2];
 #pragma unroll
-    for (int hb = 0; hb < 4; ++hb)
+    for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[hb][r] = 0.f;
 
+    // staging registers as named scalars + macros: arrays captured by a lambda (or conditionally written in the loop) were
+    // kept in scratch memory by hipcc (scratch_store/scratch_load around every chunk)
+    uint4 k0r, k1r, k2r, k3r, v0r, v1r, v2r, v3r;
+    const int srow = threadIdx.x >> 4, sc16 = threadIdx.x & 15;  // + 16 rows per p
+#define ATT_G1(kk, vv, p, ch)                                                               \
+  {                                                                                         \
+    const int key_ = min(key0 + (ch) * ATT_CHUNK + srow + 16 * (p), last_key);              \
+    kk = *reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8);               \
+    vv = *reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8);               \
+  }
+#define ATT_GLOAD(ch) ATT_G1(k0r, v0r, 0, ch) ATT_G1(k1r, v1r, 1, ch) ATT_G1(k2r, v2r, 2, ch) ATT_G1(k3r, v3r, 3, ch)
+#define ATT_W1(kk, vv, p, sK_, sV_)                                                         \
+  *reinterpret_cast<uint4*>(sK_ + att_swz(srow + 16 * (p), sc16 * 16)) = kk;                \
+  *reinterpret_cast<uint4*>(sV_ + att_swz(srow + 16 * (p), sc16 * 16)) = vv;
+#define ATT_LWRITE(buf)                                                                     \
+  {                                                                                         \
+    unsigned char* sK_ = smem + (buf) * (2 * ATT_CHUNK * 256);                              \
+    unsigned char* sV_ = sK_ + ATT_CHUNK * 256;                                             \
+    ATT_W1(k0r, v0r, 0, sK_, sV_) ATT_W1(k1r, v1r, 1, sK_, sV_) ATT_W1(k2r, v2r, 2, sK_, sV_) ATT_W1(k3r, v3r, 3, sK_, sV_) \
+  }
+    __syncthreads();  // previous q-tile's merge is done with the LDS
+    ATT_GLOAD(0)
+    ATT_LWRITE(0)
+    __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
-      const int c0 = key0 + ch * ATT_CHUNK;
-      {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          const int s = p * 256 + threadIdx.x, row = s >> 4, c16 = s & 15;
-          const int key = c0 + row;
-          uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-          if (key < key_end) {
-            kv4 = *reinterpret_cast<const uint4*>(Kh + (size_t)key * 128 + c16 * 8);
-            vv4 = *reinterpret_cast<const uint4*>(Vh + (size_t)key * 128 + c16 * 8);
-          }
-          *reinterpret_cast<uint4*>(sK + att_swz(row, c16 * 16)) = kv4;
-          *reinterpret_cast<uint4*>(sV + att_swz(row, c16 * 16)) = vv4;
-        }
-        __syncthreads();
-      }
-      const int kbase = c0 + wave * 32;
+      const int buf = ch & 1;
+      if (ch + 1 < nchunk) { ATT_GLOAD(ch + 1) }  // in flight during the MFMA work below
+      const unsigned char* sK = smem + buf * (2 * ATT_CHUNK * 256);
+      const unsigned char* sV = sK + ATT_CHUNK * 256;
+      const int kbase = key0 + ch * ATT_CHUNK + kt * 32;
       if (kbase < key_end) {
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        const int krow = wave * 32 + j;
+        const int krow = kt * 32 + j;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
+          const uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
           S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
         }
-        float sc[16];
         float mx = NEG_INF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float s = EAGER ? rdbf(rdbf(S[r]) / sqrt_hd) : S[r] * scale;
+          float sc = EAGER ? rdbf(rdbf(S[r]) / sqrt_hd) : S[r] * scale;
           bool vis = key < n_prefix;
           if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
-          s = vis ? s : NEG_INF;
-          sc[r] = s;
-          mx = fmaxf(mx, s);
+          sc = vis ? sc : NEG_INF;
+          S[r] = sc;
+          mx = fmaxf(mx, sc);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
@@ -427,8 +442,8 @@ __global__ __launch_bounds__(256) void tree_attn_partial_kernel(
         unsigned pb[8];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          float p0 = (sc[r] == NEG_INF) ? 0.f : __expf(sc[r] - m_new);
-          float p1 = (sc[r + 1] == NEG_INF) ? 0.f : __expf(sc[r + 1] - m_new);
+          const float p0 = (S[r] == NEG_INF) ? 0.f : __expf(S[r] - m_new);
+          const float p1 = (S[r + 1] == NEG_INF) ? 0.f : __expf(S[r + 1] - m_new);
           psum += p0 + p1;
           pb[r >> 1] = pack2(p0, p1);
         }
@@ -436,62 +451,61 @@ __global__ __launch_bounds__(256) void tree_attn_partial_kernel(
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int hb = 0; hb < 4; ++hb)
+        for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) O[hb][r] *= alpha;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          uint4 pB = make_uint4(pb[kb * 4 + 0], pb[kb * 4 + 1], pb[kb * 4 + 2], pb[kb * 4 + 3]);
+          const uint4 pB = make_uint4(pb[kb * 4 + 0], pb[kb * 4 + 1], pb[kb * 4 + 2], pb[kb * 4 + 3]);
 #pragma unroll
-          for (int hb = 0; hb < 4; ++hb) {
+          for (int hb = 0; hb < 2; ++hb) {
+            const int col = ((dh * 2 + hb) * 32 + j) * 2;
             unsigned va[4];
 #pragma unroll
             for (int t2 = 0; t2 < 4; ++t2) {
               const int ta = 2 * t2, tb = 2 * t2 + 1;
-              const int ra = wave * 32 + (ta & 3) + 8 * (ta >> 2) + 4 * hi + 16 * kb;
-              const int rb = wave * 32 + (tb & 3) + 8 * (tb >> 2) + 4 * hi + 16 * kb;
-              const unsigned lo = *reinterpret_cast<const bf16_t*>(sV + att_swz(ra, (hb * 32 + j) * 2));
-              const unsigned hi16 = *reinterpret_cast<const bf16_t*>(sV + att_swz(rb, (hb * 32 + j) * 2));
+              const int ra = kt * 32 + (ta & 3) + 8 * (ta >> 2) + 4 * hi + 16 * kb;
+              const int rb = kt * 32 + (tb & 3) + 8 * (tb >> 2) + 4 * hi + 16 * kb;
+              const unsigned lo = *reinterpret_cast<const bf16_t*>(sV + att_swz(ra, col));
+              const unsigned hi16 = *reinterpret_cast<const bf16_t*>(sV + att_swz(rb, col));
               va[t2] = lo | (hi16 << 16);
             }
-            uint4 vA = make_uint4(va[0], va[1], va[2], va[3]);
+            const uint4 vA = make_uint4(va[0], va[1], va[2], va[3]);
             O[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vA), as_bf16x8(pB), O[hb], 0, 0, 0);
           }
         }
       }
+      if (ch + 1 < nchunk) ATT_LWRITE(buf ^ 1)  // buffer buf^1 was last read before the previous barrier
+      __syncthreads();
     }
-    // ---- merge the 4 waves' (m, l, O) ----
-    __syncthreads();  // all waves done with sK/sV of the last chunk
-    if (hi == 0) {
-      sM[wave * 32 + j] = m_run;
-    }
+    // ---- merge the two key-tile waves of each head_dim half (the (m,l) of equal-kt waves are bit-identical) ----
+    float* sM = reinterpret_cast<float*>(smem + 2 * 2 * ATT_CHUNK * 256);  // [2 kt][32] m, then [2][32] l
+    float* sO = reinterpret_cast<float*>(smem);                            // [128 hd][32 q] fp32 (aliases buffer 0)
+    if (dh == 0 && hi == 0) sM[kt * 32 + j] = m_run;
     __syncthreads();
-    float m_all = fmaxf(fmaxf(sM[j], sM[32 + j]), fmaxf(sM[64 + j], sM[96 + j]));
+    const float m_all = fmaxf(sM[j], sM[32 + j]);
     const float f = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_all);
-    if (hi == 0) sM[128 + wave * 32 + j] = l_run * f;
-    float* sO = reinterpret_cast<float*>(sK);  // [128 hd][32 q] fp32 = 16 KB
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
+    if (dh == 0 && hi == 0) sM[64 + kt * 32 + j] = l_run * f;
+    for (int t = 0; t < 2; ++t) {
+      if (kt == t) {
 #pragma unroll
-        for (int hb = 0; hb < 4; ++hb)
+        for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int drow = hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float v = O[hb][r] * f;
-            if (w == 0) sO[drow * 32 + j] = v; else sO[drow * 32 + j] += v;
+            const int drow = (dh * 2 + hb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float v = O[hb][r] * f;
+            if (t == 0) sO[drow * 32 + j] = v; else sO[drow * 32 + j] += v;
           }
       }
       __syncthreads();
     }
     const size_t pidx = ((size_t)(kvh * NQT + qt) * nsplit + split);
-    float* po = part_o + pidx * (128 * 32);
-    for (int e = threadIdx.x; e < 128 * 32; e += 256) po[e] = sO[e];
+    float4* po = reinterpret_cast<float4*>(part_o + pidx * (128 * 32));
+    for (int e = threadIdx.x; e < 128 * 32 / 4; e += 256) po[e] = reinterpret_cast<const float4*>(sO)[e];
     if (threadIdx.x < 32) {
-      float l_all = (sM[128 + threadIdx.x] + sM[160 + threadIdx.x]) + (sM[192 + threadIdx.x] + sM[224 + threadIdx.x]);
-      part_ml[pidx * 64 + threadIdx.x] = m_all;  // every lane with the same j computed the same m_all
-      part_ml[pidx * 64 + 32 + threadIdx.x] = l_all;
+      part_ml[pidx * 64 + threadIdx.x] = fmaxf(sM[threadIdx.x], sM[32 + threadIdx.x]);
+      part_ml[pidx * 64 + 32 + threadIdx.x] = sM[64 + threadIdx.x] + sM[96 + threadIdx.x];
     }
-    __syncthreads();
   }
 }
 

@@ -150,7 +150,7 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   }
 #undef A
   ctx->n_hint = c.max_pos;
-  const int lds = 2 * ATT_CHUNK * 256 + 1024;
+  const int lds = ATT_LDS_BYTES;
   if (hipFuncSetAttribute((const void*)tree_attn_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
           hipSuccess ||
       hipFuncSetAttribute((const void*)tree_attn_partial_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -393,7 +393,7 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
   if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
-  const int lds = 2 * ATT_CHUNK * 256 + 1024;
+  const int lds = ATT_LDS_BYTES;
   dim3 grid(nsplit, H_kv), block(256);
   prof_begin(s, PROF_ATT_PARTIAL, 0.0);
   if (eager)
