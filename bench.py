@@ -193,6 +193,16 @@ def main():
 
     extra = {}
     if rank == 0:
+        # ---- clean (un-instrumented) split of one request into prefill and decode wall time
+        ids, pix = reqs[W]
+        torch.cuda.synchronize()
+        t1 = time.time()
+        out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                                return_decode_time=True)
+        torch.cuda.synchronize()
+        t_req = time.time() - t1
+        extra["request_split"] = dict(wall_s=round(t_req, 4), prefill_s=round(t_req - t_dec_clean, 4), decode_s=round(t_dec_clean, 4),
+                                      rounds=idx + 1, ms_per_round=round(1e3 * t_dec_clean / (idx + 1), 3))
         # ---- decode-only rate + roofline leg: one more request with HIP events around every skinny-GEMM / attention launch
         ids, pix = reqs[W]
         torch.cuda.synchronize()

@@ -24,20 +24,22 @@ for M in (30, 8):
     for name, N, K in SHAPES:
         nbuf = max(2, int(1.5e9 // (N * K * 2)))
         Ws = [pack_weight((torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)) for _ in range(nbuf)]
-        X = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        PAD = int(os.environ.get("XPAD", "0"))
+        Xfull = torch.randn(M, K + PAD, device=dev, dtype=torch.bfloat16)
+        X = Xfull
         Y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         res = []
         for v in variants:
-            if (v // 100) * 32 * N > 8 * 32 * 16384:
+            if ((v % 10000) // 100) * 32 * N > 8 * 32 * 16384:
                 continue
             for w in Ws[:2]:
-                L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K, p(w), p(Y), N, M, N, K))
+                L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K + PAD, p(w), p(Y), N, M, N, K))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             iters = 3 * nbuf
             e0.record()
             for i in range(iters):
-                L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K, p(Ws[i % nbuf]), p(Y), N, M, N, K))
+                L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K + PAD, p(Ws[i % nbuf]), p(Y), N, M, N, K))
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters

@@ -130,14 +130,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     uint4 a[NT][UNROLL];
     uint4 x[NINST];
   };
-  auto load = [&](Regs& g) {  // all loads unconditional plain global loads (see the note in the commit history / DESIGN.md)
+  auto load = [&](Regs& g) {  // all loads unconditional plain global loads; X first (it is consumed first, through LDS)
+#pragma unroll
+    for (int i = 0; i < NINST; ++i) g.x[i] = *reinterpret_cast<const uint4*>(sx[i]);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       g.a[0][u] = pa0[u * 64];
       if (NT == 2) g.a[NT - 1][u] = pa1[u * 64];
     }
-#pragma unroll
-    for (int i = 0; i < NINST; ++i) g.x[i] = *reinterpret_cast<const uint4*>(sx[i]);
     pa0 += 64 * UNROLL;
     pa1 += 64 * UNROLL;
 #pragma unroll
@@ -158,17 +158,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
   };
   const int n_steps = w_hi - w_lo;
   const int n_groups = n_steps / UNROLL;  // wave-uniform
-  if (n_groups > 0) {  // register double-buffering: group g+1 is in flight while group g feeds the matrix core
+  if (n_groups > 0) {
+    // Register double-buffering: group g+1 is in flight while group g feeds the matrix core.  The steady-state loop issues
+    // its prefetch UNCONDITIONALLY: a prefetch under `if (more)` makes hipcc size every s_waitcnt for the no-prefetch path,
+    // i.e. it waits for the prefetch it just issued (seen in the ISA as vmcnt(3..0) with 16 loads outstanding).
     Regs r0, r1;
     load(r0);
-    int gi = 1;
-    while (true) {
-      if (gi < n_groups) load(r1);
+    int g = 0;
+    while (g + 2 < n_groups) {
+      load(r1);
       compute(r0, 0);
-      if (++gi > n_groups) break;
-      if (gi < n_groups) load(r0);
+      load(r0);
       compute(r1, 1);
-      if (++gi > n_groups) break;
+      g += 2;
+    }
+    if (g + 1 < n_groups) {
+      load(r1);
+      compute(r0, 0);
+      compute(r1, 1);
+    } else {
+      compute(r0, 0);
     }
   }
   {  // < UNROLL leftover k-steps: fragment-shaped X loads straight from global

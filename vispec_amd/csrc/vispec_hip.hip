@@ -465,6 +465,8 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P;
   const int tiles = (N + 31) / 32;
+  const bool no_reduce = variant >= 10000;  // time the GEMM kernel alone
+  variant %= 10000;
   const int S = variant / 100, nwc = (variant / 10) % 10, unc = variant % 10;
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
@@ -481,6 +483,7 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   }
 #undef V
   KCHK();
+  if (no_reduce) return 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), 0, s, ctx->gemm_part, S, N, nullptr, nullptr, 0, (bf16_t*)Y, ldy, nullptr,
                      nullptr, 0, 0.f);
   KCHK();
