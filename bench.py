@@ -221,7 +221,18 @@ def main():
         all_ms = sum(v["ms"] for v in gemm.values())
         n_mid = (ids.shape[1] + st["n_ctx"]) // 2
         b_round = algorithmic_bytes_per_round(n_mid, n_mid - N_IMG + 1)
-        extra["roofline"] = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=None,
+        # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
+        # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
+            key = {"gemm_swiglu": "<2, 2,", "gemm_none": "<1, 0,", "gemm_splitk_partial": "<1, 3,"}.get(dom)
+            for k, v in pmc.items():
+                if key and "gemm_w32_kernel" + key in k:
+                    traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
+        except Exception:
+            pass
+        extra["roofline"] = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
                                  kernel=f"gemm_skinny_kernel[{dom}]", launches=int(d["launches"]), avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                                  algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                                  all_skinny_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1))
