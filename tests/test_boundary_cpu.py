@@ -69,3 +69,38 @@ def test_synth_structured_pair_is_a_successor_model():
     t = np.arange(3, V)
     assert (np.argmax(E[t] @ Hd.T, axis=1) == s[t]).mean() > 0.999
     assert s.min() >= 3
+
+
+def test_weights_io_reads_hf_and_vispec_checkpoint_dirs(tmp_path):
+    """On-disk formats: sharded HF safetensors of a LLaVA-NeXT target (4.x key layout) + ViSpec draft dir."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from vispec_amd import synth, weights_io
+    T = synth.TINY
+    tw = synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"], seed=3)
+    dw = synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"], seed=4)
+    tdir, ddir = tmp_path / "target", tmp_path / "draft"
+    tdir.mkdir(); ddir.mkdir()
+    hf = {("language_model." + k if k.startswith("model.") else "language_model." + k): torch.from_numpy(v).to(torch.bfloat16) for k, v in tw.items()}
+    hf["vision_tower.dummy"] = torch.zeros(4)
+    keys = sorted(hf)
+    shards = {"model-00001-of-00002.safetensors": keys[: len(keys) // 2], "model-00002-of-00002.safetensors": keys[len(keys) // 2:]}
+    wm = {}
+    for fn, ks in shards.items():
+        save_file({k: hf[k].contiguous() for k in ks}, str(tdir / fn))
+        wm.update({k: fn for k in ks})
+    json.dump({"weight_map": wm}, open(tdir / "model.safetensors.index.json", "w"))
+    json.dump({"architectures": ["LlavaNextForConditionalGeneration"], "image_token_index": T["V"] - 1,
+               "text_config": {"hidden_size": T["D"], "num_attention_heads": T["H"], "num_key_value_heads": T["H"], "intermediate_size": T["I"],
+                               "vocab_size": T["V"], "num_hidden_layers": T["NL"], "rms_norm_eps": 1e-5}}, open(tdir / "config.json", "w"))
+    save_file({k: torch.from_numpy(v).to(torch.bfloat16).contiguous() for k, v in dw.items()}, str(ddir / "model.safetensors"))
+    json.dump({"hidden_size": T["D"], "num_attention_heads": T["H"], "intermediate_size": T["I"], "vocab_size": T["V"],
+               "max_position_embeddings": T["max_pos"]}, open(ddir / "config.json", "w"))
+    tcfg, sd, tok = weights_io.load_target_dir(str(tdir))
+    assert (tcfg.hidden_size, tcfg.num_layers, tcfg.architectures[0], tcfg.image_token_index) == (T["D"], T["NL"], "LlavaNextForConditionalGeneration", T["V"] - 1)
+    assert set(sd) == set(tw)
+    for k in tw:
+        np.testing.assert_array_equal(sd[k].float().numpy(), tw[k])
+    dcfg, dsd = weights_io.load_draft_dir(str(ddir), tcfg)
+    assert set(dsd) == set(dw) and dcfg.hidden_size == T["D"]

@@ -296,3 +296,16 @@ def test_logsoftmax_topk(lib, engine, M, V, k):
         assert len(set(got_idx[r].tolist())) == k
         assert (np.diff(got_lp[r]) <= 0).all()
     assert got_idx[0, :3].tolist() == [7, 900, 901]
+
+
+@pytest.mark.parametrize("M,N,K", [(30, 5120, 5120), (30, 2 * 13824, 5120), (8, 5120, 13824), (30, 3584 + 2 * 512, 3584), (8, 18944 * 2, 3584)])
+def test_gemm_other_model_shapes(lib, engine, M, N, K):
+    """LLaVA-1.6-13B (D=5120, I=13824) and Qwen2.5-VL-7B (D=3584, GQA qkv, I=18944) GEMM shapes."""
+    rng = np.random.default_rng(N + K)
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((N, K), dtype=np.float32) * 0.03)
+    X, W = tb(x), packed(w)
+    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(X), K, p(W), None, p(Y), N, None, 0, M, N, K, 0))
+    torch.cuda.synchronize()
+    assert_bf16_close(fn(Y), vo.Ops(True).linear(x, w))

@@ -194,3 +194,46 @@ def test_forced_accept_is_bench_only_and_consistent():
                                                forced_accept=lambda r: r % 3)
     assert all(a <= (r % 3) for r, a in enumerate(acc))
     assert out.shape[1] == len(ids) + sum(a + 1 for a in acc)
+
+
+def test_multi_image_prompt_matches_oracle():
+    """4 image runs (BASELINE config 3's shape of prompt).  The reference crashes on this (index bug in the trans_mat it builds
+    for a scatter nobody reads, cnets_ours.py:938-941); oracle and HIP implement the intent — parity unpinned
+    upstream, pinned between oracle and HIP."""
+    sm, ot, od = build(70, 71, True, arch="LlavaNextForConditionalGeneration")
+    rng = np.random.default_rng(123)
+    D = T["D"]
+    segs = [(3, 17), (5, 40), (1, 9), (7, 33)]
+    ids, mask = [], []
+    for n_txt, n_img in segs:
+        ids += rng.integers(3, IMG_TOK, size=n_txt).tolist() + [IMG_TOK] * n_img
+        mask += [False] * n_txt + [True] * n_img
+    ids += rng.integers(3, IMG_TOK, size=6).tolist()
+    mask += [False] * 6
+    ids, mask = np.array(ids), np.array(mask)
+    feats = synth.bf16_grid(rng.standard_normal((int(mask.sum()), D), dtype=np.float32) * 0.05)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(),
+                                               max_new_tokens=24, log=True, return_acceptance_len=True)
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[mask] = feats
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, inputs_embeds=emb, image_mask=mask, max_new_tokens=24, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc and max(acc) >= 3
+    st = sm.engine.state()
+    assert st["draft_len"] == st["n_ctx"] - int(mask.sum()) + len(segs) * (sm.engine.num_q - 1)
+
+
+def test_llava15_semantics_no_compression(golden_dir):
+    """BASELINE config 0 semantics (LLaVA-1.5): image features reach the target, the draft never compresses."""
+    sm, ot, od = build(70, 71, True, arch="LlavaForConditionalGeneration")
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids, emb, mask = g["img_ids"].copy(), g["img_emb"], g["img_mask"]
+    ids_in = ids.copy()
+    ids_in[mask] = IMG_TOK
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids_in)[None], pixel_values=torch.from_numpy(emb[mask]).to(torch.bfloat16).cuda(),
+                                               max_new_tokens=20, log=True, return_acceptance_len=True)
+    st = sm.engine.state()
+    assert st["draft_len"] == st["n_ctx"]  # no image-token compression in the draft's KV
+    # target saw the image features: same greedy tokens as the LLaVA-NeXT run of the same request
+    L = len(ids)
+    np.testing.assert_array_equal(out[0].cpu().numpy()[L:L + 16], g["img_out"][L:L + 16])

@@ -127,10 +127,22 @@ class SpecModel:
                 inputs_embeds[mask] = image_features.to(inputs_embeds.dtype)
                 special_image_mask = mask
             draft_embeds = inputs_embeds
-        elif arch in ("LlamaForCausalLM", "LlavaForConditionalGeneration"):
-            # text target, and LLaVA-1.5: the reference has no vision branch for it -> no compression,
-            # the draft embeds the ids itself (cnets_ours.py:1099-1107)
-            pass
+        elif arch == "LlavaForConditionalGeneration":
+            # LLaVA-1.5: the reference's specgenerate has NO vision branch for it: the target merges the
+            # image features itself (HF forward with pixel_values), while the draft gets inputs_embeds=None / image_mask=None, i.e.
+            # it embeds the ids (placeholder tokens included) with its own table and never compresses (g = 0).
+            pixel_values = kwargs.get("pixel_values")
+            if inputs_embeds is None:
+                inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
+                if pixel_values is not None:
+                    feats = self.base_model.get_image_features(pixel_values, kwargs.get("image_sizes"))
+                    mask = input_ids == self.base_model.config.image_token_index
+                    if int(mask.sum()) != feats.shape[0]:
+                        raise ValueError(f"Image features and image tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")
+                    inputs_embeds = inputs_embeds.clone()
+                    inputs_embeds[mask] = feats.to(inputs_embeds.dtype)
+        elif arch == "LlamaForCausalLM":
+            pass  # text target: the draft embeds the ids itself (cnets_ours.py:1099-1107)
         else:
             raise NotImplementedError(f"target architecture {arch} (Qwen2.5-VL is a later row of SURVEY.md §8)")
         return inputs_embeds, special_image_mask, draft_embeds
