@@ -36,7 +36,8 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(device, seed, rank, world):
+def build_models(device, seed, rank, world, lanes):
+    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU."""
     from vispec_amd import parallel, synth_gpu
     from vispec_amd.engine import LLAVA_16_7B, DraftConfig, TargetConfig
     from vispec_amd.model import SpecModel
@@ -59,10 +60,35 @@ def build_model(device, seed, rank, world):
         if not same:
             raise RuntimeError("weight replication checksum mismatch across ranks")
         log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over RCCL in {t_rep:.2f} s, checksums equal")
-    base = TargetLM(tcfg, tw)
-    draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
-    sm = SpecModel(base, draft, **TREE)
-    return sm, tcfg, t_rep
+    sms = []
+    for _ in range(lanes):
+        base = TargetLM(tcfg, tw)
+        draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
+        sms.append(SpecModel(base, draft, **TREE))
+    return sms, tcfg, t_rep
+
+
+def run_lanes(fns):
+    """Run one callable per lane concurrently (one host thread + one HIP stream per lane); returns their results."""
+    import threading
+    out = [None] * len(fns)
+    err = []
+
+    def work(i):
+        try:
+            out[i] = fns[i]()
+        except BaseException as e:  # surface worker failures in the main thread
+            err.append(e)
+
+    if len(fns) == 1:
+        work(0)
+    else:
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    if err:
+        raise err[0]
+    return out
 
 
 def make_request(tcfg, req_id, device):
@@ -139,6 +165,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=3, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -158,28 +185,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sm, tcfg, t_rep = build_model(device, args.seed, rank, world)
+    R = max(1, args.lanes)
+    sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R)
+    sm = sms[0]
     eng = sm.engine
     K, W = args.steps, args.warmup
-    # weak scaling: every rank runs K requests of its own (request id = rank + i*world)
-    reqs = [make_request(tcfg, rank + i * world, device) for i in range(W + K)]
+    streams = [torch.cuda.Stream(device) for _ in range(R)]
+    # weak scaling: every (rank, lane) runs K requests of its own; a "step" = one request on every lane of every GPU, concurrently
+    reqs = [[make_request(tcfg, (rank * R + lane) + i * world * R, device) for i in range(W + K)] for lane in range(R)]
 
-    def run(req):
-        ids, pix = req
-        return sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True)
+    def lane_fn(lane, lo, hi, ar=False):
+        def f():
+            tok = rnd = 0
+            accs = []
+            with torch.cuda.stream(streams[lane]):
+                for i in range(lo, hi):
+                    ids, pix = reqs[lane][i]
+                    if ar:
+                        o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, pixel_values=pix)
+                        tok += o.shape[1] - ids.shape[1]
+                    else:
+                        o, new_token, idx, acc = sms[lane].specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True,
+                                                                        return_acceptance_len=True)
+                        tok += int(new_token)
+                        rnd += idx + 1
+                        accs += acc
+                streams[lane].synchronize()
+            return tok, rnd, accs
+        return f
 
-    for i in range(W):
-        run(reqs[i])
+    run_lanes([lane_fn(l, 0, W) for l in range(R)])
     barrier()
     t0 = time.time()
-    tokens, rounds, accs = 0, 0, []
-    for i in range(W, W + K):
-        out, new_token, idx, acc = run(reqs[i])
-        tokens += int(new_token)
-        rounds += idx + 1
-        accs += acc
+    res = run_lanes([lane_fn(l, W, W + K) for l in range(R)])
     barrier()
     dt = time.time() - t0
+    tokens = sum(r[0] for r in res)
+    rounds = sum(r[1] for r in res)
+    accs = [a for r in res for a in r[2]]
     stats = torch.tensor([dt, tokens, rounds, sum(accs)], dtype=torch.float64, device=device)
     if dist is not None:
         mx = stats.clone()
@@ -194,17 +237,18 @@ def main():
     extra = {}
     if rank == 0:
         # ---- clean (un-instrumented) split of one request into prefill and decode wall time
-        ids, pix = reqs[W]
+        ids, pix = reqs[0][W]
         torch.cuda.synchronize()
         t1 = time.time()
-        out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
-                                                                return_decode_time=True)
+        with torch.cuda.stream(streams[0]):
+            out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True,
+                                                                    return_acceptance_len=True, return_decode_time=True)
         torch.cuda.synchronize()
         t_req = time.time() - t1
+        extra["single_lane"] = dict(tokens_per_s=round(int(new_token) / t_req, 2))
         extra["request_split"] = dict(wall_s=round(t_req, 4), prefill_s=round(t_req - t_dec_clean, 4), decode_s=round(t_dec_clean, 4),
                                       rounds=idx + 1, ms_per_round=round(1e3 * t_dec_clean / (idx + 1), 3))
         # ---- decode-only rate + roofline leg: one more request with HIP events around every skinny-GEMM / attention launch
-        ids, pix = reqs[W]
         torch.cuda.synchronize()
         eng.prof_enable(True)
         t1 = time.time()
@@ -241,19 +285,28 @@ def main():
                               algorithmic_GB_per_round=round(b_round / 1e9, 2),
                               round_roofline_frac_of_8TBps=round((b_round * rounds_prof / t_dec) / 8e12, 4),
                               kernel_ms_per_round={k: round(v["ms"] / rounds_prof, 4) for k, v in rep.items()})
-        # ---- AR baseline leg (gen_baseline_answer_coco_caption.py): same request, same kernels at T=1, whole request wall time
+        # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
+        #      once on a single lane (latency) and once with the same lane concurrency as the timed region (throughput)
         if not args.no_ar:
             torch.cuda.synchronize()
             t1 = time.time()
-            ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, pixel_values=pix)
+            with torch.cuda.stream(streams[0]):
+                ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, pixel_values=pix)
             torch.cuda.synchronize()
             t_ar = time.time() - t1
             n_ar = ar.shape[1] - ids.shape[1]
-            extra["ar_baseline"] = dict(tokens_per_s=round(n_ar / t_ar, 2), new_tokens=int(n_ar), wall_s=round(t_ar, 3))
-            extra["speedup_vs_ar"] = round((tokens / world / K / (dt / K)) / (n_ar / t_ar), 3)
+            extra["single_lane"].update(ar_tokens_per_s=round(n_ar / t_ar, 2), speedup_vs_ar=round(extra["single_lane"]["tokens_per_s"] / (n_ar / t_ar), 3))
             # greedy invariance at full size: speculative tokens == AR tokens of the same target
             nmin = min(ar.shape[1], out.shape[1])
             extra["spec_equals_ar_prefix"] = int((ar[0, :nmin] == out[0, :nmin]).long().cumprod(0).sum().item()) - ids.shape[1]
+            torch.cuda.synchronize()
+            t1 = time.time()
+            res_ar = run_lanes([lane_fn(l, W, W + 1, ar=True) for l in range(R)])
+            torch.cuda.synchronize()
+            t_arR = time.time() - t1
+            ar_rate = sum(r[0] for r in res_ar) / t_arR
+            extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, new_tokens=int(sum(r[0] for r in res_ar)), wall_s=round(t_arR, 3))
+            extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 extra["cpu_baseline"] = cpu_baseline_leg()
@@ -266,9 +319,9 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "LLaVA-v1.6-vicuna-7B-shaped target + ViSpec draft, 1 image (2144 image tokens) + 512 text + 48 template "
                                    "tokens per request (L=2704), max_new_tokens=512, temperature=0, total_token=30 depth=3 top_k=8 num_q=2; "
-                                   "1 request per step per GPU, replicas only",
+                                   f"a step = 1 request on each of {R} concurrent batch-1 lanes per GPU (replicas sharing one weight copy)",
                        "weights": "synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho=0.115) so acceptance is measured",
-                       "parallelism": f"dp{world} (independent replicas, one-time RCCL weight replication {t_rep:.2f}s)"},
+                       "parallelism": f"dp{world} x {R} lanes/GPU (independent replicas, one-time RCCL weight replication {t_rep:.2f}s)"},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }
         line.update(extra)

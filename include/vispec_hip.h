@@ -157,6 +157,9 @@ int vispec_get_tokens_host(vispec_ctx*, void* stream, int* out_host, int n);    
 int vispec_get_accept_log_host(vispec_ctx*, void* stream, int* out_host, int n_rounds);
 int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve_Txd2,
                          int* n_leaf, int* max_depth);
+/* hipGraph replay of the round functions (verify_accept / draft_round / ar_step) on capturable (non-null) streams: on by default. */
+int vispec_set_graphs(vispec_ctx*, int on);
+int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, direct runs} */
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
    HIP events on its own stream.  kinds 0..4 = skinny GEMM {none, residual, swiglu, split-K partial, split-K reduce(+norm)}, 9 = attention
    partial, 10 = attention reduce.  report: out[kind*3+{0,1,2}] = {launches, total ms, total algorithmic bytes}. Blocking. */

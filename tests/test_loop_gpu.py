@@ -237,3 +237,26 @@ def test_llava15_semantics_no_compression(golden_dir):
     # target saw the image features: same greedy tokens as the LLaVA-NeXT run of the same request
     L = len(ids)
     np.testing.assert_array_equal(out[0].cpu().numpy()[L:L + 16], g["img_out"][L:L + 16])
+
+
+def test_hipgraph_replay_equals_direct_launches():
+    """On a side stream the round functions are captured once and replayed (hipGraph); on the null stream they launch directly.
+    Same tokens, same accept lengths; a second request (different prompt length -> new capture key) still matches the oracle."""
+    sm, ot, od = build(50, 60, True)
+    rng = np.random.default_rng(11)
+    side = torch.cuda.Stream()
+    for n in (14, 23):
+        ids = rng.integers(3, T["V"], size=n)
+        direct = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=30, log=True, return_acceptance_len=True)
+        with torch.cuda.stream(side):
+            graphed = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=30, log=True, return_acceptance_len=True)
+            ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=20)
+            side.synchronize()
+        np.testing.assert_array_equal(direct[0].cpu().numpy(), graphed[0].cpu().numpy())
+        assert direct[1:] == graphed[1:]
+        o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=30, max_pos=T["max_pos"])
+        np.testing.assert_array_equal(graphed[0][0].cpu().numpy(), o_out)
+        k = min(ar.shape[1], len(o_out))
+        np.testing.assert_array_equal(ar[0, :k].cpu().numpy(), o_out[:k])
+    gs = sm.engine.graph_stats()
+    assert gs["captures"] >= 3 and gs["replays"] > gs["captures"] and gs["direct"] > 0, gs

@@ -58,6 +58,11 @@ struct vispec_ctx {
   size_t gemm_part_elems = 0;
   size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
   int n_hint = 0;             // upper bound of keys any attention call of this request can see
+  // hipGraph cache: the launch sequence of a round is static for a given (n_hint, forced_accept) — see run_graphed()
+  struct GraphSlot { hipGraphExec_t exec = nullptr; long key = -1; };
+  GraphSlot g_verify, g_draft, g_ar;
+  bool use_graphs = true;
+  long graph_replays = 0, graph_captures = 0, direct_runs = 0;
   std::vector<void*> allocs;
 };
 
@@ -163,6 +168,8 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
 
 extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
   if (!ctx) return;
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar})
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   delete ctx;
@@ -522,6 +529,63 @@ extern "C" int vispec_logsoftmax_topk(vispec_ctx* ctx, void* stream, const void*
   return launch_lstopk(ctx, (hipStream_t)stream, logits, ld, M, V, k, out_idx, out_logp);
 }
 
+// ------------------------------------------------------------------------------------------------ hipGraph replay
+// A round is ~390 dependent launches whose arguments never change (all variable quantities live in DevState): capture the
+// sequence once per (ctx, key) with stream capture and replay it with ONE hipGraphLaunch.  This does not shorten the GPU work
+// (the round is GPU-bound on one stream) but removes ~1.4 ms of host launch time per round, which is what limits several
+// concurrent batch-1 lanes per GPU.  The legacy null stream cannot be captured: calls on it launch directly.
+template <class F>
+static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& slot, long key, F body) {
+  if (!ctx->use_graphs || g_prof.on || s == nullptr) {
+    ++ctx->direct_runs;
+    return body();
+  }
+  if (slot.exec && slot.key == key) {
+    HIPCHK(hipGraphLaunch(slot.exec, s));
+    ++ctx->graph_replays;
+    return 0;
+  }
+  if (slot.exec) {
+    (void)hipGraphExecDestroy(slot.exec);
+    slot.exec = nullptr;
+    slot.key = -1;
+  }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    ++ctx->direct_runs;
+    return body();  // stream not capturable: plain launches
+  }
+  const int rc = body();
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  const hipError_t ei = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    slot.exec = nullptr;
+    return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+  }
+  slot.key = key;
+  ++ctx->graph_captures;
+  HIPCHK(hipGraphLaunch(slot.exec, s));
+  return 0;
+}
+// out[0..2] = {graph replays, graph captures, direct (un-graphed) runs} of the round functions since ctx creation
+extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
+  if (!ctx || !out3) return fail("null");
+  out3[0] = ctx->graph_replays; out3[1] = ctx->graph_captures; out3[2] = ctx->direct_runs;
+  return 0;
+}
+extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
+  if (!ctx) return fail("null ctx");
+  ctx->use_graphs = on != 0;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ the path
 __global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos) {
   if (threadIdx.x == 0) {
@@ -620,9 +684,13 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
   return 0;
 }
 
+static int draft_round_body(vispec_ctx* ctx, hipStream_t s);
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
+  return run_graphed(ctx, s, ctx->g_draft, (long)ctx->n_hint, [&]() { return draft_round_body(ctx, s); });
+}
+static int draft_round_body(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, MC = c.depth + 2;  // a+1 <= depth+2 catch-up rows; rows beyond a are scratch
   // catch-up forward on the accepted hidden states (cnets_ours.py:1090-1097)
@@ -821,8 +889,12 @@ static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accep
 
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
-  if (target_forward(ctx, (hipStream_t)stream, ctx->c.total_token)) return -1;
-  return target_accept(ctx, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+  hipStream_t s = (hipStream_t)stream;
+  const long key = (long)ctx->n_hint * 64 + (forced_accept + 1);
+  return run_graphed(ctx, s, ctx->g_verify, key, [&]() {
+    if (target_forward(ctx, s, ctx->c.total_token)) return -1;
+    return target_accept(ctx, s, ctx->c.total_token, forced_accept);
+  });
 }
 extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
@@ -864,10 +936,12 @@ extern "C" int vispec_set_next_token(vispec_ctx* ctx, void* stream, const int* t
 extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
-  KCHK();
-  if (target_forward(ctx, s, 1)) return -1;
-  return target_accept(ctx, s, 1, -1);
+  return run_graphed(ctx, s, ctx->g_ar, (long)ctx->n_hint, [&]() {
+    hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
+    KCHK();
+    if (target_forward(ctx, s, 1)) return -1;
+    return target_accept(ctx, s, 1, -1);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ read-back

@@ -269,6 +269,14 @@ class Engine:
     PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "k5", "k6", "k7", "k8",
                   "attn_partial", "attn_reduce"]
 
+    def set_graphs(self, on: bool):
+        L.check(self.lib.vispec_set_graphs(self.h, int(on)))
+
+    def graph_stats(self) -> Dict[str, int]:
+        out = (C.c_longlong * 3)()
+        L.check(self.lib.vispec_graph_stats(self.h, out))
+        return dict(replays=int(out[0]), captures=int(out[1]), direct=int(out[2]))
+
     def prof_enable(self, on: bool):
         L.check(self.lib.vispec_prof_enable(self.h, int(on)))
 
