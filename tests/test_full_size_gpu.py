@@ -1,0 +1,63 @@
+"""Full BASELINE size (LLaVA-v1.6-vicuna-7B shapes, L = 2704 = 48 + 2144 image + 512 text tokens): size-independent properties.
+The numpy oracle cannot run at this size in seconds, so parity here is: (1) the reference's own invariant — speculative output ==
+greedy AR output of the same target, token for token; (2) exact integer logic replayed by the oracle on the device's buffers;
+(3) bookkeeping identities of the compressed draft KV and of the accept log."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from helpers import vo  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def model7b():
+    import bench
+    sms, tcfg, _ = bench.build_models(torch.device("cuda:0"), 0, 0, 1, 1)
+    return sms[0], tcfg
+
+
+def test_speculative_equals_greedy_ar_at_full_size(model7b):
+    import bench
+    sm, tcfg = model7b
+    ids, pix = bench.make_request(tcfg, 3, torch.device("cuda:0"))
+    out, new_token, idx, acc = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=96, log=True, return_acceptance_len=True)
+    L = ids.shape[1]
+    assert L == 2704 and new_token > 96 and len(acc) == idx + 1
+    assert out.shape[1] == L + sum(a + 1 for a in acc) == L + new_token            # accept log <-> token count
+    assert 0 <= min(acc) and max(acc) <= sm.engine.depth + 1
+    st = sm.engine.state()
+    assert st["n_ctx"] == out.shape[1]
+    assert st["draft_len"] == st["n_ctx"] - bench.N_IMG + (sm.engine.num_q - 1)  # image tokens compressed to num_q-1 draft rows
+    # exact tree logic on the device's own candidate lists at full vocabulary
+    k, d = sm.engine.top_k, sm.engine.depth
+    n_all = k + d * k * k
+    sc = sm.engine.buffer("scores_all", (n_all,), torch.float32).cpu().numpy()
+    tk = sm.engine.buffer("tokens_all", (n_all,), torch.int32).cpu().numpy()
+    pa = sm.engine.buffer("parents_all", (1 + d * k,), torch.int32).cpu().numpy()
+    tok, pos, mask, ret = sm.engine.tree()
+    w_tok, w_ret, w_mask, w_pos = vo.build_tree(sc, tk.astype(np.int64), pa.astype(np.int64), tok[0], sm.engine.total_token - 1, k)
+    np.testing.assert_array_equal(tok, w_tok)
+    np.testing.assert_array_equal(mask, w_mask)
+    np.testing.assert_array_equal(ret, w_ret)
+    # greedy invariance: same target, same kernels at T = 1
+    ar = sm.baseline_generate(ids, max_new_tokens=96, max_steps=97, pixel_values=pix)
+    n = min(ar.shape[1], out.shape[1])
+    assert n >= L + 96
+    np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), out[0, :n].cpu().numpy())
+    assert np.mean(acc) > 1.5  # the structured synthetic pair really exercises multi-token acceptance
+
+
+def test_idempotent_and_request_independent(model7b):
+    """Running the same request twice (KV buffers reused, state reset on the device) gives identical tokens; an interleaved
+    different request does not leak into it."""
+    import bench
+    sm, tcfg = model7b
+    dev = torch.device("cuda:0")
+    a_ids, a_pix = bench.make_request(tcfg, 5, dev)
+    b_ids, b_pix = bench.make_request(tcfg, 6, dev)
+    a1 = sm.specgenerate(a_ids, pixel_values=a_pix, max_new_tokens=48)
+    b1 = sm.specgenerate(b_ids, pixel_values=b_pix, max_new_tokens=48)
+    a2 = sm.specgenerate(a_ids, pixel_values=a_pix, max_new_tokens=48)
+    assert torch.equal(a1, a2) and not torch.equal(a1[:, -40:], b1[:, -40:])

@@ -473,12 +473,25 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P;
   const int tiles = (N + 31) / 32;
   const bool no_reduce = variant >= 10000;  // time the GEMM kernel alone
+  const int dbg = variant / 10000 >= 2 ? variant / 10000 - 1 : 0;  // 2xxxx: no activation loads, 3xxxx: no epilogue
   variant %= 10000;
   const int S = variant / 100, nwc = (variant / 10) % 10, unc = variant % 10;
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S)
+  if (dbg == 1) {
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 1>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+    KCHK();
+    return 0;
+  }
+  if (dbg == 2) {
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+    KCHK();
+    return 0;
+  }
   switch (nwc * 10 + unc) {
     case 0: V(4, 4); break;
     case 1: V(4, 8); break;
