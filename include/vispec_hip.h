@@ -144,6 +144,10 @@ int vispec_set_tree_host(vispec_ctx*, void* stream, const int* tokens_T, const i
    last vispec_verify_accept. */
 int vispec_draft_round(vispec_ctx*, void* stream);
 
+/* Qwen2.5-VL: the rope_deltas cached by the prefill (modeling_qwen2_5_vl_kv.py) shift every decode position: tree verify and AR
+   steps rotate at n + tree_pos + delta (utils.py:397-402; the three M-RoPE components are equal there, i.e. ordinary 1-D rotary).
+   Call after vispec_begin_request (which resets it to 0). */
+int vispec_set_rope_delta(vispec_ctx*, void* stream, int delta);
 /* Seed the next token to decode (the prefill's argmax) when no draft is used (AR baseline). */
 int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
 /* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */

@@ -420,10 +420,28 @@ class TargetConfig:
     max_position_embeddings: int = 8192
     rms_norm_eps: float = 1e-5
     rope_theta: float = 10000.0
+    attn_impl: str = "eager"          # "eager": modeling_llama_kv.py:602-623 ; "sdpa": modeling_qwen2_5_vl_kv.py:1156-1163
+    mrope_section: Optional[tuple] = None  # Qwen2.5-VL multimodal rotary sections, e.g. (16, 24, 24)
 
     @property
     def head_dim(self):
         return self.hidden_size // self.num_heads
+
+
+def mrope_tables(pos3: np.ndarray, head_dim: int, theta: float, section) -> Tuple[np.ndarray, np.ndarray]:
+    """cos/sin [S, head_dim] for 3-component (t, h, w) position ids [3, S] — modeling_qwen2_5_vl_kv.py rotary embedding +
+    apply_multimodal_rotary_pos_emb: chunk i of sizes section*2 takes component i % 3."""
+    inv_freq = (1.0 / (np.float32(theta) ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim)))).astype(np.float32)
+    freqs = pos3.astype(np.float32)[:, :, None] * inv_freq[None, None, :]  # [3, S, hd/2]
+    emb = np.concatenate([freqs, freqs], axis=-1)  # [3, S, hd]
+    cos3, sin3 = np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
+    cos, sin = np.zeros(emb.shape[1:], np.float32), np.zeros(emb.shape[1:], np.float32)
+    o = 0
+    for i, w in enumerate(list(section) * 2):
+        cos[:, o : o + w] = cos3[i % 3][:, o : o + w]
+        sin[:, o : o + w] = sin3[i % 3][:, o : o + w]
+        o += w
+    return cos, sin
 
 
 class TargetLlama:
@@ -452,6 +470,12 @@ class TargetLlama:
         S = x.shape[0]
         n_past = past_key_values[0][0].shape[2]
         pos = np.arange(n_past, n_past + S, dtype=np.int64) if position_ids is None else np.asarray(position_ids, np.int64)
+        if pos.ndim == 2:  # [3, S] multimodal rotary positions (Qwen2.5-VL)
+            cosT, sinT = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
+            pos_idx = np.arange(S)
+        else:
+            cosT, sinT, pos_idx = self.cos, self.sin, pos
+        attn = o.attn_sdpa if c.attn_impl == "sdpa" else o.attn_eager
         allow = np.ones((S, n_past + S), bool)
         allow[:, n_past:] = np.tril(np.ones((S, S), bool))  # :892-900
         if self.tree_mask is not None:  # :917-922
@@ -467,14 +491,14 @@ class TargetLlama:
             q = q.reshape(S, c.num_heads, c.head_dim).transpose(1, 0, 2)
             k = k.reshape(S, c.num_kv_heads, c.head_dim).transpose(1, 0, 2)
             v = v.reshape(S, c.num_kv_heads, c.head_dim).transpose(1, 0, 2)
-            q = o.rope(q, self.cos, self.sin, pos)
-            k = o.rope(k, self.cos, self.sin, pos)
+            q = o.rope(q, cosT, sinT, pos_idx)
+            k = o.rope(k, cosT, sinT, pos_idx)
             kk = past_key_values[i][0].cat(k[None])[0]  # :583,593
             vv = past_key_values[i][1].cat(v[None])[0]
             if rep > 1:
                 kk = np.repeat(kk, rep, axis=0)
                 vv = np.repeat(vv, rep, axis=0)
-            a = o.attn_eager(q, kk, vv, allow).transpose(1, 0, 2).reshape(S, c.hidden_size)
+            a = attn(q, kk, vv, allow).transpose(1, 0, 2).reshape(S, c.hidden_size)
             x = o.add(x, o.linear(a, self.w[p + "self_attn.o_proj.weight"]))
             h = o.rmsnorm(x, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
             g = o.linear(h, self.w[p + "mlp.gate_proj.weight"])
@@ -498,9 +522,10 @@ def evaluate_posterior_greedy(logits: np.ndarray, candidates: np.ndarray):
     return best, accept_length, logits[best, accept_length]
 
 
-def tree_decoding(target: TargetLlama, pkv, tree_candidates, tree_position_ids, n_ctx, retrieve_indices):
-    """utils.py:389-412.  -> (logits [n_leaf, m, V], hidden_state_new [T,D])."""
-    position_ids = tree_position_ids + n_ctx
+def tree_decoding(target: TargetLlama, pkv, tree_candidates, tree_position_ids, n_ctx, retrieve_indices, rope_delta=0):
+    """utils.py:389-412.  -> (logits [n_leaf, m, V], hidden_state_new [T,D]).  Qwen2.5-VL adds the cached rope_deltas and
+    expands to 3 equal components (:397-402), which is ordinary 1-D rotary at the shifted position."""
+    position_ids = tree_position_ids + n_ctx + rope_delta
     tree_logits, hidden = target.forward(pkv, input_ids=tree_candidates, position_ids=position_ids)
     return tree_logits[retrieve_indices], hidden  # -1 wraps to the last row exactly as torch indexing does
 
@@ -536,7 +561,8 @@ def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_
 
 
 def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embeds=None, image_mask=None,
-                 max_new_tokens=512, max_length=2048, eos_token_id=2, max_pos=None, scripted_accept=None):
+                 max_new_tokens=512, max_length=2048, eos_token_id=2, max_pos=None, scripted_accept=None, position_ids=None,
+                 rope_delta=0):
     """SpecModel.specgenerate, temperature 0 (spec_model_ours.py:247-582).
     -> (input_ids, new_token, idx, accept_lengths).  `scripted_accept` (bench-only knob, never used by
     parity tests) is None."""
@@ -549,9 +575,9 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
     target.tree_mask = None  # reset_tree_mode :456
     # initialize_tree, utils.py:266-327
     if inputs_embeds is None:
-        logits, hidden = target.forward(pkv, input_ids=input_ids)
+        logits, hidden = target.forward(pkv, input_ids=input_ids, position_ids=position_ids)
     else:
-        logits, hidden = target.forward(pkv, inputs_embeds=inputs_embeds)
+        logits, hidden = target.forward(pkv, inputs_embeds=inputs_embeds, position_ids=position_ids)
     token = argmax_first(logits[-1])  # :290
     ids1 = np.concatenate([input_ids, [token]])
     dt, ri, tm, tp = draft.topK_genrate(hidden, ids1, target.lm_head, inputs_embeds=inputs_embeds, image_mask=image_mask)
@@ -559,7 +585,8 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
     idx = 0
     for idx in range(max_length):  # :484
         target.tree_mask = st.tree_mask  # :486-489
-        logits, hidden_new = tree_decoding(target, pkv, st.draft_tokens, st.tree_position_ids, st.input_ids.shape[0], st.retrieve_indices)
+        logits, hidden_new = tree_decoding(target, pkv, st.draft_tokens, st.tree_position_ids, st.input_ids.shape[0], st.retrieve_indices,
+                                           rope_delta)
         ext = np.concatenate([st.draft_tokens, [-1]])  # :503
         candidates = ext[st.retrieve_indices]  # :504
         best, acc, sample_p = evaluate_posterior_greedy(logits, candidates)  # :505-507
@@ -572,21 +599,22 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
     return st.input_ids, st.new_token, idx, st.accept_lengths
 
 
-def baseline_forward(target: TargetLlama, input_ids, inputs_embeds=None, max_steps=2048, eos_token_id=2, max_pos=None):
+def baseline_forward(target: TargetLlama, input_ids, inputs_embeds=None, max_steps=2048, eos_token_id=2, max_pos=None,
+                     position_ids=None, rope_delta=0):
     """evaluation/gen_baseline_answer_coco_caption.py:34-133 — greedy AR with the same KV cache."""
     c = target.cfg
     pkv, _, _ = initialize_past_key_values(c.num_layers, c.num_kv_heads, max_pos or c.max_position_embeddings, c.head_dim)
     target.tree_mask = None
     input_ids = np.asarray(input_ids, np.int64).copy()
     if inputs_embeds is None:
-        logits, _ = target.forward(pkv, input_ids=input_ids)
+        logits, _ = target.forward(pkv, input_ids=input_ids, position_ids=position_ids)
     else:
-        logits, _ = target.forward(pkv, inputs_embeds=inputs_embeds)
+        logits, _ = target.forward(pkv, inputs_embeds=inputs_embeds, position_ids=position_ids)
     out = input_ids
     for _ in range(max_steps):
         tok = argmax_first(logits[-1])
         out = np.concatenate([out, [tok]])
         if tok == eos_token_id:
             break
-        logits, _ = target.forward(pkv, input_ids=np.asarray([tok]))
+        logits, _ = target.forward(pkv, input_ids=np.asarray([tok]), position_ids=np.asarray([out.shape[0] - 1 + rope_delta]))
     return out

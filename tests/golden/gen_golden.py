@@ -365,9 +365,71 @@ def g9_bf16():
     np.savez_compressed(os.path.join(OUT, "g9_bf16.npz"), **out)
 
 
+def g10_qwen():
+    """Qwen2.5-VL text model of the reference (modeling_qwen2_5_vl_kv.Qwen2_5_VLModel: KVCache.cat, tree mask, multimodal rotary,
+    GQA, q/k/v bias, SDPA) on CPU: prefill with an image block in the 3-component positions, then a tree verify at delta-shifted
+    positions.  Extra shims for transformers 5.x: text_config carries the flat attributes the reference reads, rope_scaling in
+    the 4.49 form, and the 'default' rope-init function the reference looks up."""
+    from vispec.model import modeling_qwen2_5_vl_kv as q
+    Q = synth.QWEN_TINY
+
+    def default_rope(config, device=None, seq_len=None, **kw):
+        dim = config.hidden_size // config.num_attention_heads
+        return 1.0 / (config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim)), 1.0
+
+    q.ROPE_INIT_FUNCTIONS = dict(q.ROPE_INIT_FUNCTIONS)
+    q.ROPE_INIT_FUNCTIONS["default"] = default_rope
+    cfg = q.Qwen2_5_VLConfig(text_config=dict(vocab_size=Q["V"], hidden_size=Q["D"], intermediate_size=Q["I"], num_hidden_layers=Q["NL"],
+                                              num_attention_heads=Q["H"], num_key_value_heads=Q["Hkv"], max_position_embeddings=Q["max_pos"],
+                                              rms_norm_eps=Q["eps"], rope_theta=Q["theta"], bos_token_id=1, eos_token_id=2))
+    tc = cfg.text_config
+    tc.pad_token_id = 0
+    tc.rope_scaling = {"type": "mrope", "rope_type": "default", "mrope_section": list(Q["mrope_section"])}
+    tc.rope_theta = Q["theta"]
+    tc._attn_implementation = "sdpa"
+    tc.sliding_window, tc.use_sliding_window, tc.max_window_layers = 32768, False, Q["NL"]
+    m = q.Qwen2_5_VLModel(tc).eval()
+    w = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=90, qkv_bias=True, H_kv=Q["Hkv"])
+    sd = {k[len("model."):]: t(v) for k, v in w.items() if k.startswith("model.")}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in k for k in missing), (missing, unexpected)
+    head = t(w["lm_head.weight"])
+    NL, hd = Q["NL"], Q["D"] // Q["H"]
+    data = torch.zeros(2 * NL, 1, Q["Hkv"], Q["max_pos"], hd)
+    cur = torch.zeros(2 * NL, dtype=torch.long)
+    pkv = [[KVCache(data[2 * i + j], cur[2 * i + j]) for j in (0, 1)] for i in range(NL)]
+    rng = np.random.default_rng(1000)
+    IMG = Q["V"] - 1
+    ids = np.concatenate([rng.integers(3, IMG, 5), np.full(12, IMG), rng.integers(3, IMG, 7)])  # one 1x6x8-patch image -> 3x4 tokens
+    pos3, delta = synth.qwen_rope_index(ids, IMG, [(1, 6, 8)])
+    L = len(ids)
+    emb = synth.bf16_grid(rng.standard_normal((L, Q["D"]), dtype=np.float32) * 0.05)
+    o = m(inputs_embeds=t(emb)[None], position_ids=torch.from_numpy(pos3)[:, None], past_key_values=pkv, use_cache=True, return_dict=True)
+    hid = o.last_hidden_state[0]
+    parents = [-1, 0, 0, 1, 1, 2, 3, 3, 6]
+    Tn = len(parents)
+    tm = np.zeros((Tn, Tn), np.float32)
+    for i, p_ in enumerate(parents):
+        tm[i, i] = 1
+        while p_ >= 0:
+            tm[i, p_] = 1
+            p_ = parents[p_]
+    tpos = tm.sum(1).astype(np.int64) - 1
+    cand = rng.integers(3, IMG, Tn)
+    m.tree_mask = t(tm)[None, None]
+    p1 = torch.from_numpy(tpos + L + delta)[None, None].expand(3, 1, Tn)  # utils.py:397-402
+    o2 = m(input_ids=torch.from_numpy(cand)[None], position_ids=p1, past_key_values=pkv, use_cache=True, return_dict=True)
+    m.tree_mask = None
+    hid2 = o2.last_hidden_state[0]
+    np.savez_compressed(os.path.join(OUT, "g10_qwen.npz"), ids=ids, emb=emb, pos3=pos3, delta=np.int64(delta), prefill_hidden=f32(hid),
+                        prefill_logits=f32(torch.nn.functional.linear(hid, head)), tree_mask=tm, tree_pos=tpos, cand=cand,
+                        hidden=f32(hid2), logits=f32(torch.nn.functional.linear(hid2, head)), cur=cur.numpy().copy(),
+                        k0=f32(data[0, 0, :, : L + Tn]), v1=f32(data[3, 0, :, : L + Tn]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
-    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g8=g8_loop, g9=g9_bf16)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
+    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g8=g8_loop, g9=g9_bf16, g10=g10_qwen)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

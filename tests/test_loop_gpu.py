@@ -260,3 +260,50 @@ def test_hipgraph_replay_equals_direct_launches():
         np.testing.assert_array_equal(ar[0, :k].cpu().numpy(), o_out[:k])
     gs = sm.engine.graph_stats()
     assert gs["captures"] >= 3 and gs["replays"] > gs["captures"] and gs["direct"] > 0, gs
+
+
+def build_qwen(seed_t=91, seed_d=92, structured=True, rho=0.25):
+    Q = synth.QWEN_TINY
+    IMG = Q["V"] - 1
+    tw = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=seed_t, structured=structured, qkv_bias=True, H_kv=Q["Hkv"])
+    dw = synth.make_draft_weights(Q["D"], Q["H"], Q["I"], Q["V"], seed=seed_d, structured=structured, qkv_bias=True,
+                                  target_embed=tw["model.embed_tokens.weight"] if structured else None, rho=rho)
+    tcfg = TargetConfig(hidden_size=Q["D"], num_heads=Q["H"], num_kv_heads=Q["Hkv"], intermediate_size=Q["I"], vocab_size=Q["V"], num_layers=Q["NL"],
+                        max_position_embeddings=Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True,
+                        architectures=("Qwen2_5_VLForConditionalGeneration",), image_token_index=IMG, attn_impl="sdpa",
+                        mrope_section=Q["mrope_section"])
+    dcfg = DraftConfig(hidden_size=Q["D"], num_heads=Q["H"], intermediate_size=Q["I"], vocab_size=Q["V"], max_position_embeddings=Q["max_pos"],
+                       rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw)
+    ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
+                                        attn_impl="sdpa", mrope_section=Q["mrope_section"]), tw, bf16=True)
+    od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)
+    return sm, ot, od, IMG
+
+
+def test_qwen25vl_target_loop_matches_oracle():
+    """Qwen2.5-VL-shaped target (GQA 4/2, q/k/v bias, theta 1e6, eps 1e-6, SDPA scores, multimodal rotary prefill with two image
+    runs, rope_delta-shifted decode positions) + its ViSpec draft (MHA with q/k/v bias): HIP loop == oracle loop, == greedy AR."""
+    sm, ot, od, IMG = build_qwen()
+    Q = synth.QWEN_TINY
+    rng = np.random.default_rng(17)
+    grids = [(1, 6, 8), (1, 4, 4)]  # -> 12 and 4 merged image tokens
+    ids = np.concatenate([rng.integers(3, IMG, 4), np.full(12, IMG), rng.integers(3, IMG, 3), np.full(4, IMG), rng.integers(3, IMG, 6)])
+    mask = ids == IMG
+    feats = synth.bf16_grid(rng.standard_normal((int(mask.sum()), Q["D"]), dtype=np.float32) * 0.05)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(),
+                                               image_grid_thw=torch.tensor(grids), max_new_tokens=24, log=True, return_acceptance_len=True)
+    pos3, delta = synth.qwen_rope_index(ids, IMG, grids)
+    assert delta < 0
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[mask] = feats
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, inputs_embeds=emb, image_mask=mask, max_new_tokens=24, max_pos=Q["max_pos"],
+                                                 position_ids=pos3, rope_delta=delta)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc and max(acc) >= 3
+    st = sm.engine.state()
+    assert st["draft_len"] == st["n_ctx"] - int(mask.sum()) + 2 * (sm.engine.num_q - 1)
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(),
+                              image_grid_thw=torch.tensor(grids), max_new_tokens=20)
+    n = min(ar.shape[1], len(o_out))
+    np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])

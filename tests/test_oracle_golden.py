@@ -166,3 +166,31 @@ def test_g9_bf16_rounding_points(golden_dir):
     logits, hidden = t.forward(pkv, input_ids=g["t_ids"])
     np.testing.assert_allclose(hidden, g["t_hidden"], **tol)
     np.testing.assert_allclose(logits, g["t_logits"], atol=0.02, rtol=0.03)
+
+
+def test_g10_qwen_target(golden_dir):
+    """Qwen2.5-VL text model of the reference (GQA, q/k/v bias, multimodal rotary with an image block, SDPA, tree verify at
+    rope_delta-shifted positions) vs the oracle."""
+    from vispec_amd import synth
+    Q = synth.QWEN_TINY
+    g = load(golden_dir, "g10_qwen.npz")
+    w = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=90, qkv_bias=True, H_kv=Q["Hkv"])
+    cfg = vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
+                          attn_impl="sdpa", mrope_section=Q["mrope_section"])
+    t = vo.TargetLlama(cfg, w)
+    pos3, delta = synth.qwen_rope_index(g["ids"], Q["V"] - 1, [(1, 6, 8)])
+    np.testing.assert_array_equal(pos3, g["pos3"])
+    assert delta == int(g["delta"]) and delta < 0
+    pkv, data, cur = vo.initialize_past_key_values(Q["NL"], Q["Hkv"], Q["max_pos"], Q["D"] // Q["H"])
+    logits, hidden = t.forward(pkv, inputs_embeds=g["emb"], position_ids=pos3)
+    close(hidden, g["prefill_hidden"])
+    close(logits, g["prefill_logits"])
+    t.tree_mask = g["tree_mask"] > 0
+    L = len(g["ids"])
+    logits, hidden = t.forward(pkv, input_ids=g["cand"], position_ids=g["tree_pos"] + L + delta)
+    close(hidden, g["hidden"])
+    close(logits, g["logits"])
+    np.testing.assert_array_equal(cur, g["cur"])
+    n = L + len(g["cand"])
+    close(data[0][0, 0, :, :n], g["k0"])
+    close(data[0][3, 0, :, :n], g["v1"])

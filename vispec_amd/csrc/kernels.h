@@ -51,7 +51,7 @@ struct DevState {
   int draft_real_len; // position base of the next catch-up row (cnets_ours.py:416-418, 862-867)
   int n_leaf, max_depth; // shape of the current tree's retrieve table
   int tree_T;       // nodes in the current tree (total_token, or 1 for the AR baseline)
-  int pad;
+  int rope_delta;   // Qwen2.5-VL: cached rope_deltas added to every decode position (utils.py:397-402); 0 otherwise
 };
 
 // ------------------------------------------------------------------------------------------------

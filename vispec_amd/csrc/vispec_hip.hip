@@ -336,8 +336,9 @@ static int launch_rmsnorm(hipStream_t s, const void* X, const void* w, void* Y, 
   return 0;
 }
 
-struct PosSpec {  // position = *base + add + (off ? off[m] : (row ? m : 0)) ; kv row = *kv_base + kv_add + m
+struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m : 0)) ; kv row = *kv_base + kv_add + m
   const int* base = nullptr;
+  const int* base2 = nullptr;
   int add = 0;
   const int* off = nullptr;
   int row = 1;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(64) void rope_append2_kernel(bf16_t* __restrict__ q
   float x1 = bf2f(x[d]), x2 = bf2f(x[d + HALF]);
   float o1 = x1, o2 = x2;
   if (do_rope) {
-    const int pos = (ps.base ? *ps.base : 0) + ps.add + (ps.off ? ps.off[m] : (ps.row ? m : 0));
+    const int pos = (ps.base ? *ps.base : 0) + (ps.base2 ? *ps.base2 : 0) + ps.add + (ps.off ? ps.off[m] : (ps.row ? m : 0));
     const float c = bf2f(cosT[(size_t)pos * HD + d]), sn = bf2f(sinT[(size_t)pos * HD + d]);
     o1 = rdbf(rdbf(x1 * c) + rdbf(-x2 * sn));
     o2 = rdbf(rdbf(x2 * c) + rdbf(x1 * sn));
@@ -852,6 +853,7 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
   if (launch_gather(s, ctx->tm.embed, D, ctx->tb.tree_tokens, 0, nullptr, ctx->xa, D, T, D)) return -1;
   PosSpec ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
   ps.base = &ctx->st->n_ctx;
+  ps.base2 = &ctx->st->rope_delta;
   ps.off = ctx->tb.tree_pos;
   ps.kv_base = &ctx->st->n_ctx;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
@@ -935,6 +937,16 @@ extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* to
   HIPCHK(hipMemcpyAsync(ctx->tb.retrieve, ret.data(), sizeof(int) * ret.size(), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));  // `ret` is a local
   hipLaunchKernelGGL(set_tree_meta_kernel, dim3(1), dim3(64), 0, s, ctx->st, n_leaf, max_depth, T);
+  KCHK();
+  return 0;
+}
+
+__global__ void set_rope_delta_kernel(DevState* st, int delta) {
+  if (threadIdx.x == 0) st->rope_delta = delta;
+}
+extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
+  if (!ctx) return fail("null ctx");
+  hipLaunchKernelGGL(set_rope_delta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, delta);
   KCHK();
   return 0;
 }

@@ -28,6 +28,9 @@ class TargetConfig:
     architectures: tuple = ("LlavaNextForConditionalGeneration",)
     image_token_index: int = 32000
     eos_token_id: int = 2
+    attn_impl: str = "eager"          # LLaVA-family KV-Llama is eager (modeling_llama_kv.py:602-623); Qwen2.5-VL runs SDPA
+    mrope_section: Optional[tuple] = None  # Qwen2.5-VL multimodal rotary sections (16, 24, 24)
+    video_token_id: int = -1
 
     @property
     def head_dim(self):
@@ -47,6 +50,11 @@ class DraftConfig:
     bias: bool = True  # fc / img_fc bias (spec_model_ours.py:59-64)
 
 
+QWEN25_VL_7B = dict(hidden_size=3584, num_heads=28, num_kv_heads=4, intermediate_size=18944, vocab_size=152064, num_layers=28,
+                    max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=1e6, qkv_bias=True,
+                    architectures=("Qwen2_5_VLForConditionalGeneration",), image_token_index=151655, video_token_id=151656,
+                    eos_token_id=151645, attn_impl="sdpa", mrope_section=(16, 24, 24))
+LLAVA_16_13B = dict(hidden_size=5120, num_heads=40, num_kv_heads=40, intermediate_size=13824, vocab_size=32064, num_layers=40)
 LLAVA_16_7B = dict(hidden_size=4096, num_heads=32, num_kv_heads=32, intermediate_size=11008, vocab_size=32064, num_layers=32)
 
 
@@ -163,7 +171,9 @@ class Engine:
     """One per (process, GPU).  Not re-entrant."""
 
     def __init__(self, tcfg: TargetConfig, dcfg: DraftConfig, tw: TargetWeights, dw: DraftWeightsDev, total_token=30, depth=3,
-                 top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=True):
+                 top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None):
+        if eager_scores is None:
+            eager_scores = tcfg.attn_impl == "eager"
         if not torch.cuda.is_available():
             raise L.VispecError("no GPU visible: the ViSpec hot path only exists as HIP kernels (no CPU fallback)")
         self.lib = L.load()
@@ -257,6 +267,9 @@ class Engine:
 
     def draft_round(self):
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
+
+    def set_rope_delta(self, delta: int):
+        L.check(self.lib.vispec_set_rope_delta(self.h, self._stream(), int(delta)))
 
     def set_next_token(self, token: torch.Tensor):
         assert token.dtype == torch.int32 and token.is_cuda

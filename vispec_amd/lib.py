@@ -64,6 +64,7 @@ SIGNATURES = {
     "vispec_accept": (c_int, [P, P, c_int]),
     "vispec_set_tree_host": (c_int, [P, P, P, P, P, P, c_int, c_int]),
     "vispec_draft_round": (c_int, [P, P]),
+    "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_next_token": (c_int, [P, P, P]),
     "vispec_ar_step": (c_int, [P, P]),
     "vispec_get_state_host": (c_int, [P, P, P]),

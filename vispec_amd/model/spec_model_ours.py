@@ -105,10 +105,12 @@ class SpecModel:
 
     def _merge_vision(self, input_ids, inputs_embeds, kwargs):
         """spec_model_ours.py:309-453: token embeddings, image features scattered over the placeholder tokens, and the
-        image mask the draft compresses with.  -> (inputs_embeds | None, special_image_mask | None, draft_embeds | None)."""
+        image mask the draft compresses with.
+        -> (inputs_embeds | None, special_image_mask | None, draft_embeds | None, position_ids [3,L] | None, rope_delta)."""
         special_image_mask = None
         arch = self.base_model.config.architectures[0]
         draft_embeds = None
+        position_ids, rope_delta = None, 0
         if arch == "LlavaNextForConditionalGeneration":  # :311-378
             pixel_values = kwargs.get("pixel_values")
             image_sizes = kwargs.get("image_sizes")
@@ -141,11 +143,36 @@ class SpecModel:
                         raise ValueError(f"Image features and image tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")
                     inputs_embeds = inputs_embeds.clone()
                     inputs_embeds[mask] = feats.to(inputs_embeds.dtype)
+        elif arch == "Qwen2_5_VLForConditionalGeneration":  # :380-453
+            from ..synth import qwen_rope_index
+            pixel_values, grid = kwargs.get("pixel_values"), kwargs.get("image_grid_thw")
+            pixel_values_videos, vgrid = kwargs.get("pixel_values_videos"), kwargs.get("video_grid_thw")
+            tok_id = self.base_model.config.image_token_id
+            if inputs_embeds is None:
+                inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
+                for pv, g_, tid in ((pixel_values, grid, self.base_model.config.image_token_id),
+                                    (pixel_values_videos, vgrid, self.base_model.cfg.video_token_id)):
+                    if pv is None:
+                        continue
+                    feats = self.base_model.get_image_features(pv)
+                    mask = input_ids == tid
+                    if int(mask.sum()) != feats.shape[0]:  # :403-406 / :435-438
+                        raise ValueError(f"Image features and image tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")
+                    inputs_embeds = inputs_embeds.clone()
+                    inputs_embeds[mask] = feats.to(inputs_embeds.dtype)
+                    special_image_mask = mask  # the reference keeps the LAST mask it built (:420,453)
+                    tok_id, grid = tid, g_
+            draft_embeds = inputs_embeds
+            # multimodal rotary positions + rope_deltas of the prefill (HF get_rope_index, cached on the model by the reference)
+            grids = [] if grid is None else [tuple(int(v) for v in g3) for g3 in (grid.tolist() if torch.is_tensor(grid) else grid)]
+            pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), tok_id, grids)
+            position_ids = torch.from_numpy(pos3)
+            self.base_model.rope_deltas = torch.tensor([[rope_delta]], device=input_ids.device)
         elif arch == "LlamaForCausalLM":
             pass  # text target: the draft embeds the ids itself (cnets_ours.py:1099-1107)
         else:
-            raise NotImplementedError(f"target architecture {arch} (Qwen2.5-VL is a later row of SURVEY.md §8)")
-        return inputs_embeds, special_image_mask, draft_embeds
+            raise NotImplementedError(f"target architecture {arch}")
+        return inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta
 
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -165,15 +192,17 @@ class SpecModel:
         if not hasattr(self, "past_key_values"):  # :286-307
             self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
         self.current_length_data.zero_()
-        inputs_embeds, special_image_mask, draft_embeds = self._merge_vision(input_ids, inputs_embeds, kwargs)
+        inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
         input_len = input_ids.shape[1]
         reset_tree_mode(self)  # :456
         # initialize_tree (:458-475): prefill + first token + draft prefill with image-token compression
         emb = (inputs_embeds if inputs_embeds is not None else self.base_model.get_input_embeddings()(input_ids))
         emb = emb.reshape(-1, emb.shape[-1]).to(torch.bfloat16).contiguous()
-        logits, hidden = self.base_model.prefill(emb)
+        logits, hidden = self.base_model.prefill(emb, position_ids=position_ids)
         first = self._first_token(logits)
         eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
+        if rope_delta:
+            eng.set_rope_delta(rope_delta)
         if draft_embeds is None:
             ids1 = torch.cat([input_ids[0], first.long()])
             demb = torch.nn.functional.embedding(ids1[:-1], self.spec_layer.w.t["embed"]).contiguous()
@@ -219,13 +248,15 @@ class SpecModel:
         eng = self.engine
         dev = eng.device
         input_ids = input_ids.clone().to(dev)
-        inputs_embeds, _, _ = self._merge_vision(input_ids, inputs_embeds, kwargs)
+        inputs_embeds, _, _, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
         if inputs_embeds is None:
             inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
         emb = inputs_embeds.reshape(-1, inputs_embeds.shape[-1]).to(torch.bfloat16).contiguous()
-        logits, _ = self.base_model.prefill(emb)
+        logits, _ = self.base_model.prefill(emb, position_ids=position_ids)
         first = self._first_token(logits)
         eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
+        if rope_delta:
+            eng.set_rope_delta(rope_delta)
         eng.set_next_token(first)
         n = 0
         sync_every = 16

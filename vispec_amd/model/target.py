@@ -88,15 +88,33 @@ class TargetLM:
     image_newline = None
 
     # ---- PyTorch prefill -----------------------------------------------------------------------------
+    def mrope_cos_sin(self, pos3: torch.Tensor):
+        """cos/sin [L, hd] for 3-component positions [3, L] (modeling_qwen2_5_vl_kv.py rotary + apply_multimodal_rotary_pos_emb):
+        fp32 angles per component, chunk i of sizes mrope_section*2 takes component i % 3, then cast to the model dtype."""
+        c = self.cfg
+        hd = c.head_dim
+        inv_freq = 1.0 / (c.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+        freqs = pos3.float().cpu()[:, :, None] * inv_freq[None, None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)
+        cos3, sin3 = emb.cos(), emb.sin()
+        sec = list(c.mrope_section) * 2
+        cos = torch.cat([m[i % 3] for i, m in enumerate(cos3.split(sec, dim=-1))], dim=-1)
+        sin = torch.cat([m[i % 3] for i, m in enumerate(sin3.split(sec, dim=-1))], dim=-1)
+        return cos.to(self.dtype).to(self.device), sin.to(self.dtype).to(self.device)
+
     @torch.no_grad()
-    def prefill(self, inputs_embeds: torch.Tensor, all_logits: bool = False):
+    def prefill(self, inputs_embeds: torch.Tensor, all_logits: bool = False, position_ids: Optional[torch.Tensor] = None):
         """inputs_embeds [L, D] bf16 -> (logits fp32 [L or 1, V], hidden [L, D] post-final-norm); K/V rows [0, L)
-        of every layer are written into the engine's KV buffer (KVCache.cat semantics, modeling_llama_kv.py:583-594)."""
+        of every layer are written into the engine's KV buffer (KVCache.cat semantics, modeling_llama_kv.py:583-594).
+        position_ids: None (0..L-1) or [3, L] multimodal rotary positions (Qwen2.5-VL)."""
         c, eng = self.cfg, self.engine
         x = inputs_embeds.to(self.dtype)
         Ln = x.shape[0]
         H, Hk, hd = c.num_heads, c.num_kv_heads, c.head_dim
-        cos, sin = eng.t_cos[:Ln], eng.t_sin[:Ln]
+        if position_ids is not None and position_ids.dim() == 2:
+            cos, sin = self.mrope_cos_sin(position_ids)
+        else:
+            cos, sin = eng.t_cos[:Ln], eng.t_sin[:Ln]
         kv = eng.target_kv
         for i, lw in enumerate(self.w.layers):
             h = _rmsnorm(x, lw["ln1"], c.rms_norm_eps)

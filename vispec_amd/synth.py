@@ -135,6 +135,36 @@ def make_draft_weights(D, H, I, V, num_q=2, seed=1, std=0.02, bias=True, qkv_bia
 # The tiny configuration shared by the golden fixtures, the oracle tests and the GPU parity tests.
 # head_dim is 128 (what the HIP attention tiles are written for); every GEMM dim is a multiple of 64/16.
 TINY = dict(D=256, H=2, I=704, V=1008, NL=2, max_pos=512)
+# Qwen2.5-VL-shaped tiny target: GQA (4 query / 2 kv heads), q/k/v bias, theta 1e6, multimodal rotary sections, eps 1e-6
+QWEN_TINY = dict(D=512, H=4, Hkv=2, I=704, V=1024, NL=2, max_pos=512, mrope_section=(16, 24, 24), theta=1e6, eps=1e-6)
+
+
+def qwen_rope_index(input_ids: np.ndarray, image_token_id: int, grids, spatial_merge: int = 2):
+    """3-component (t, h, w) position ids [3, L] and rope_delta for a prompt with image runs — the image branch of HF's
+    Qwen2_5_VLForConditionalGeneration.get_rope_index (called by the reference's prefill, modeling_qwen2_5_vl_kv.py forward):
+    text tokens advance all three components together; an image run of grid (t, h, w) gets t-index 0.., h-index, w-index over
+    its (h/merge)x(w/merge) tokens, offset by the running text position; the next text token continues from max+1.
+    grids: list of (t, h, w) in patches, one per image run, in order."""
+    L = input_ids.shape[0]
+    pos = np.zeros((3, L), np.int64)
+    i, st, gi = 0, 0, 0
+    while i < L:
+        if input_ids[i] == image_token_id:
+            t, h, w = grids[gi]
+            gi += 1
+            lh, lw = h // spatial_merge, w // spatial_merge
+            n = t * lh * lw
+            tt = np.repeat(np.arange(t), lh * lw)
+            hh = np.tile(np.repeat(np.arange(lh), lw), t)
+            ww = np.tile(np.arange(lw), t * lh)
+            pos[:, i : i + n] = np.stack([tt, hh, ww]) + st
+            st = int(pos[:, i : i + n].max()) + 1
+            i += n
+        else:
+            pos[:, i] = st
+            st += 1
+            i += 1
+    return pos, int(pos.max()) + 1 - L
 
 
 def make_request(V, D, L_text_pre, n_img, L_text_post, seed, image_token_id=None, embed: np.ndarray | None = None,
