@@ -30,6 +30,14 @@ sys.path.insert(0, ROOT)
 N_PRE, N_IMG, N_POST = 48, 2144, 512
 MAX_NEW = 512
 TREE = dict(total_token=30, depth=3, top_k=8, num_q=2)
+# --model selects the BASELINE.json config; the default (configs[1]) is the headline line, the others are extra coverage runs
+MODELS = {
+    "llava7b": dict(name="LLaVA-v1.6-vicuna-7B", desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
+    "llava13b": dict(name="LLaVA-v1.6-vicuna-13B", desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
+    "qwen7b": dict(name="Qwen2.5-VL-7B-Instruct", desc="4 images of 32x32 patches (256 merged tokens each) in a multi-turn prompt + 512 text tokens (L=1584)"),
+    "qwen7b-hires": dict(name="Qwen2.5-VL-7B-Instruct", desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124), bf16 weights"),
+}
+MODEL = "llava7b"
 
 
 def log(*a):
@@ -43,10 +51,20 @@ def build_models(device, seed, rank, world, lanes):
     from vispec_amd.model import SpecModel
     from vispec_amd.model.cnets_ours import Model
     from vispec_amd.model.target import TargetLM
-    tcfg = TargetConfig(**LLAVA_16_7B)
-    dcfg = DraftConfig(hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32064, max_position_embeddings=4096)
+    from vispec_amd.engine import LLAVA_16_13B, QWEN25_VL_7B
+    if MODEL == "llava13b":
+        tcfg = TargetConfig(**LLAVA_16_13B)
+        dcfg = DraftConfig(hidden_size=5120, num_heads=40, intermediate_size=13824, vocab_size=32064, max_position_embeddings=4096)
+    elif MODEL.startswith("qwen7b"):
+        tcfg = TargetConfig(**QWEN25_VL_7B)
+        dcfg = DraftConfig(hidden_size=3584, num_heads=28, intermediate_size=18944, vocab_size=152064, max_position_embeddings=8192,
+                           rms_norm_eps=1e-6, rope_theta=1e6, qkv_bias=True)  # vispec/train/qwen2.5_vl_7B_config.json
+    else:
+        tcfg = TargetConfig(**LLAVA_16_7B)
+        dcfg = DraftConfig(hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32064, max_position_embeddings=4096)
     # rank 0 creates the weights; the others allocate same-shaped buffers (different seed) and receive rank 0's over RCCL
-    tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=True, num_q=TREE["num_q"])
+    tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=True, num_q=TREE["num_q"],
+                                 succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
     t_rep = 0.0
     if world > 1:
         import torch.distributed as dist
@@ -64,7 +82,8 @@ def build_models(device, seed, rank, world, lanes):
         if not same:
             del tw, dw
             torch.cuda.empty_cache()
-            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=True, num_q=TREE["num_q"])
+            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=True, num_q=TREE["num_q"],
+                                         succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
         log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over RCCL in {t_rep:.2f} s, checksums equal")
     sms = []
     for _ in range(lanes):
@@ -98,18 +117,34 @@ def run_lanes(fns):
 
 
 def make_request(tcfg, req_id, device):
+    """-> (input_ids [1,L] on the device, specgenerate kwargs)."""
     from vispec_amd import synth_gpu
+    if MODEL == "qwen7b":  # 4 image runs of 256 merged tokens, text in between (multi-turn), 512 text tokens in total
+        g = torch.Generator().manual_seed(1000 + req_id)
+        parts, grids = [], []
+        for seg in (48, 96, 96, 96):
+            parts += [torch.randint(3, 151640, (seg,), generator=g), torch.full((256,), tcfg.image_token_index)]
+            grids.append((1, 32, 32))
+        parts.append(torch.randint(3, 151640, (224,), generator=g))
+        ids = torch.cat(parts)
+        return ids[None].to(device), dict(pixel_values=(4 * 256, req_id), image_grid_thw=torch.tensor(grids))
+    if MODEL == "qwen7b-hires":
+        g = torch.Generator().manual_seed(1000 + req_id)
+        ids = torch.cat([torch.randint(3, 151640, (48,), generator=g), torch.full((34 * 46,), tcfg.image_token_index),
+                         torch.randint(3, 151640, (512,), generator=g)])
+        return ids[None].to(device), dict(pixel_values=(34 * 46, req_id), image_grid_thw=torch.tensor([(1, 68, 92)]))
     ids = synth_gpu.make_request_ids(32000, N_PRE, N_IMG, N_POST, req_id, tcfg.image_token_index)
-    return ids[None].to(device), (N_IMG, req_id)
+    return ids[None].to(device), dict(pixel_values=(N_IMG, req_id))
 
 
-def algorithmic_bytes_per_round(n_ctx, n_c):
+def algorithmic_bytes_per_round(tcfg, n_ctx, n_c):
     """B_round = B_target + (1+d)(B_draft_layer + B_lmhead) + KV_t(n) + (1+d) KV_d(n_c)."""
-    D, I, V, NL, d = 4096, 11008, 32064, 32, TREE["depth"]
-    b_target = 2 * (NL * (4 * D * D + 3 * D * I) + V * D)
+    D, I, V, NL, d = tcfg.hidden_size, tcfg.intermediate_size, tcfg.vocab_size, tcfg.num_layers, TREE["depth"]
+    kvd = tcfg.num_kv_heads * tcfg.head_dim
+    b_target = 2 * (NL * (2 * D * D + 2 * D * kvd + 3 * D * I) + V * D)
     b_draft_layer = 2 * (2 * 2 * D * D + 4 * D * D + 3 * D * I)
     b_lm = 2 * V * D
-    return b_target + (1 + d) * (b_draft_layer + b_lm) + 524288 * n_ctx + (1 + d) * 16384 * n_c
+    return b_target + (1 + d) * (b_draft_layer + b_lm) + 2 * NL * kvd * 2 * n_ctx + (1 + d) * 2 * D * 2 * n_c
 
 
 def cpu_baseline_leg():
@@ -171,8 +206,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
     ap.add_argument("--lanes", type=int, default=3, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
     args = ap.parse_args()
+    global MODEL
+    MODEL = args.model
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -208,11 +246,10 @@ def main():
                 for i in range(lo, hi):
                     ids, pix = reqs[lane][i]
                     if ar:
-                        o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, pixel_values=pix)
+                        o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
                         tok += o.shape[1] - ids.shape[1]
                     else:
-                        o, new_token, idx, acc = sms[lane].specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True,
-                                                                        return_acceptance_len=True)
+                        o, new_token, idx, acc = sms[lane].specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True, **pix)
                         tok += int(new_token)
                         rnd += idx + 1
                         accs += acc
@@ -247,8 +284,8 @@ def main():
         torch.cuda.synchronize()
         t1 = time.time()
         with torch.cuda.stream(streams[0]):
-            out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True,
-                                                                    return_acceptance_len=True, return_decode_time=True)
+            out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                                    return_decode_time=True, **pix)
         torch.cuda.synchronize()
         t_req = time.time() - t1
         extra["single_lane"] = dict(tokens_per_s=round(int(new_token) / t_req, 2))
@@ -258,8 +295,8 @@ def main():
         torch.cuda.synchronize()
         eng.prof_enable(True)
         t1 = time.time()
-        out, new_token, idx, acc, t_dec = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
-                                                          return_decode_time=True)
+        out, new_token, idx, acc, t_dec = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                          return_decode_time=True, **pix)
         rep = eng.prof_report()
         eng.prof_enable(False)
         st = eng.state()
@@ -270,7 +307,8 @@ def main():
         all_b = sum(v["bytes"] for v in gemm.values())
         all_ms = sum(v["ms"] for v in gemm.values())
         n_mid = (ids.shape[1] + st["n_ctx"]) // 2
-        b_round = algorithmic_bytes_per_round(n_mid, n_mid - N_IMG + 1)
+        n_img = int((ids == tcfg.image_token_index).sum())
+        b_round = algorithmic_bytes_per_round(tcfg, n_mid, n_mid - n_img + 1)
         # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
         # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
         traffic = None
@@ -297,7 +335,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.time()
             with torch.cuda.stream(streams[0]):
-                ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, pixel_values=pix)
+                ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
             torch.cuda.synchronize()
             t_ar = time.time() - t1
             n_ar = ar.shape[1] - ids.shape[1]
@@ -319,12 +357,12 @@ def main():
             except Exception as e:  # never lose the GPU line to the CPU leg
                 extra["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
         line = {
-            "metric": "accepted output tokens/sec (ViSpec speculative decoding, LLaVA-v1.6-vicuna-7B + ViSpec draft, T=0)",
+            "metric": f"accepted output tokens/sec (ViSpec speculative decoding, {MODELS[MODEL]['name']} + ViSpec draft, T=0)",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LLaVA-v1.6-vicuna-7B-shaped target + ViSpec draft, 1 image (2144 image tokens) + 512 text + 48 template "
-                                   "tokens per request (L=2704), max_new_tokens=512, temperature=0, total_token=30 depth=3 top_k=8 num_q=2; "
+            "config": {"workload": f"{MODELS[MODEL]['name']}-shaped target + ViSpec draft, {MODELS[MODEL]['desc']}, "
+                                   "max_new_tokens=512, temperature=0, total_token=30 depth=3 top_k=8 num_q=2; "
                                    f"a step = 1 request on each of {R} concurrent batch-1 lanes per GPU (replicas sharing one weight copy)",
                        "weights": "synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho=0.115) so acceptance is measured",
                        "parallelism": f"dp{world} x {R} lanes/GPU (independent replicas, one-time RCCL weight replication {t_rep:.2f}s)"},

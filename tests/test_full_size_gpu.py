@@ -22,7 +22,7 @@ def test_speculative_equals_greedy_ar_at_full_size(model7b):
     import bench
     sm, tcfg = model7b
     ids, pix = bench.make_request(tcfg, 3, torch.device("cuda:0"))
-    out, new_token, idx, acc = sm.specgenerate(ids, pixel_values=pix, max_new_tokens=96, log=True, return_acceptance_len=True)
+    out, new_token, idx, acc = sm.specgenerate(ids, max_new_tokens=96, log=True, return_acceptance_len=True, **pix)
     L = ids.shape[1]
     assert L == 2704 and new_token > 96 and len(acc) == idx + 1
     assert out.shape[1] == L + sum(a + 1 for a in acc) == L + new_token            # accept log <-> token count
@@ -42,7 +42,7 @@ def test_speculative_equals_greedy_ar_at_full_size(model7b):
     np.testing.assert_array_equal(mask, w_mask)
     np.testing.assert_array_equal(ret, w_ret)
     # greedy invariance: same target, same kernels at T = 1
-    ar = sm.baseline_generate(ids, max_new_tokens=96, max_steps=97, pixel_values=pix)
+    ar = sm.baseline_generate(ids, max_new_tokens=96, max_steps=97, **pix)
     n = min(ar.shape[1], out.shape[1])
     assert n >= L + 96
     np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), out[0, :n].cpu().numpy())
@@ -57,7 +57,7 @@ def test_idempotent_and_request_independent(model7b):
     dev = torch.device("cuda:0")
     a_ids, a_pix = bench.make_request(tcfg, 5, dev)
     b_ids, b_pix = bench.make_request(tcfg, 6, dev)
-    a1 = sm.specgenerate(a_ids, pixel_values=a_pix, max_new_tokens=48)
-    b1 = sm.specgenerate(b_ids, pixel_values=b_pix, max_new_tokens=48)
-    a2 = sm.specgenerate(a_ids, pixel_values=a_pix, max_new_tokens=48)
+    a1 = sm.specgenerate(a_ids, max_new_tokens=48, **a_pix)
+    b1 = sm.specgenerate(b_ids, max_new_tokens=48, **b_pix)
+    a2 = sm.specgenerate(a_ids, max_new_tokens=48, **a_pix)
     assert torch.equal(a1, a2) and not torch.equal(a1[:, -40:], b1[:, -40:])

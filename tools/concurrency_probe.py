@@ -27,7 +27,7 @@ def worker(r, idxs):
         tok = 0
         for i in idxs:
             ids, pix = reqs[i]
-            out, new_token, idx, acc = models[r].specgenerate(ids, pixel_values=pix, max_new_tokens=512, log=True, return_acceptance_len=True)
+            out, new_token, idx, acc = models[r].specgenerate(ids, max_new_tokens=512, log=True, return_acceptance_len=True, **pix)
             tok += int(new_token)
         streams[r].synchronize()
         results[r] = tok

@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
   // clamped to the last valid key (never visible: masked by key >= n_total) so every load stays unconditional
   const int last_key = n_total - 1;
 
-  for (int qt = 0; qt < NQT; ++qt) {
+  {
+    // one q-tile per workgroup (blockIdx.z): with GQA the G*MT q-tiles of a KV head re-read its K/V through L2, which keeps
+    // the grid wide (Qwen2.5-VL has only 4 KV heads) at no extra HBM traffic
+    const int qt = blockIdx.z;
     const int head = kvh * G + qt / MT, m0 = (qt % MT) * 32;
     const int mrow = m0 + j;
     const bool qvalid = mrow < M;
@@ -422,7 +425,6 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
     unsigned char* sV_ = sK_ + ATT_CHUNK * 256;                                             \
     ATT_W1(k0r, v0r, 0, sK_, sV_) ATT_W1(k1r, v1r, 1, sK_, sV_) ATT_W1(k2r, v2r, 2, sK_, sV_) ATT_W1(k3r, v3r, 3, sK_, sV_) \
   }
-    __syncthreads();  // previous q-tile's merge is done with the LDS
     ATT_GLOAD(0)
     ATT_LWRITE(0)
     __syncthreads();

@@ -313,7 +313,7 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 4096 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
                      epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn,
                      o.eps);
   KCHK();
@@ -396,13 +396,13 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   if (M < 1 || M > 64) return fail("tree_attention: M must be in [1,64]");
   if (tail < 0 || tail > 64) return fail("tree_attention: tail must be in [0,64]");
   const int MT = (M + 31) / 32, NQT = (H / H_kv) * MT;
-  int kpw = (NQT == 1) ? 256 : 128;
+  int kpw = 256;
   if (max_keys < 1) max_keys = 1;
   while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
   if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
   const int lds = ATT_LDS_BYTES;
-  dim3 grid(nsplit, H_kv), block(256);
+  dim3 grid(nsplit, H_kv, NQT), block(256);
   prof_begin(s, PROF_ATT_PARTIAL, 0.0);
   if (eager)
     hipLaunchKernelGGL(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
