@@ -36,6 +36,8 @@ MODELS = {
     "llava13b": dict(name="LLaVA-v1.6-vicuna-13B", desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
     "qwen7b": dict(name="Qwen2.5-VL-7B-Instruct", desc="4 images of 32x32 patches (256 merged tokens each) in a multi-turn prompt + 512 text tokens (L=1584)"),
     "qwen7b-hires": dict(name="Qwen2.5-VL-7B-Instruct", desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124), bf16 weights"),
+    "qwen7b-fp8": dict(name="Qwen2.5-VL-7B-Instruct (fp8 e4m3 target weights, W8A16)",
+                       desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124)"),
 }
 MODEL = "llava7b"
 
@@ -89,7 +91,7 @@ def build_models(device, seed, rank, world, lanes):
     for _ in range(lanes):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
-        sms.append(SpecModel(base, draft, **TREE))
+        sms.append(SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE))
     return sms, tcfg, t_rep
 
 
@@ -128,7 +130,7 @@ def make_request(tcfg, req_id, device):
         parts.append(torch.randint(3, 151640, (224,), generator=g))
         ids = torch.cat(parts)
         return ids[None].to(device), dict(pixel_values=(4 * 256, req_id), image_grid_thw=torch.tensor(grids))
-    if MODEL == "qwen7b-hires":
+    if MODEL in ("qwen7b-hires", "qwen7b-fp8"):
         g = torch.Generator().manual_seed(1000 + req_id)
         ids = torch.cat([torch.randint(3, 151640, (48,), generator=g), torch.full((34 * 46,), tcfg.image_token_index),
                          torch.randint(3, 151640, (512,), generator=g)])
@@ -313,6 +315,8 @@ def main():
         # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
         traffic = None
         try:
+            if MODEL != "llava7b":
+                raise KeyError("the committed PMC pass was collected on the headline config only")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
             key = {"gemm_swiglu": "<2, 2,", "gemm_none": "<1, 0,", "gemm_splitk_partial": "<1, 3,"}.get(dom)
             for k, v in pmc.items():

@@ -43,12 +43,16 @@ typedef struct {
 /* per-layer target weights; wqkv = rows [q | k | v] fused, wgu = rows [gate | up] fused, all W32-packed (done once at load) */
 typedef struct {
   const void *wqkv, *bqkv, *wo, *wgu, *wdown, *ln1, *ln2;
+  /* fp8 (OCP e4m3) weights, BASELINE config 5: when a scale pointer is non-NULL the matching weight is an fp8 W32 image
+     (vispec_pack_weight_fp8) and the pointer holds its per-output-channel fp32 dequantisation scales; NULL = bf16 weight */
+  const void *sqkv, *so, *sgu, *sdown;
 } vispec_layer_weights;
 
 typedef struct {
   const void *embed;      /* [V, D]   model.embed_tokens.weight */
   const void *norm;       /* [D]      model.norm.weight */
   const void *lm_head;    /* [V, D]   lm_head.weight (also the draft's head, utils.py:300) */
+  const void *lm_head_scale; /* fp32 [V] when lm_head is an fp8 image, else NULL */
   const void *rope_cos, *rope_sin; /* [max_pos, head_dim] bf16, built as modeling_llama_kv.py:147-181 */
 } vispec_target_misc;
 
@@ -82,6 +86,11 @@ int  vispec_set_kv(vispec_ctx*, void* target_kv, void* draft_kv);
    row-major nn.Linear weight [N, K] once at load; P must hold vispec_packed_elems(N, K) bf16 elements. */
 int vispec_pack_weight(vispec_ctx*, void* stream, const void* W_rowmajor, int N, int K, void* P);
 long long vispec_packed_elems(int N, int K);
+/* fp8 weights (W8A16): Wq is a row-major uint8 matrix of OCP e4m3fn codes; the GEMM computes bf16(scale[n]·(X·Wqᵀ)+bias) with bf16
+   activations (the tile is up-converted in registers, exact) — the kernel is HBM-bound, the gain is the halved weight stream. */
+int vispec_pack_weight_fp8(vispec_ctx*, void* stream, const void* Wq_rowmajor_u8, int N, int K, void* P8);
+int vispec_gemm_skinny_fp8(vispec_ctx*, void* stream, const void* X, int ldx, const void* P8, const void* wscale_f32, const void* bias,
+                           void* Y, int ldy, const void* R, int ldr, int M, int N, int K, int epilogue);
 /* Y[M,N] = X[M,K] · W[N,K]^T (+bias) ; epilogue: 0 none, 1 += residual R (bf16 add of two bf16 tensors),
    2 SwiGLU: W holds [gate rows | up rows] (2N rows), Y = silu(g)*u.  M <= 32.   nn.Linear in every module above.
    W is W32-packed.  Small N is split over K across workgroups (needs ctx for the partial workspace). */

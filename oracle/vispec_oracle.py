@@ -44,6 +44,25 @@ def bf16_round(x) -> np.ndarray:
     return out.reshape(x.shape)
 
 
+def e4m3_round(x) -> np.ndarray:
+    """float32 -> nearest-even OCP e4m3fn value (4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormal step 2^-9),
+    returned as float32; magnitudes above 448 saturate."""
+    x = np.asarray(x, np.float32)
+    a = np.minimum(np.abs(x).astype(np.float64), 464.0)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -20)))
+    ulp = np.where(a >= 2.0 ** -6, 2.0 ** (e - 3), 2.0 ** -9)
+    q = np.rint(a / ulp) * ulp  # numpy rint = round-half-to-even
+    q = np.minimum(q, 448.0)
+    return (np.sign(x) * q).astype(np.float32)
+
+
+def quantize_fp8(W):
+    """per-output-channel e4m3 quantisation used for BASELINE config 5: W ≈ scale[n] * q[n, k]  (fp32 arithmetic throughout)."""
+    W = np.asarray(W, np.float32)
+    scale = (np.maximum(np.abs(W).max(axis=1), np.float32(1e-12)) / np.float32(448.0)).astype(np.float32)
+    return e4m3_round((W / scale[:, None]).astype(np.float32)), scale
+
+
 def _ident(x) -> np.ndarray:
     return np.asarray(x, dtype=np.float32)
 
@@ -78,6 +97,11 @@ class Ops:
         self.rd = bf16_round if bf16 else _ident
 
     def linear(self, x, W, b=None):
+        if isinstance(W, tuple):  # (e4m3 values, per-output-channel scales): y = scale * (x · q^T) (+b), W8A16
+            y = (np.asarray(x, np.float32) @ W[0].T) * W[1][None, :]
+            if b is not None:
+                y = y + np.asarray(b, np.float32)
+            return self.rd(y.astype(np.float32))
         y = np.asarray(x, np.float32) @ np.asarray(W, np.float32).T
         if b is not None:
             y = y + np.asarray(b, np.float32)
@@ -447,9 +471,15 @@ def mrope_tables(pos3: np.ndarray, head_dim: int, theta: float, section) -> Tupl
 class TargetLlama:
     """KV-Llama target: modeling_llama_kv.py:527-653 (attention), :927-1080 (model), lm_head + .float() :1190-1197."""
 
-    def __init__(self, cfg: TargetConfig, weights: Dict[str, np.ndarray], bf16: bool = False, cos=None, sin=None):
+    def __init__(self, cfg: TargetConfig, weights: Dict[str, np.ndarray], bf16: bool = False, cos=None, sin=None, fp8=False):
+        """fp8: True = quantise every streamed GEMM weight (projections + lm_head) here; or a dict name -> (e4m3 values, scales)
+        of already-quantised weights (the product's own codes, so that exact .5 ties of w/scale cannot differ)."""
         self.cfg = cfg
         self.w = {k: np.asarray(v, np.float32) for k, v in weights.items()}
+        if fp8:
+            for k in list(self.w):
+                if k.endswith("_proj.weight") or k == "lm_head.weight":
+                    self.w[k] = fp8[k] if isinstance(fp8, dict) else quantize_fp8(self.w[k])
         self.ops = Ops(bf16)
         if cos is None:
             cos, sin = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)

@@ -32,7 +32,7 @@ def test_ctypes_structs_match_header_layout():
     import ctypes as C
     from vispec_amd import lib as L
     assert C.sizeof(L.VispecConfig) == 22 * 4
-    assert C.sizeof(L.LayerWeights) == 7 * 8 and C.sizeof(L.TargetMisc) == 5 * 8 and C.sizeof(L.DraftWeights) == 17 * 8
+    assert C.sizeof(L.LayerWeights) == 11 * 8 and C.sizeof(L.TargetMisc) == 6 * 8 and C.sizeof(L.DraftWeights) == 17 * 8
 
 
 def test_no_silent_fallback_without_gpu():

@@ -39,7 +39,7 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None):
+def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None, outlier_frac=2e-5, outlier_mult=2):
     """`scale`: magnitude the ulp is taken at (default: the values themselves).  For a chained epilogue
     (linear -> round -> + residual -> round) a 1-ulp flip of the FIRST rounding survives at the magnitude of the
     operands, not of the (possibly cancelling) sum, so the operands' magnitude is passed as scale."""
@@ -51,7 +51,7 @@ def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None):
     bad = np.abs(got - want) > tol
     # statistical tail of large shapes: a handful of elements per million sit where two roundings flip together (e.g. a
     # result next to a binade boundary); allow <= 2e-5 of the elements up to twice the bound, nothing beyond that
-    if bad.mean() <= 2e-5 and not (np.abs(got - want) > 2 * tol).any():
+    if bad.mean() <= outlier_frac and not (np.abs(got - want) > outlier_mult * tol).any():
         bad[:] = False
     if bad.any():
         i = np.unravel_index(np.argmax(np.abs(got - want) / tol), got.shape)
@@ -309,3 +309,46 @@ def test_gemm_other_model_shapes(lib, engine, M, N, K):
     L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(X), K, p(W), None, p(Y), N, None, 0, M, N, K, 0))
     torch.cuda.synchronize()
     assert_bf16_close(fn(Y), vo.Ops(True).linear(x, w))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (30, 256, 704), (8, 1008, 256), (30, 4096, 3584), (30, 1024, 18944), (5, 96, 11008)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
+    """W8A16: e4m3 weights (per-output-channel scale), bf16 activations; Y = bf16(scale * (X · q^T) + b) (+ epilogue)."""
+    from vispec_amd.engine import pack_weight_fp8, quantize_fp8
+    if epi == 2 and N % 32:
+        pytest.skip("SwiGLU needs N % 32 == 0")
+    rng = np.random.default_rng(N * 3 + K + M + epi)
+    o = vo.Ops(bf16=True)
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    rows = 2 * N if epi == 2 else N
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((M, N), dtype=np.float32))
+    q_u8, sc = quantize_fp8(tb(w))
+    # the product quantiser (torch float8 on the GPU) and the oracle's numpy e4m3 quantiser agree except on exact .5 ties of
+    # w/scale (bf16 weights make such ties real; the last ulp of the fp32 division decides them)
+    qo, so = vo.quantize_fp8(w)
+    qp = q_u8.view(torch.float8_e4m3fn).float().cpu().numpy()
+    assert (qp != qo).mean() < 2e-3 and np.abs(qp - qo).max() <= np.abs(qo).max() / 8
+    np.testing.assert_allclose(sc.cpu().numpy(), so, rtol=2e-7)
+    qo, so = qp, sc.cpu().numpy()  # the GEMM itself is checked on the product's own codes
+    P8 = pack_weight_fp8(q_u8)
+    scale = None
+    if epi == 0:
+        want = o.linear(x, (qo, so), b)
+    elif epi == 1:
+        lin = o.linear(x, (qo, so), b)
+        want = o.add(r, lin)
+        scale = np.maximum(np.abs(r), np.abs(lin))
+    else:
+        gu = o.linear(x, (qo, so), b)
+        want = o.silu_mul(gu[:, :N], gu[:, N:])
+    X, B, R = tb(x), tb(b), tb(r)
+    Y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_skinny_fp8(engine.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, M, N, K, epi))
+    torch.cuda.synchronize()
+    # SwiGLU on fp8 codes (|q| up to 448): a gate that cancels to ~0 carries the fp32 accumulation-order error of much larger
+    # terms, so a few elements per 10^4 sit further out (bounded at 8x)
+    assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale,
+                      outlier_frac=1e-3 if epi == 2 else 2e-5, outlier_mult=8 if epi == 2 else 2)

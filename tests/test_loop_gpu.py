@@ -307,3 +307,55 @@ def test_qwen25vl_target_loop_matches_oracle():
                               image_grid_thw=torch.tensor(grids), max_new_tokens=20)
     n = min(ar.shape[1], len(o_out))
     np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])
+
+
+def test_fp8_target_weights_loop_matches_oracle():
+    """BASELINE config 5 shape of model: Qwen2.5-VL-like target with fp8 (e4m3, per-output-channel) weights in every streamed
+    GEMM incl. lm_head; bf16 draft.  Oracle = same quantised model (numpy e4m3).  The product prefill runs on the dequantised
+    bf16 weights (torch), so KV differs from the oracle's at the rounding level; the structured pair keeps tokens identical."""
+    Q = synth.QWEN_TINY
+    IMG = Q["V"] - 1
+    tw = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=91, structured=True, qkv_bias=True, H_kv=Q["Hkv"])
+    dw = synth.make_draft_weights(Q["D"], Q["H"], Q["I"], Q["V"], seed=92, structured=True, qkv_bias=True,
+                                  target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    tcfg = TargetConfig(hidden_size=Q["D"], num_heads=Q["H"], num_kv_heads=Q["Hkv"], intermediate_size=Q["I"], vocab_size=Q["V"], num_layers=Q["NL"],
+                        max_position_embeddings=Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True,
+                        architectures=("Qwen2_5_VLForConditionalGeneration",), image_token_index=IMG, attn_impl="sdpa",
+                        mrope_section=Q["mrope_section"])
+    dcfg = DraftConfig(hidden_size=Q["D"], num_heads=Q["H"], intermediate_size=Q["I"], vocab_size=Q["V"], max_position_embeddings=Q["max_pos"],
+                       rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, target_weight_dtype="fp8")
+    # hand the oracle the product's own e4m3 codes and scales (split back per projection)
+    etw = sm.engine.tw
+    f8 = lambda t: t.view(torch.float8_e4m3fn).float().cpu().numpy()
+    hd, codes = Q["D"] // Q["H"], {}
+    for i in range(Q["NL"]):
+        p_ = f"model.layers.{i}."
+        c8, s8 = etw.codes8[i], etw.scales8[i]
+        nq, nk = Q["H"] * hd, Q["Hkv"] * hd
+        for nm, key, lo, hi in (("self_attn.q_proj", "wqkv", 0, nq), ("self_attn.k_proj", "wqkv", nq, nq + nk), ("self_attn.v_proj", "wqkv", nq + nk, nq + 2 * nk),
+                                ("self_attn.o_proj", "wo", 0, Q["D"]), ("mlp.gate_proj", "wgu", 0, Q["I"]), ("mlp.up_proj", "wgu", Q["I"], 2 * Q["I"]),
+                                ("mlp.down_proj", "wdown", 0, Q["D"])):
+            codes[p_ + nm + ".weight"] = (f8(c8[key][lo:hi]), s8[key][lo:hi].cpu().numpy())
+    codes["lm_head.weight"] = (f8(etw.c_lm_head8), etw.s_lm_head8.cpu().numpy())
+    ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
+                                        attn_impl="sdpa", mrope_section=Q["mrope_section"]), tw, bf16=True, fp8=codes)
+    od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)
+    rng = np.random.default_rng(19)
+    grids = [(1, 6, 8)]
+    ids = np.concatenate([rng.integers(3, IMG, 6), np.full(12, IMG), rng.integers(3, IMG, 8)])
+    mask = ids == IMG
+    feats = synth.bf16_grid(rng.standard_normal((12, Q["D"]), dtype=np.float32) * 0.05)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(),
+                                               image_grid_thw=torch.tensor(grids), max_new_tokens=24, log=True, return_acceptance_len=True)
+    pos3, delta = synth.qwen_rope_index(ids, IMG, grids)
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[mask] = feats
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, inputs_embeds=emb, image_mask=mask, max_new_tokens=24, max_pos=Q["max_pos"],
+                                         position_ids=pos3, rope_delta=delta)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc and max(acc) >= 3
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(),
+                              image_grid_thw=torch.tensor(grids), max_new_tokens=20)
+    n = min(ar.shape[1], len(o_out))
+    np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])

@@ -194,3 +194,15 @@ def test_g10_qwen_target(golden_dir):
     n = L + len(g["cand"])
     close(data[0][0, 0, :, :n], g["k0"])
     close(data[0][3, 0, :, :n], g["v1"])
+
+
+def test_e4m3_round_matches_torch_float8():
+    import torch
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-3, 0.1, 1, 20, 200)] +
+                       [np.array([0, 448, -448, 449.9, 463.9, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 0.0009765625, 17.0, 18.0, 19.0], np.float32)])
+    want = torch.from_numpy(np.clip(x, -448, 448)).to(torch.float8_e4m3fn).float().numpy()
+    got = vo.e4m3_round(x)
+    np.testing.assert_array_equal(got, want)
+    q, s = vo.quantize_fp8(rng.standard_normal((16, 64)).astype(np.float32))
+    assert np.abs(q).max() == 448 and (np.abs(q).max(axis=1) == 448).all() and s.shape == (16,)

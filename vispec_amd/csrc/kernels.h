@@ -79,6 +79,27 @@ __global__ __launch_bounds__(64) void pack_w32_kernel(const bf16_t* __restrict__
   *reinterpret_cast<uint4*>(P + (((size_t)tile * (K >> 4) + ks) * 64 + l) * 8) = v;
 }
 
+// ---- fp8 (OCP e4m3fn) weights: the same tiling with 32 k per 1 KiB tile (lane l: W[32t + (l&31)][32c + 16(l>>5) .. +16]).
+// The GEMM stays HBM-bound, so the win is the halved weight stream; activations stay bf16 and the tile is up-converted in
+// registers (e4m3 is exactly representable in bf16) for the bf16 MFMA, the per-output-channel scale is applied to the fp32
+// accumulator in the epilogue (W8A16).
+__global__ __launch_bounds__(64) void pack_w32_fp8_kernel(const unsigned char* __restrict__ W, int N, int K, unsigned char* __restrict__ P) {
+  const int ks = blockIdx.x, tile = blockIdx.y, l = threadIdx.x;
+  const int row = tile * 32 + (l & 31), k = ks * 32 + (l >> 5) * 16;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < N) v = *reinterpret_cast<const uint4*>(W + (size_t)row * K + k);
+  *reinterpret_cast<uint4*>(P + (((size_t)tile * (K >> 5) + ks) * 64 + l) * 16) = v;
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned fp8x2_to_bf16x2(unsigned v, bool hi_word) {
+  const f32x2_t f = hi_word ? __builtin_amdgcn_cvt_pk_f32_fp8(v, true) : __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
+  return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xFFFF0000u);  // exact: e4m3 fits bf16
+}
+__device__ __forceinline__ void fp8x16_to_bf16(uint4 raw, uint4& lo, uint4& hi) {
+  lo = make_uint4(fp8x2_to_bf16x2(raw.x, false), fp8x2_to_bf16x2(raw.x, true), fp8x2_to_bf16x2(raw.y, false), fp8x2_to_bf16x2(raw.y, true));
+  hi = make_uint4(fp8x2_to_bf16x2(raw.z, false), fp8x2_to_bf16x2(raw.z, true), fp8x2_to_bf16x2(raw.w, false), fp8x2_to_bf16x2(raw.w, true));
+}
+
 // bytes of LDS one staged X group takes: UNROLL k-step images of 1 KiB, padded so that both the staging writes
 // (8 lanes = one 128-B row segment -> 8 different 16-B bank groups) and the fragment reads are conflict-free
 #define XS_STEP 1056
@@ -88,22 +109,25 @@ constexpr int gemm_w32_lds_bytes() {
   return (NW * 2 * UNROLL * XS_STEP) > (NW * NT * 4096) ? (NW * 2 * UNROLL * XS_STEP) : (NW * NT * 4096);
 }
 
-template <int NT, int EPI, int UNROLL, int NW, int DBG = 0>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
+template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
 __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
-                                                           int S) {
+                                                           int S, const float* __restrict__ wscale) {
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
   const int j = lane & 31, hi = lane >> 5;
   const int tile = blockIdx.x, split = blockIdx.y;
-  const int KS = K >> 4;
+  // a "step" is one 1 KiB weight tile: 16 k in bf16, 32 k in fp8 (two MFMAs); a group is 64 k either way
+  constexpr int KSTEP = W8 ? 32 : 16;
+  constexpr int LOADS = W8 ? UNROLL / 2 : UNROLL;  // weight loads per group
+  const int KS = K / KSTEP;
   const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
   const int len = ks_hi - ks_lo;
   const int w_lo = ks_lo + (int)((long)len * wave / NW), w_hi = ks_lo + (int)((long)len * (wave + 1) / NW);
-  const uint4* pa0 = reinterpret_cast<const uint4*>(P + (size_t)tile * KS * 512) + lane + (size_t)w_lo * 64;
-  const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P + (size_t)(tile + tile2_off) * KS * 512) + lane + (size_t)w_lo * 64 : pa0;
+  const uint4* pa0 = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * 64 + lane + (size_t)w_lo * 64;
+  const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P) + (size_t)(tile + tile2_off) * KS * 64 + lane + (size_t)w_lo * 64 : pa0;
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -121,13 +145,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
 #pragma unroll
   for (int i = 0; i < NINST; ++i) {
     const int row = srow0 + i * RPI;
-    sx[i] = X + (size_t)(row < M ? row : 0) * ldx + (size_t)w_lo * 16 + seg * 8;  // rows >= M read row 0, never stored
+    sx[i] = X + (size_t)(row < M ? row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;  // rows >= M read row 0, never stored
     woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
   const int roff = hi * XS_HALF + j * 16;
 
   struct Regs {
-    uint4 a[NT][UNROLL];
+    uint4 a[NT][LOADS];
     uint4 x[NINST];
   };
   auto load = [&](Regs& g) {  // all loads unconditional plain global loads; X first (it is consumed first, through LDS)
@@ -136,12 +160,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
       for (int i = 0; i < NINST; ++i) g.x[i] = *reinterpret_cast<const uint4*>(sx[i]);
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < LOADS; ++u) {
       g.a[0][u] = pa0[u * 64];
       if (NT == 2) g.a[NT - 1][u] = pa1[u * 64];
     }
-    pa0 += 64 * UNROLL;
-    pa1 += 64 * UNROLL;
+    pa0 += 64 * LOADS;
+    pa1 += 64 * LOADS;
 #pragma unroll
     for (int i = 0; i < NINST; ++i) sx[i] += 16 * UNROLL;
   };
@@ -152,17 +176,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
       for (int i = 0; i < NINST; ++i) *reinterpret_cast<uint4*>(xb + woff[i]) = g.x[i];
     }
     // same-wave LDS traffic is processed in issue order: the fragment reads below see the writes above
+    if (!W8) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const uint4 bv = (DBG == 1) ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
-                                  : *reinterpret_cast<const uint4*>(xb + u * XS_STEP + roff);
+      for (int u = 0; u < UNROLL; ++u) {
+        const uint4 bv = (DBG == 1) ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                    : *reinterpret_cast<const uint4*>(xb + u * XS_STEP + roff);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t], 0, 0, 0);
+      }
+    } else {
+      // fp8 tile c holds k = 32c + 16*hi + [0,16) for this lane: its two 8-k halves pair with the staged bf16 step (2c + hi),
+      // half 0 / half 1 of the activation image
+#pragma unroll
+      for (int c = 0; c < LOADS; ++c) {
+        const unsigned char* xstep = xb + (2 * c + hi) * XS_STEP + j * 16;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(xstep);
+        const uint4 b1 = *reinterpret_cast<const uint4*>(xstep + XS_HALF);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          uint4 a_lo, a_hi;
+          fp8x16_to_bf16(g.a[t][c], a_lo, a_hi);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[t], 0, 0, 0);
+        }
+      }
     }
   };
   const int n_steps = w_hi - w_lo;
-  const int n_groups = n_steps / UNROLL;  // wave-uniform
+  const int n_groups = n_steps / LOADS;  // wave-uniform
   if (n_groups > 0) {
     // Register double-buffering: group g+1 is in flight while group g feeds the matrix core.  The steady-state loop issues
     // its prefetch UNCONDITIONALLY: a prefetch under `if (more)` makes hipcc size every s_waitcnt for the no-prefetch path,
@@ -185,19 +227,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
       compute(r0, 0);
     }
   }
-  {  // < UNROLL leftover k-steps: fragment-shaped X loads straight from global
-    const bf16_t* px = X + (size_t)(j < M ? j : 0) * ldx + hi * 8 + (size_t)(w_lo + n_groups * UNROLL) * 16;
-    for (int rstep = n_groups * UNROLL; rstep < n_steps; ++rstep) {
+  {  // leftover steps (less than a group): fragment-shaped X loads straight from global
+    const bf16_t* px = X + (size_t)(j < M ? j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
+    for (int rstep = n_groups * LOADS; rstep < n_steps; ++rstep) {
       const uint4 av = pa0[0];
       const uint4 bv = *reinterpret_cast<const uint4*>(px);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0], 0, 0, 0);
-      if (NT == 2) {
-        const uint4 av1 = pa1[0];
-        acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
+      if (!W8) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0], 0, 0, 0);
+        if (NT == 2) {
+          const uint4 av1 = pa1[0];
+          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
+        }
+      } else {
+        const uint4 bv1 = *reinterpret_cast<const uint4*>(px + 8);
+        uint4 a_lo, a_hi;
+        fp8x16_to_bf16(av, a_lo, a_hi);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[0], 0, 0, 0);
+        if (NT == 2) {
+          fp8x16_to_bf16(pa1[0], a_lo, a_hi);
+          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
+          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[NT - 1], 0, 0, 0);
+        }
       }
       pa0 += 64;
       pa1 += 64;
-      px += 16;
+      px += KSTEP;
     }
   }
   if (DBG == 2) {
@@ -230,6 +285,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
       }
     }
     const int n = (tile + (tt ? tile2_off : 0)) * 32 + 8 * q + 4 * hi;
+    if (W8 && n < N) {  // per-output-channel dequantisation scale on the fp32 accumulator
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] *= wscale[n + r];
+        if (EPI == EPI_SWIGLU) u2[r] *= wscale[tile2_off * 32 + n + r];
+      }
+    }
     if (j < M && n < N) {
       if (EPI == EPI_PARTIAL) {
         float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * 32 + j) * N + n;

@@ -263,6 +263,7 @@ static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
 // RMSNorm that follows in the layer (one kernel boundary and one activation round trip less).
 //   Y (bf16, ld ldy) may be null when only the normed output is wanted.  M <= 32.
 struct GemmOut {
+  const float* wscale = nullptr;  // non-null: P is an fp8 (e4m3) W32 image with per-output-channel scales (W8A16)
   void* Y = nullptr; int ldy = 0;
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
@@ -270,16 +271,20 @@ struct GemmOut {
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
   if (M < 1 || M > 32) return fail("gemm_skinny: M must be in [1,32]");
-  if (N % 8 || K % 16) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 == 0 required");
+  if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
-  const int tiles = (N + 31) / 32, KS = K / 16;
+  const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
   if (epi == EPI_SWIGLU) {
     if (N % 32) return fail("gemm_skinny: SwiGLU needs N %% 32 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
-    prof_begin(s, 2, (double)N * K * 4.0);
-    hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x, ldx, w,
-                       tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+    prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
+    if (o.wscale)
+      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x,
+                         ldx, w, tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
+    else
+      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x, ldx, w,
+                         tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
@@ -294,22 +299,32 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   }
   if (force_split > 0) S = force_split;
   if (S == 1 && !o.norm_w) {
-    prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * 2.0);
-    if (epi == EPI_RESIDUAL)
+    prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
+    if (epi == EPI_RESIDUAL && o.wscale)
+      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x,
+                         ldx, w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
+    else if (epi == EPI_RESIDUAL)
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w,
-                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
+    else if (o.wscale)
+      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
+                         w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
     else
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1);
+                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
   }
   if (!ctx) return fail("gemm_skinny: split-K needs a ctx (partial workspace)");
   if ((size_t)S * 32 * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
-  prof_begin(s, 3, (double)N * K * 2.0);
-  hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                     nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+  prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
+  if (o.wscale)
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, true>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
+                       w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, o.wscale);
+  else
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
@@ -323,8 +338,9 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 
 // legacy-shaped helper used by most call sites
 static int launch_gemm(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, void* Y, int ldy,
-                       const void* R, int ldr, int M, int N, int K, int epi) {
+                       const void* R, int ldr, int M, int N, int K, int epi, const void* wscale = nullptr) {
   GemmOut o;
+  o.wscale = (const float*)wscale;
   o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr;
   return launch_gemm_ex(ctx, s, X, ldx, P, bias, M, N, K, epi, o);
 }
@@ -453,6 +469,19 @@ extern "C" int vispec_pack_weight(vispec_ctx*, void* stream, const void* W, int 
   return launch_pack((hipStream_t)stream, W, N, K, P);
 }
 extern "C" long long vispec_packed_elems(int N, int K) { return (long long)packed_elems(N, K); }
+extern "C" int vispec_pack_weight_fp8(vispec_ctx*, void* stream, const void* Wq_rowmajor_u8, int N, int K, void* P) {
+  if (K % 32) return fail("pack_fp8: K %% 32");
+  hipLaunchKernelGGL(pack_w32_fp8_kernel, dim3(K / 32, (N + 31) / 32), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)Wq_rowmajor_u8,
+                     N, K, (unsigned char*)P);
+  KCHK();
+  return 0;
+}
+// vispec_gemm_skinny on an fp8 (e4m3) W32 image: Y = bf16(scale[n] * (X · Wq^T) + bias) (+ epilogue); scale fp32 [N] (2N for SwiGLU)
+extern "C" int vispec_gemm_skinny_fp8(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P8, const void* wscale,
+                                      const void* bias, void* Y, int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
+  if (epilogue < 0 || epilogue > 2 || !wscale) return fail("gemm_skinny_fp8: bad arguments");
+  return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P8, bias, Y, ldy, R, ldr, M, N, K, epilogue, wscale);
+}
 extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
                                   int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
   if (epilogue < 0 || epilogue > 2) return fail("gemm_skinny: bad epilogue");
@@ -480,16 +509,16 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
-                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S)
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr)
   if (dbg == 1) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 1>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
     KCHK();
     return 0;
   }
   if (dbg == 2) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
     KCHK();
     return 0;
   }
@@ -672,7 +701,7 @@ static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, con
 static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
-  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE)) return -1;
+  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
   if (launch_lstopk(ctx, s, ctx->dlogits, V, 1, V, k, ctx->top_idx, ctx->top_logp)) return -1;
   hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, ctx->in_h, D);
   KCHK();
@@ -687,7 +716,7 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
     ps.kv_base = &ctx->st->draft_len;
     ps.kv_add = lvl * k;
     if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
-    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE)) return -1;
+    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
     if (launch_lstopk(ctx, s, ctx->dlogits, V, k, V, k, ctx->top_idx, ctx->top_logp)) return -1;
     hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(256), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
                        ctx->in_h, D);
@@ -862,7 +891,7 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
     const vispec_layer_weights& w = ctx->layers[l];
     bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
     bf16_t* vc = ctx->target_kv + (size_t)(2 * l + 1) * slab;
-    if (launch_gemm(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE)) return -1;
+    if (launch_gemm(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE, w.sqkv)) return -1;
     if (launch_rope(s, ctx->qkv, T, H, Hk, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc, vc, c.max_pos, 1)) return -1;
     if (launch_attention(ctx, s, ctx->qkv, QKV, kc, vc, c.max_pos, H, Hk, T, &ctx->st->n_ctx, T, ctx->tb.tree_mask, ctx->attn_o,
                          H * 128, c.eager_scores, ctx->n_hint))
@@ -870,19 +899,22 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
     {
       GemmOut o;  // x += o_proj(attn) ; xn = post_attention_layernorm(x)   — one split-K GEMM + one reduce
       o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.norm_w = w.ln2; o.normed = ctx->xn; o.ldn = D; o.eps = c.rms_eps;
+      o.wscale = (const float*)w.so;
       if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, T, D, H * 128, EPI_RESIDUAL, o)) return -1;
     }
-    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU)) return -1;
+    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU, w.sgu)) return -1;
     {
       GemmOut o;  // x += down(act) ; then the NEXT layer's input_layernorm, or the final model.norm (hidden_states[-1] is post-norm)
       const bool last = l + 1 == c.num_layers;
       o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.eps = c.rms_eps; o.ldn = D;
       o.norm_w = last ? ctx->tm.norm : ctx->layers[l + 1].ln1;
       o.normed = last ? ctx->hidden_new : ctx->xn;
+      o.wscale = (const float*)w.sdown;
       if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, T, D, I, EPI_RESIDUAL, o)) return -1;
     }
   }
-  if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE)) return -1;
+  if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE, ctx->tm.lm_head_scale))
+    return -1;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(256), 0, s, ctx->logits, V, V, ctx->am);
   KCHK();
   return 0;

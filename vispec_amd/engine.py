@@ -84,6 +84,27 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+E4M3_MAX = 448.0
+
+
+def quantize_fp8(w: torch.Tensor):
+    """Row-major bf16 weight [N, K] -> (e4m3fn codes uint8 [N, K], per-output-channel fp32 scales [N]); W ≈ scale[n] * q[n, k]."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / E4M3_MAX).contiguous()
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale
+
+
+def pack_weight_fp8(q_u8: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    assert q_u8.is_cuda and q_u8.dtype == torch.uint8 and q_u8.dim() == 2 and q_u8.is_contiguous()
+    N, K = q_u8.shape
+    out = torch.empty(((N + 31) // 32) * 32 * K, dtype=torch.uint8, device=q_u8.device)
+    with torch.cuda.device(q_u8.device):
+        L.check(lib.vispec_pack_weight_fp8(None, C.c_void_p(torch.cuda.current_stream(q_u8.device).cuda_stream), _p(q_u8), N, K, _p(out)))
+    return out
+
+
 class TargetWeights:
     """Target language-model weights on the device, fused for streaming: wqkv [ (H+2Hkv)*hd, D ], wgu [2I, D]."""
 
@@ -171,7 +192,8 @@ class Engine:
     """One per (process, GPU).  Not re-entrant."""
 
     def __init__(self, tcfg: TargetConfig, dcfg: DraftConfig, tw: TargetWeights, dw: DraftWeightsDev, total_token=30, depth=3,
-                 top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None):
+                 top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None,
+                 target_weight_dtype: str = "bf16"):
         if eager_scores is None:
             eager_scores = tcfg.attn_impl == "eager"
         if not torch.cuda.is_available():
@@ -199,16 +221,41 @@ class Engine:
         self.d_cos, self.d_sin = rope_tables(dcfg.hidden_size // dcfg.num_heads, self.draft_max_pos, dcfg.rope_theta, self.device)
         # W32-packed copies of every streamed GEMM weight (the row-major originals stay for the PyTorch prefill)
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
-        if not hasattr(tw, "packed"):
+        self.target_weight_dtype = target_weight_dtype
+        if target_weight_dtype == "fp8":
+            # BASELINE config 5: fp8 (e4m3, per-output-channel scales) target weights.  The row-major bf16 copies that the
+            # PyTorch prefill uses are replaced by the DEQUANTISED weights so prefill and decode see the same model.
+            if not hasattr(tw, "packed8"):
+                tw.packed8, tw.scales8, tw.codes8 = [], [], []  # codes8: row-major e4m3 codes (kept for inspection / tests)
+                for lw in tw.layers:
+                    pk, sc, cd = {}, {}, {}
+                    for k in GEMM_T:
+                        q, s_ = quantize_fp8(lw[k])
+                        pk[k], sc[k], cd[k] = pack_weight_fp8(q), s_, q
+                        lw[k] = (q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16)
+                    tw.packed8.append(pk)
+                    tw.scales8.append(sc)
+                    tw.codes8.append(cd)
+                q, s_ = quantize_fp8(tw.lm_head)
+                tw.p_lm_head8, tw.s_lm_head8, tw.c_lm_head8 = pack_weight_fp8(q), s_, q
+                tw.lm_head.copy_((q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16))
+        elif target_weight_dtype != "bf16":
+            raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
+        if target_weight_dtype == "bf16" and not hasattr(tw, "packed"):
             tw.packed = [{k: pack_weight(lw[k]) for k in GEMM_T} for lw in tw.layers]
             tw.p_lm_head = pack_weight(tw.lm_head)
         GEMM_D = ("fc_w", "imgfc_w", "wqkv", "wo", "wgu", "wdown", "ad_wkv", "ad_wo")
         if not hasattr(dw, "packed"):
             dw.packed = {k: pack_weight(dw.t[k]) for k in GEMM_D}
+        fp8 = target_weight_dtype == "fp8"
         for i, lw in enumerate(tw.layers):
-            s = L.LayerWeights(**{k: _p(tw.packed[i][k] if k in GEMM_T else v) for k, v in lw.items()})
+            pk = tw.packed8[i] if fp8 else tw.packed[i]
+            s = L.LayerWeights(**{k: _p(pk[k] if k in GEMM_T else v) for k, v in lw.items()})
+            if fp8:
+                s.sqkv, s.so, s.sgu, s.sdown = (_p(tw.scales8[i][k]) for k in GEMM_T)
             L.check(self.lib.vispec_set_target_layer(self.h, i, C.byref(s)))
-        m = L.TargetMisc(embed=_p(tw.embed), norm=_p(tw.norm), lm_head=_p(tw.p_lm_head), rope_cos=_p(self.t_cos), rope_sin=_p(self.t_sin))
+        m = L.TargetMisc(embed=_p(tw.embed), norm=_p(tw.norm), lm_head=_p(tw.p_lm_head8 if fp8 else tw.p_lm_head),
+                         lm_head_scale=_p(tw.s_lm_head8) if fp8 else None, rope_cos=_p(self.t_cos), rope_sin=_p(self.t_sin))
         L.check(self.lib.vispec_set_target_misc(self.h, C.byref(m)))
         d = L.DraftWeights(rope_cos=_p(self.d_cos), rope_sin=_p(self.d_sin),
                            **{k: _p(dw.packed[k] if k in GEMM_D else v) for k, v in dw.t.items()})

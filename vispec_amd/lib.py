@@ -24,11 +24,11 @@ class VispecConfig(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("wqkv", "bqkv", "wo", "wgu", "wdown", "ln1", "ln2")]
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "bqkv", "wo", "wgu", "wdown", "ln1", "ln2", "sqkv", "so", "sgu", "sdown")]
 
 
 class TargetMisc(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("embed", "norm", "lm_head", "rope_cos", "rope_sin")]
+    _fields_ = [(n, c_void_p) for n in ("embed", "norm", "lm_head", "lm_head_scale", "rope_cos", "rope_sin")]
 
 
 class DraftWeights(C.Structure):
@@ -50,6 +50,8 @@ SIGNATURES = {
     "vispec_gemm_skinny": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int]),
     "vispec_pack_weight": (c_int, [P, P, P, c_int, c_int, P]),
     "vispec_packed_elems": (C.c_longlong, [c_int, c_int]),
+    "vispec_pack_weight_fp8": (c_int, [P, P, P, c_int, c_int, P]),
+    "vispec_gemm_skinny_fp8": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int]),
     "vispec_gemm_skinny_norm": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int, P, P, c_int, c_float, c_int, c_int, c_int]),
     "vispec_gemm_skinny_tune": (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int]),
     "vispec_rmsnorm": (c_int, [P, P, P, P, P, c_int, c_int, c_float]),

@@ -26,7 +26,7 @@ from .utils import initialize_tree, reset_tree_mode
 
 class SpecModel:
     def __init__(self, base_model: TargetLM, spec_layer: Model, tokenizer=None, total_token=30, depth=3, top_k=8, num_q=2,
-                 kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None):
+                 kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, target_weight_dtype: str = "bf16"):
         self.base_model = base_model
         self.config = base_model.config
         self.hidden_size = base_model.cfg.hidden_size
@@ -34,7 +34,8 @@ class SpecModel:
         self.tokenizer = tokenizer or SimpleNamespace(eos_token_id=base_model.cfg.eos_token_id, vocab_size=base_model.cfg.vocab_size)
         self.spec_layer = spec_layer
         self.engine = Engine(base_model.cfg, spec_layer.config, base_model.w, spec_layer.w, total_token=total_token, depth=depth,
-                             top_k=top_k, num_q=num_q, kv_max_pos=kv_max_pos, draft_max_pos=draft_max_pos)
+                             top_k=top_k, num_q=num_q, kv_max_pos=kv_max_pos, draft_max_pos=draft_max_pos,
+                             target_weight_dtype=target_weight_dtype)
         base_model.engine = self.engine
         spec_layer.engine = self.engine
         spec_layer.init_tree()
