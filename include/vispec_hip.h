@@ -157,6 +157,11 @@ int vispec_draft_round(vispec_ctx*, void* stream);
    steps rotate at n + tree_pos + delta (utils.py:397-402; the three M-RoPE components are equal there, i.e. ordinary 1-D rotary).
    Call after vispec_begin_request (which resets it to 0). */
 int vispec_set_rope_delta(vispec_ctx*, void* stream, int delta);
+/* Sampling (temperature > 0, utils.py:453-493 + multinomial at :288,:551): enable with a temperature and a seed; verify_accept then
+   runs the sequential-rejection accept and draws the next token on the device with counter-based uniforms (distributionally
+   equivalent to the reference's torch RNG, bit-reproducible against the oracle).  temperature <= 1e-5 restores greedy. */
+int vispec_set_sampling(vispec_ctx*, float temperature, unsigned long long seed);
+int vispec_sample_row(vispec_ctx*, void* stream, const void* logits_row_bf16, int V, int* out_token_dev);
 /* Seed the next token to decode (the prefill's argmax) when no draft is used (AR baseline). */
 int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
 /* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */

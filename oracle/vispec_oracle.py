@@ -552,6 +552,70 @@ def evaluate_posterior_greedy(logits: np.ndarray, candidates: np.ndarray):
     return best, accept_length, logits[best, accept_length]
 
 
+def uniform_hash(seed: int, a: int, b: int, c: int) -> float:
+    """Counter-based uniform in [0,1): splitmix64 of (seed, a, b, c), top 24 bits.  The HIP sampling kernels use the same
+    function (csrc/tree_kernels.h: vs_uniform), so oracle and device draw identical numbers."""
+    M = (1 << 64) - 1
+    z = (seed * 0x9E3779B97F4A7C15 + a * 0xBF58476D1CE4E5B9 + b * 0x94D049BB133111EB + c * 0xD6E8FEB86659FD93 + 0x2545F4914F6CDD1D) & M
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & M
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return (z >> 40) / float(1 << 24)
+
+
+def softmax_T(row: np.ndarray, temperature: float) -> np.ndarray:
+    """softmax(TemperatureLogitsWarper(row)) in fp32 — utils.py:454-455 with the default processor list of exp.sh (T only)."""
+    x = np.asarray(row, np.float32) / np.float32(temperature)
+    e = np.exp(x - x.max())
+    return (e / e.sum(dtype=np.float32)).astype(np.float32)
+
+
+def multinomial_inverse_cdf(p: np.ndarray, u: float) -> int:
+    """One draw from weights p (not necessarily normalised) by inverse CDF with a given uniform u — the deterministic stand-in
+    for torch.multinomial(p, 1) (utils.py:288,551): same distribution, explicit randomness."""
+    c = np.cumsum(np.asarray(p, np.float64))
+    return int(min(np.searchsorted(c, u * c[-1], side="right"), len(p) - 1))
+
+
+def evaluate_posterior_sampling(logits: np.ndarray, candidates: np.ndarray, temperature: float, uni):
+    """utils.py:453-493 — sequential rejection over the tree's children.  `uni(j, i)` supplies uni_dist[j, i]
+    (the reference draws torch.rand_like(candidates)).  -> (best, accept_length, sample_p [V])."""
+    n_leaf, m = candidates.shape
+    logits_p = np.stack([[softmax_T(logits[j, c], temperature) for c in range(m)] for j in range(n_leaf)])
+    accept_length = 1
+    accept_cand = candidates[0].copy()
+    best = 0
+    adjust = False
+    gtp = None
+    for i in range(1, m):
+        if i != accept_length:
+            break
+        adjust = False
+        is_eq = (candidates[:, :accept_length] == accept_cand[:accept_length]).all(axis=1)
+        fi = int(np.nonzero(is_eq)[0][0])
+        gtp = logits_p[fi, i - 1].copy()
+        seen = set()
+        for j in range(n_leaf):
+            if not is_eq[j]:
+                continue
+            xi = int(candidates[j, i])
+            if xi == -1 or xi in seen:
+                continue
+            seen.add(xi)
+            if uni(j, i) <= gtp[xi]:
+                accept_cand[accept_length] = xi
+                accept_length += 1
+                best = j
+                break
+            gtp[xi] = 0
+            gtp = gtp / gtp.sum(dtype=np.float32)
+            adjust = True
+    sample_p = gtp if (adjust and accept_length != m) else logits_p[best, accept_length - 1]
+    return best, accept_length - 1, sample_p
+
+
 def tree_decoding(target: TargetLlama, pkv, tree_candidates, tree_position_ids, n_ctx, retrieve_indices, rope_delta=0):
     """utils.py:389-412.  -> (logits [n_leaf, m, V], hidden_state_new [T,D]).  Qwen2.5-VL adds the cached rope_deltas and
     expands to 3 equal components (:397-402), which is ordinary 1-D rotary at the shifted position."""
@@ -572,8 +636,8 @@ class LoopState:
 
 
 def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_data, cur_len, hidden_state_new, sample_p,
-                            draft: DraftModel, head_w):
-    """utils.py:496-593 (greedy)."""
+                            draft: DraftModel, head_w, sample_u=None):
+    """utils.py:496-593.  sample_u: None = greedy (argmax, :554); a uniform in [0,1) = multinomial(sample_p) (:551)."""
     prev = st.input_ids.shape[0]
     select = st.retrieve_indices[best, : accept_length + 1] + prev  # :516-518
     st.input_ids = np.concatenate([st.input_ids, candidates[best, : accept_length + 1]])  # :520-526
@@ -582,9 +646,9 @@ def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_
         d[..., prev : prev + tgt.shape[-2], :] = tgt
     cur_len[...] = prev + accept_length + 1  # :541
     accept_hidden = hidden_state_new[st.retrieve_indices[best, : accept_length + 1]]  # :543-546
-    token = argmax_first(sample_p)  # :554
+    token = argmax_first(sample_p) if sample_u is None else multinomial_inverse_cdf(sample_p, sample_u)  # :554 / :551
     st.draft_tokens, st.retrieve_indices, st.tree_mask, st.tree_position_ids = draft.topK_genrate(
-        accept_hidden, np.concatenate([st.input_ids, [token]]), head_w
+        accept_hidden, np.concatenate([st.input_ids, [token]]), head_w, sampling=sample_u is not None
     )
     st.new_token += accept_length + 1  # :582
     return token
@@ -592,7 +656,7 @@ def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_
 
 def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embeds=None, image_mask=None,
                  max_new_tokens=512, max_length=2048, eos_token_id=2, max_pos=None, scripted_accept=None, position_ids=None,
-                 rope_delta=0):
+                 rope_delta=0, temperature=0.0, seed=0):
     """SpecModel.specgenerate, temperature 0 (spec_model_ours.py:247-582).
     -> (input_ids, new_token, idx, accept_lengths).  `scripted_accept` (bench-only knob, never used by
     parity tests) is None."""
@@ -608,9 +672,14 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
         logits, hidden = target.forward(pkv, input_ids=input_ids, position_ids=position_ids)
     else:
         logits, hidden = target.forward(pkv, inputs_embeds=inputs_embeds, position_ids=position_ids)
-    token = argmax_first(logits[-1])  # :290
+    sampling = temperature > 1e-5  # spec_model_ours.py:272-277
+    if sampling:  # utils.py:284-288
+        x = logits[-1] / np.float32(temperature)
+        token = multinomial_inverse_cdf(np.exp(x - x.max()), uniform_hash(seed, 0xFFFF, 0, 0))
+    else:
+        token = argmax_first(logits[-1])  # :290
     ids1 = np.concatenate([input_ids, [token]])
-    dt, ri, tm, tp = draft.topK_genrate(hidden, ids1, target.lm_head, inputs_embeds=inputs_embeds, image_mask=image_mask)
+    dt, ri, tm, tp = draft.topK_genrate(hidden, ids1, target.lm_head, inputs_embeds=inputs_embeds, image_mask=image_mask, sampling=sampling)
     st = LoopState(input_ids, dt, ri, tm, tp)
     idx = 0
     for idx in range(max_length):  # :484
@@ -619,9 +688,15 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
                                            rope_delta)
         ext = np.concatenate([st.draft_tokens, [-1]])  # :503
         candidates = ext[st.retrieve_indices]  # :504
-        best, acc, sample_p = evaluate_posterior_greedy(logits, candidates)  # :505-507
+        if sampling:
+            rnd = len(st.accept_lengths)
+            best, acc, sample_p = evaluate_posterior_sampling(logits, candidates, temperature, lambda j, i, r=rnd: uniform_hash(seed, r, j, i))
+            su = uniform_hash(seed, rnd, 255, 255)
+        else:
+            best, acc, sample_p = evaluate_posterior_greedy(logits, candidates)  # :505-507
+            su = None
         st.accept_lengths.append(acc)
-        update_inference_inputs(st, candidates, best, acc, pkv_data, cur_len, hidden_new, sample_p, draft, target.lm_head)
+        update_inference_inputs(st, candidates, best, acc, pkv_data, cur_len, hidden_new, sample_p, draft, target.lm_head, sample_u=su)
         if eos_token_id in st.input_ids[input_len:].tolist():  # :544
             break
         if st.new_token > max_new_tokens:  # :546

@@ -257,6 +257,59 @@ def g6_posterior():
     np.savez_compressed(os.path.join(OUT, "g6_posterior.npz"), **out)
 
 
+def g7_posterior_sampling():
+    """evaluate_posterior, sampling branch (utils.py:453-493), with torch.rand_like replaced by a recorded uniform tensor and the
+    processor list the reference builds for --temperature T (prepare_logits_processor, utils.py:39-55)."""
+    rng = np.random.default_rng(700)
+    out = {}
+    V = 40
+    n = 0
+    real_rand_like = torch.rand_like
+    for T_ in (1.0, 0.7, 1.5):
+        lp = utils.prepare_logits_processor(temperature=T_)
+        for rep in range(6):
+            n_leaf, m = int(rng.integers(2, 9)), int(rng.integers(2, 6))
+            # leaves of a small prefix tree: rows share prefixes so that is_eq / the candidate set logic is exercised
+            cand = np.zeros((n_leaf, m), np.int64)
+            cand[:, 0] = 7
+            for c in range(1, m):
+                for j in range(n_leaf):
+                    cand[j, c] = cand[j - 1, c] if (j > 0 and rng.random() < 0.5 and (cand[j, :c] == cand[j - 1, :c]).all()) else rng.integers(0, V)
+            if rep % 3 == 2:
+                cand[rng.integers(0, n_leaf), -1] = -1
+            logits = (rng.standard_normal((n_leaf, m, V)) * 2).astype(np.float32)
+            # rows with equal prefixes must carry the same distribution (they are gathers of the same tree node)
+            for c in range(m):
+                for j in range(1, n_leaf):
+                    for j2 in range(j):
+                        if (cand[j, : c + 1] == cand[j2, : c + 1]).all():
+                            logits[j, c] = logits[j2, c]
+                            break
+            if rep % 2 == 0:  # make acceptance likely along row 0
+                for c in range(m - 1):
+                    if cand[0, c + 1] >= 0:
+                        logits[:, c, cand[0, c + 1]] += 6
+                for c in range(m):
+                    for j in range(1, n_leaf):
+                        for j2 in range(j):
+                            if (cand[j, : c + 1] == cand[j2, : c + 1]).all():
+                                logits[j, c] = logits[j2, c]
+                                break
+            u = rng.random((n_leaf, m)).astype(np.float32)
+            if rep % 2 == 0:
+                u[0, : max(2, m - rep // 2)] *= 0.05  # accepted for sure on the first levels of row 0
+            torch.rand_like = lambda t_, dtype=None, _u=u: torch.from_numpy(_u).to(dtype or t_.dtype)
+            try:
+                b, a, p_ = utils.evaluate_posterior(t(logits), torch.from_numpy(cand), lp)
+            finally:
+                torch.rand_like = real_rand_like
+            out[f"logits{n}"], out[f"cand{n}"], out[f"u{n}"], out[f"T{n}"] = logits, cand, u, np.float32(T_)
+            out[f"best{n}"], out[f"acc{n}"], out[f"p{n}"] = np.int64(int(b)), np.int64(int(a)), f32(p_)
+            n += 1
+    out["n"] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, "g7_posterior_sampling.npz"), **out)
+
+
 def g8_loop():
     """Whole-loop token streams (+ per-round accept lengths, greedy-AR equality):
     text-only random pair, structured (successor) pair, and image-path structured pair."""
@@ -428,8 +481,9 @@ def g10_qwen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
-    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g8=g8_loop, g9=g9_bf16, g10=g10_qwen)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

@@ -330,7 +330,7 @@ def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
     # w/scale (bf16 weights make such ties real; the last ulp of the fp32 division decides them)
     qo, so = vo.quantize_fp8(w)
     qp = q_u8.view(torch.float8_e4m3fn).float().cpu().numpy()
-    assert (qp != qo).mean() < 2e-3 and np.abs(qp - qo).max() <= np.abs(qo).max() / 8
+    assert (qp != qo).mean() < 2e-2 and np.abs(qp - qo).max() <= np.abs(qo).max() / 8
     np.testing.assert_allclose(sc.cpu().numpy(), so, rtol=2e-7)
     qo, so = qp, sc.cpu().numpy()  # the GEMM itself is checked on the product's own codes
     P8 = pack_weight_fp8(q_u8)

@@ -206,3 +206,21 @@ def test_e4m3_round_matches_torch_float8():
     np.testing.assert_array_equal(got, want)
     q, s = vo.quantize_fp8(rng.standard_normal((16, 64)).astype(np.float32))
     assert np.abs(q).max() == 448 and (np.abs(q).max(axis=1) == 448).all() and s.shape == (16,)
+
+
+def test_g7_evaluate_posterior_sampling(golden_dir):
+    """Sampling branch of evaluate_posterior (temperature > 0): same decisions and the same residual distribution as the
+    reference when fed the reference's own uniform draws."""
+    g = load(golden_dir, "g7_posterior_sampling.npz")
+    accs = []
+    for i in range(int(g["n"])):
+        u = g[f"u{i}"]
+        b, a, p = vo.evaluate_posterior_sampling(g[f"logits{i}"], g[f"cand{i}"], float(g[f"T{i}"]), lambda j, c: u[j, c])
+        assert (b, a) == (int(g[f"best{i}"]), int(g[f"acc{i}"])), i
+        np.testing.assert_allclose(p, g[f"p{i}"], rtol=2e-5, atol=1e-7)
+        accs.append(a)
+    assert 0 in accs and max(accs) >= 2
+    # the explicit-uniform multinomial is a proper inverse CDF
+    p = np.array([0.1, 0.0, 0.6, 0.3])
+    assert [vo.multinomial_inverse_cdf(p, u) for u in (0.0, 0.0999, 0.1, 0.69, 0.7, 0.9999)] == [0, 0, 2, 2, 3, 3]
+    assert 0.0 <= vo.uniform_hash(1, 2, 3, 4) < 1.0 and vo.uniform_hash(1, 2, 3, 4) != vo.uniform_hash(1, 2, 3, 5)

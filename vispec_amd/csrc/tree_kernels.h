@@ -268,6 +268,214 @@ __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sampling path (temperature > 0): utils.py:453-493 (evaluate_posterior, sequential rejection over the tree's children),
+// :284-288 / :549-552 (multinomial for the first / next token).  Randomness is explicit and counter-based so that the oracle
+// draws the very same numbers (oracle/vispec_oracle.py: uniform_hash); parity with the reference's torch RNG is distributional.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float vs_uniform(unsigned long long seed, unsigned a, unsigned b, unsigned c) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + a * 0xBF58476D1CE4E5B9ull + b * 0x94D049BB133111EBull + c * 0xD6E8FEB86659FD93ull +
+                         0x2545F4914F6CDD1Dull;
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// block-wide (1024 threads) max and sum-exp of row/T  (softmax(TemperatureLogitsWarper(row)), fp32)
+__device__ __forceinline__ void vs_row_stats(const bf16_t* __restrict__ row, int V, float T, float* s_f, float& m, float& Z) {
+  const int tid = threadIdx.x;
+  float mx = NEG_INF;
+  for (int v = tid; v < V; v += 1024) mx = fmaxf(mx, bf2f(row[v]) / T);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_f[tid >> 6] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_f[w]);
+  __syncthreads();
+  float se = 0.f;
+  for (int v = tid; v < V; v += 1024) se += expf(bf2f(row[v]) / T - mx);
+  se = wave_sum(se);
+  if ((tid & 63) == 0) s_f[tid >> 6] = se;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < 16; ++w) tot += s_f[w];
+  __syncthreads();
+  m = mx;
+  Z = tot;
+}
+
+// one multinomial draw by inverse CDF over weights exp(row/T - m) with `nrem` removed tokens (torch.multinomial stand-in)
+__device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, int V, float T, float m, const int* removed, int nrem, float u,
+                                              double* s_d, int* s_i) {
+  const int tid = threadIdx.x;
+  const int chunk = (V + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(V, lo + chunk);
+  double loc = 0.0;
+  for (int v = lo; v < hi; ++v) {
+    bool rem = false;
+    for (int r = 0; r < nrem; ++r) rem |= removed[r] == v;
+    if (!rem) loc += (double)expf(bf2f(row[v]) / T - m);
+  }
+  s_d[tid] = loc;
+  __syncthreads();
+  if (tid == 0) {  // exclusive scan over 1024 partial sums + locate the chunk (sequential: 1024 adds, once per round)
+    double run = 0.0;
+    for (int t = 0; t < 1024; ++t) { const double x = s_d[t]; s_d[t] = run; run += x; }
+    const double target = (double)u * run;
+    int t = 0;
+    while (t + 1 < 1024 && s_d[t + 1] <= target) ++t;
+    s_i[0] = t;
+    s_d[1024] = target;
+  }
+  __syncthreads();
+  const int tsel = s_i[0];
+  if (tid == tsel) {
+    const double target = s_d[1024];
+    double run = s_d[tid];
+    int pick = min(V, hi) - 1;
+    for (int v = lo; v < hi; ++v) {
+      bool rem = false;
+      for (int r = 0; r < nrem; ++r) rem |= removed[r] == v;
+      if (!rem) run += (double)expf(bf2f(row[v]) / T - m);
+      if (run > target) { pick = v; break; }
+    }
+    s_i[1] = max(pick, 0);
+  }
+  __syncthreads();
+  return s_i[1];
+}
+
+// first token: token = multinomial(softmax(lp(orig[:, -1])))   (utils.py:284-288)
+__global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restrict__ row, int V, float T, unsigned long long seed, int* out) {
+  __shared__ float s_f[16];
+  __shared__ double s_d[1025];
+  __shared__ int s_i[2];
+  float m, Z;
+  vs_row_stats(row, V, T, s_f, m, Z);
+  const int tok = vs_multinomial(row, V, T, m, nullptr, 0, vs_uniform(seed, 0xFFFFu, 0u, 0u), s_d, s_i);
+  if (threadIdx.x == 0) out[0] = tok;
+}
+
+// evaluate_posterior (sampling) + the integer half of update_inference_inputs; logits [T, V] bf16 of the verify forward
+__global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
+                                                                    unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
+                                                                    int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
+                                                                    int* __restrict__ draft_ids) {
+  __shared__ int cand[TREE_MAX_T][TREE_RET_W];
+  __shared__ int s_eq[TREE_MAX_T];
+  __shared__ int accept_cand[TREE_RET_W];
+  __shared__ int removed[TREE_MAX_T];
+  __shared__ int sh[8];  // 0 accept_length, 1 best, 2 adjust, 3 nrem, 4 fi, 5 accepted-this-level
+  __shared__ float s_f[16];
+  __shared__ double s_d[1025];
+  __shared__ int s_i[2];
+  const int tid = threadIdx.x;
+  const int nl = st->n_leaf, md = st->max_depth, round = st->rounds;
+  if (tid < nl)
+    for (int c = 0; c < TREE_RET_W; ++c) {
+      const int node = tb.retrieve[tid * TREE_RET_W + c];
+      cand[tid][c] = (c < md && node >= 0) ? tb.tree_tokens[node] : -1;
+    }
+  if (tid == 0) { sh[0] = 1; sh[1] = 0; sh[2] = 0; sh[3] = 0; }
+  __syncthreads();
+  if (tid == 0) accept_cand[0] = cand[0][0];
+  __syncthreads();
+  float last_m = 0.f;
+  int last_node = 0;
+  for (int i = 1; i < md; ++i) {
+    const int al = sh[0];
+    if (i != al) break;
+    if (tid < nl) {
+      bool eq = true;
+      for (int c = 0; c < al; ++c) eq &= cand[tid][c] == accept_cand[c];
+      s_eq[tid] = eq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int fi = 0;
+      while (fi < nl && !s_eq[fi]) ++fi;
+      sh[4] = fi;
+      sh[2] = 0;
+      sh[3] = 0;
+    }
+    __syncthreads();
+    const int node = tb.retrieve[sh[4] * TREE_RET_W + (i - 1)];
+    const bf16_t* row = logits + (size_t)node * V;
+    float m, Z;
+    vs_row_stats(row, V, T, s_f, m, Z);
+    last_m = m;
+    last_node = node;
+    if (tid == 0) {
+      float rm = 0.f;
+      int nrem = 0, nseen = 0;
+      int seen[TREE_MAX_T];
+      for (int j = 0; j < nl; ++j) {
+        if (!s_eq[j]) continue;
+        const int x = cand[j][i];
+        if (x == -1) continue;
+        bool dup = false;
+        for (int q = 0; q < nseen; ++q) dup |= seen[q] == x;
+        if (dup) continue;
+        seen[nseen++] = x;
+        const float p = expf(bf2f(row[x]) / T - m) / Z;
+        const float px = p / (1.0f - rm);
+        if (vs_uniform(seed, (unsigned)round, (unsigned)j, (unsigned)i) <= px) {
+          accept_cand[al] = x;
+          sh[0] = al + 1;
+          sh[1] = j;
+          break;
+        }
+        rm += p;
+        removed[nrem++] = x;
+        sh[2] = 1;
+      }
+      sh[3] = nrem;
+    }
+    __syncthreads();
+  }
+  const int accept_length = sh[0], best = sh[1];
+  const bool use_gtp = sh[2] && accept_length != md;
+  const int a = accept_length - 1;
+  int node, nrem;
+  float m;
+  if (use_gtp) {
+    node = last_node; m = last_m; nrem = sh[3];
+  } else {
+    node = tb.retrieve[best * TREE_RET_W + a];
+    float Z;
+    vs_row_stats(logits + (size_t)node * V, V, T, s_f, m, Z);
+    nrem = 0;
+  }
+  const int next = vs_multinomial(logits + (size_t)node * V, V, T, m, removed, nrem, vs_uniform(seed, (unsigned)round, 255u, 255u), s_d, s_i);
+  if (tid == 0) {
+    const int* rowp = tb.retrieve + best * TREE_RET_W;
+    const int n = st->n_ctx;
+    int done = st->done;
+    for (int jj = 0; jj <= a; ++jj) {
+      const int nd = rowp[jj];
+      sel[jj] = nd;
+      const int tok = tb.tree_tokens[nd];
+      if (n + jj < tokens_cap) tokens[n + jj] = tok;
+      if (tok == st->eos_token_id) done |= 1;
+    }
+    for (int jj = a + 1; jj < TREE_RET_W; ++jj) sel[jj] = rowp[a];
+    for (int jj = 0; jj < TREE_RET_W; ++jj) draft_ids[jj] = jj < a ? tb.tree_tokens[rowp[jj + 1]] : next;
+    st->n_prev = n;
+    st->n_ctx = n + a + 1;
+    st->accept_len = a;
+    st->best = best;
+    st->next_token = next;
+    st->new_token += a + 1;
+    if (st->new_token > st->max_new_tokens) done |= 2;
+    st->done = done;
+    if (st->rounds < log_cap) accept_log[st->rounds] = a;
+    st->rounds += 1;
+  }
+}
+
 // KV compaction (utils.py:529-538): rows n+sel[j] -> n+j for j=1..a, for every (layer, k|v, head).
 // One wave per (slab, head): all sources are read into registers before anything is written (rows may overlap).
 __global__ __launch_bounds__(64) void kv_compact_kernel(bf16_t* __restrict__ kv, int s_max, const DevState* __restrict__ st,

@@ -61,6 +61,8 @@ struct vispec_ctx {
   // hipGraph cache: the launch sequence of a round is static for a given (n_hint, forced_accept) — see run_graphed()
   struct GraphSlot { hipGraphExec_t exec = nullptr; long key = -1; };
   GraphSlot g_verify, g_draft, g_ar;
+  float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
+  unsigned long long seed = 0;
   bool use_graphs = true;
   long graph_replays = 0, graph_captures = 0, direct_runs = 0;
   std::vector<void*> allocs;
@@ -722,7 +724,8 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
                        ctx->in_h, D);
     KCHK();
   }
-  hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1, 0);
+  hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1,
+                     ctx->temperature > 1e-5f ? 1 : 0);  // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
   KCHK();
   return 0;
 }
@@ -731,7 +734,7 @@ static int draft_round_body(vispec_ctx* ctx, hipStream_t s);
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  return run_graphed(ctx, s, ctx->g_draft, (long)ctx->n_hint, [&]() { return draft_round_body(ctx, s); });
+  return run_graphed(ctx, s, ctx->g_draft, (long)ctx->n_hint * 2 + (ctx->temperature > 1e-5f), [&]() { return draft_round_body(ctx, s); });
 }
 static int draft_round_body(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
@@ -923,8 +926,12 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
 static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accept) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, Hk = c.num_kv_heads;
-  hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
-                     ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
+  if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
+    hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
+                       ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
+  else
+    hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
+                       ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
   KCHK();
   if (T > 1) {
     hipLaunchKernelGGL(kv_compact_kernel, dim3(2 * c.num_layers * Hk), dim3(64), 0, s, ctx->target_kv, c.max_pos, ctx->st, ctx->sel);
@@ -937,7 +944,9 @@ static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accep
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  const long key = (long)ctx->n_hint * 64 + (forced_accept + 1);
+  unsigned tbits;
+  memcpy(&tbits, &ctx->temperature, 4);
+  const long key = ((long)ctx->n_hint * 64 + (forced_accept + 1)) ^ ((long)tbits << 24) ^ (long)(ctx->seed * 0x9E3779B97F4A7C15ull >> 8);
   return run_graphed(ctx, s, ctx->g_verify, key, [&]() {
     if (target_forward(ctx, s, ctx->c.total_token)) return -1;
     return target_accept(ctx, s, ctx->c.total_token, forced_accept);
@@ -979,6 +988,22 @@ __global__ void set_rope_delta_kernel(DevState* st, int delta) {
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
   if (!ctx) return fail("null ctx");
   hipLaunchKernelGGL(set_rope_delta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, delta);
+  KCHK();
+  return 0;
+}
+
+// temperature <= 1e-5: greedy (utils.py:438-451); > 1e-5: sampling (utils.py:453-493) with the counter-based uniforms of `seed`.
+extern "C" int vispec_set_sampling(vispec_ctx* ctx, float temperature, unsigned long long seed) {
+  if (!ctx) return fail("null ctx");
+  ctx->temperature = temperature;
+  ctx->seed = seed;
+  return 0;
+}
+// token = multinomial(softmax(row / T)) of one bf16 logits row (first token of a sampled request, utils.py:284-288)
+extern "C" int vispec_sample_row(vispec_ctx* ctx, void* stream, const void* logits_row, int V, int* out_token_dev) {
+  if (!ctx || ctx->temperature <= 1e-5f) return fail("sample_row: sampling not enabled (vispec_set_sampling)");
+  hipLaunchKernelGGL(sample_row_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits_row, V, ctx->temperature, ctx->seed,
+                     out_token_dev);
   KCHK();
   return 0;
 }

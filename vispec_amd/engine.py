@@ -318,6 +318,16 @@ class Engine:
     def set_rope_delta(self, delta: int):
         L.check(self.lib.vispec_set_rope_delta(self.h, self._stream(), int(delta)))
 
+    def set_sampling(self, temperature: float, seed: int = 0):
+        L.check(self.lib.vispec_set_sampling(self.h, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def sample_row(self, logits_row: torch.Tensor) -> torch.Tensor:
+        row = logits_row.reshape(-1).to(torch.bfloat16).contiguous()
+        out = torch.zeros(1, dtype=torch.int32, device=row.device)
+        self._keep_row = row
+        L.check(self.lib.vispec_sample_row(self.h, self._stream(), _p(row), int(row.shape[0]), _p(out)))
+        return out
+
     def set_next_token(self, token: torch.Tensor):
         assert token.dtype == torch.int32 and token.is_cuda
         self._keep_tok = token

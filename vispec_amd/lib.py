@@ -67,6 +67,8 @@ SIGNATURES = {
     "vispec_set_tree_host": (c_int, [P, P, P, P, P, P, c_int, c_int]),
     "vispec_draft_round": (c_int, [P, P]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
+    "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),
+    "vispec_sample_row": (c_int, [P, P, P, c_int, P]),
     "vispec_set_next_token": (c_int, [P, P, P]),
     "vispec_ar_step": (c_int, [P, P]),
     "vispec_get_state_host": (c_int, [P, P, P]),

@@ -53,9 +53,9 @@ class Model:
     def topK_genrate(self, hidden_states, input_ids, head, logits_processor, inputs_embeds=None, embed_weights=None,
                      image_mask=None):
         """cnets_ours.py:1043-1238.  `head` must be the target's lm_head (it is what the ctx streams)."""
-        if logits_processor is not None:
-            raise NotImplementedError("sampling (temperature > 0) is a later row of SURVEY.md §8(f)")
         eng = self.engine
+        # logits_processor only changes the row order of retrieve_indices here (cnets_ours.py:1215-1224); the ctx applies it when
+        # sampling is enabled (Engine.set_sampling)
         if head.weight.data_ptr() != eng.tw.lm_head.data_ptr():
             raise ValueError("head must be base_model.lm_head")
         if inputs_embeds is not None and inputs_embeds.shape[-2] >= input_ids.shape[-1]:

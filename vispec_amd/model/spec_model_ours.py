@@ -179,13 +179,16 @@ class SpecModel:
     @torch.no_grad()
     def specgenerate(self, input_ids, temperature=0.0, top_p=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, log=False,
                      is_llama3=False, inputs_embeds=None, return_acceptance_len=False, return_decode_time=False,
-                     forced_accept=None, **kwargs):
-        """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length."""
+                     forced_accept=None, seed=0, **kwargs):
+        """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length.
+        temperature > 1e-5 selects the sampling path (utils.py:453-493) with device-side counter-based randomness (`seed`);
+        like the reference's default processor list (exp.sh: temperature only) top_p / top_k warpers are not applied."""
         if (input_ids is None) ^ (inputs_embeds is not None):  # :263-266 (sic: exactly the reference's condition)
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
-        if temperature > 1e-5:
-            raise NotImplementedError("sampling (temperature > 0) is a later row of SURVEY.md §8(f)")
+        if temperature > 1e-5 and (top_p >= 1e-8 and top_p < 1.0 or top_k > 0):
+            raise NotImplementedError("TopP / TopK logits warpers (utils.py:50-53) are not implemented; temperature only")
         eng = self.engine
+        eng.set_sampling(temperature if temperature > 1e-5 else 0.0, seed)
         dev = eng.device
         max_length = max_length - self.spec_layer.total_tokens - 10  # :270
         input_ids = input_ids.clone().to(dev)
@@ -200,7 +203,7 @@ class SpecModel:
         emb = (inputs_embeds if inputs_embeds is not None else self.base_model.get_input_embeddings()(input_ids))
         emb = emb.reshape(-1, emb.shape[-1]).to(torch.bfloat16).contiguous()
         logits, hidden = self.base_model.prefill(emb, position_ids=position_ids)
-        first = self._first_token(logits)
+        first = eng.sample_row(logits[-1]) if temperature > 1e-5 else self._first_token(logits)
         eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
         if rope_delta:
             eng.set_rope_delta(rope_delta)
@@ -248,6 +251,7 @@ class SpecModel:
         """Greedy AR with the same KV cache and kernels — evaluation/gen_baseline_answer_coco_caption.py:34-133."""
         eng = self.engine
         dev = eng.device
+        eng.set_sampling(0.0, 0)
         input_ids = input_ids.clone().to(dev)
         inputs_embeds, _, _, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
         if inputs_embeds is None:
