@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
+    ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=3, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
     args = ap.parse_args()
     global MODEL
@@ -251,7 +252,8 @@ def main():
                         o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
                         tok += o.shape[1] - ids.shape[1]
                     else:
-                        o, new_token, idx, acc = sms[lane].specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True, **pix)
+                        o, new_token, idx, acc = sms[lane].specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                                        temperature=args.temperature, seed=i, **pix)
                         tok += int(new_token)
                         rnd += idx + 1
                         accs += acc
@@ -366,7 +368,7 @@ def main():
             "ms_per_step": round(1e3 * dt / K, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{MODELS[MODEL]['name']}-shaped target + ViSpec draft, {MODELS[MODEL]['desc']}, "
-                                   "max_new_tokens=512, temperature=0, total_token=30 depth=3 top_k=8 num_q=2; "
+                                   f"max_new_tokens=512, temperature={args.temperature:g}, total_token=30 depth=3 top_k=8 num_q=2; "
                                    f"a step = 1 request on each of {R} concurrent batch-1 lanes per GPU (replicas sharing one weight copy)",
                        "weights": "synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho=0.115) so acceptance is measured",
                        "parallelism": f"dp{world} x {R} lanes/GPU (independent replicas, one-time RCCL weight replication {t_rep:.2f}s)"},
