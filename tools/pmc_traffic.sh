@@ -4,7 +4,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 out=/tmp/pmc_$tag
 rm -rf $out
-( cd "$GRAFT_REPO_ROOT" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-ar > /dev/null 2> gpurun_out/pmc_$tag.err )
+( cd "$GRAFT_REPO_ROOT" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-ar --lanes 1 > /dev/null 2> gpurun_out/pmc_$tag.err )
 find $out -name "*.csv" | head
 f=$(find $out -name "*counter_collection.csv" | head -1)
 head -3 "$f" | cut -c1-400

@@ -22,6 +22,7 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", SRC, "-o", OUT]
+    cmd[1:1] = os.environ.get("VISPEC_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DVISPEC_W_NT=0)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -100,6 +100,21 @@ __device__ __forceinline__ void fp8x16_to_bf16(uint4 raw, uint4& lo, uint4& hi) 
   hi = make_uint4(fp8x2_to_bf16x2(raw.z, false), fp8x2_to_bf16x2(raw.z, true), fp8x2_to_bf16x2(raw.w, false), fp8x2_to_bf16x2(raw.w, true));
 }
 
+// Weight-stream load.  Every weight byte is read exactly once per launch by exactly one wave, so it is loaded non-temporal
+// (`global_load_dwordx4 ... nt`): the stream does not displace the L2-resident activations / split-K partials.
+#ifndef VISPEC_W_NT
+#define VISPEC_W_NT 1
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_weight(const uint4* p) {
+#if VISPEC_W_NT
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+
 // bytes of LDS one staged X group takes: UNROLL k-step images of 1 KiB, padded so that both the staging writes
 // (8 lanes = one 128-B row segment -> 8 different 16-B bank groups) and the fragment reads are conflict-free
 #define XS_STEP 1056
@@ -161,8 +176,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     }
 #pragma unroll
     for (int u = 0; u < LOADS; ++u) {
-      g.a[0][u] = pa0[u * 64];
-      if (NT == 2) g.a[NT - 1][u] = pa1[u * 64];
+      g.a[0][u] = ld_weight(pa0 + u * 64);
+      if (NT == 2) g.a[NT - 1][u] = ld_weight(pa1 + u * 64);
     }
     pa0 += 64 * LOADS;
     pa1 += 64 * LOADS;
@@ -597,47 +612,72 @@ __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(const float* __re
                                                                const int* __restrict__ prefix_dev, int tail,
                                                                int keys_per_wg, int nsplit, bf16_t* __restrict__ out,
                                                                int ldo) {
+  // Latency-bound (a few hundred KB per launch): every load of a phase is issued before the first use, with clamped
+  // (always valid) addresses instead of guards, so the dependent chain is prefix -> {m,l and the first 16 partial tiles} -> out.
   __shared__ float wgt[64][32];
+  __shared__ float smax[8][32], ssum[8][32];
   __shared__ float linv[32];
   const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
   const int head = blockIdx.x / MT, mt = blockIdx.x % MT;
   const int kvh = head / G, qt = (head % G) * MT + mt;
   const int dpart = blockIdx.y;  // 4 blocks per (head, m-tile): 32 d-rows each
   const int n_total = (prefix_dev ? *prefix_dev : 0) + tail;
-  const int ns = min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg);
+  const int ns = max(1, min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg));
   const size_t base = (size_t)(kvh * NQT + qt) * nsplit;
-  {
-    __shared__ float smax[8][32], ssum[8][32];
-    const int q = threadIdx.x & 31, s8 = threadIdx.x >> 5;
-    float mm = NEG_INF;
-    for (int s = s8; s < ns; s += 8) mm = fmaxf(mm, part_ml[(base + s) * 64 + q]);
-    smax[s8][q] = mm;
-    __syncthreads();
+  const int q = threadIdx.x & 31, s8 = threadIdx.x >> 5;
+  const int e4 = dpart * 1024 + threadIdx.x * 4;  // 4 consecutive elements of the [128 d][32 q] tile: one d, queries q4..q4+3
+  float mv[8], lv[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) mm = fmaxf(mm, smax[t][q]);
-    float L = 0.f;
-    for (int s = s8; s < ns; s += 8) {
-      const float ms = part_ml[(base + s) * 64 + q];
-      const float w = (ms == NEG_INF) ? 0.f : __expf(ms - mm);
-      wgt[s][q] = w;
-      L += w * part_ml[(base + s) * 64 + 32 + q];
-    }
-    ssum[s8][q] = L;
-    __syncthreads();
-    if (s8 == 0) {
-      float Lt = 0.f;
+  for (int t = 0; t < 8; ++t) {
+    const int sc = min(s8 + 8 * t, ns - 1);
+    mv[t] = part_ml[(base + sc) * 64 + q];
+    lv[t] = part_ml[(base + sc) * 64 + 32 + q];
+  }
+  float4 po[16];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) Lt += ssum[t][q];
-      linv[q] = (Lt > 0.f) ? 1.0f / Lt : 0.f;
-    }
+  for (int t = 0; t < 16; ++t) po[t] = *reinterpret_cast<const float4*>(part_o + (base + min(t, ns - 1)) * (128 * 32) + e4);
+  float mm = NEG_INF;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) mm = fmaxf(mm, mv[t]);  // clamped duplicates do not change a max
+  smax[s8][q] = mm;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) mm = fmaxf(mm, smax[t][q]);
+  float L = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int sp = s8 + 8 * t;
+    const float w = (sp < ns && mv[t] != NEG_INF) ? __expf(mv[t] - mm) : 0.f;
+    wgt[sp][q] = w;  // rows >= ns get weight 0: the clamped partial loads above contribute nothing
+    L += w * lv[t];
+  }
+  ssum[s8][q] = L;
+  __syncthreads();
+  if (s8 == 0) {
+    float Lt = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Lt += ssum[t][q];
+    linv[q] = (Lt > 0.f) ? 1.0f / Lt : 0.f;
   }
   __syncthreads();
-  for (int e = dpart * 1024 + threadIdx.x; e < (dpart + 1) * 1024; e += 256) {
-    const int d = e >> 5, q = e & 31;
-    float acc = 0.f;
-    for (int s = 0; s < ns; ++s) acc += wgt[s][q] * part_o[(base + s) * (128 * 32) + e];
-    const int m = mt * 32 + q;
-    if (m < M) out[(size_t)m * ldo + head * 128 + d] = f2bf(acc * linv[q]);
+  const int d = e4 >> 5, q4 = e4 & 31;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float4 w = *reinterpret_cast<const float4*>(&wgt[t][q4]);
+    acc.x += w.x * po[t].x; acc.y += w.y * po[t].y; acc.z += w.z * po[t].z; acc.w += w.w * po[t].w;
+  }
+  for (int sp = 16; sp < ns; ++sp) {  // long contexts only (> 16 key splits)
+    const float4 w = *reinterpret_cast<const float4*>(&wgt[sp][q4]);
+    const float4 v = *reinterpret_cast<const float4*>(part_o + (base + sp) * (128 * 32) + e4);
+    acc.x += w.x * v.x; acc.y += w.y * v.y; acc.z += w.z * v.z; acc.w += w.w * v.w;
+  }
+  const float4 li = *reinterpret_cast<const float4*>(&linv[q4]);
+  const float o[4] = {acc.x * li.x, acc.y * li.y, acc.z * li.z, acc.w * li.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mt * 32 + q4 + i;
+    if (m < M) out[(size_t)m * ldo + head * 128 + d] = f2bf(o[i]);
   }
 }
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -414,7 +415,8 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   if (M < 1 || M > 64) return fail("tree_attention: M must be in [1,64]");
   if (tail < 0 || tail > 64) return fail("tree_attention: tail must be in [0,64]");
   const int MT = (M + 31) / 32, NQT = (H / H_kv) * MT;
-  int kpw = 256;
+  static const int kpw_env = getenv("VISPEC_ATT_KPW") ? atoi(getenv("VISPEC_ATT_KPW")) : 0;  // tuning experiments only
+  int kpw = (kpw_env >= 64 && kpw_env % 64 == 0) ? kpw_env : 256;
   if (max_keys < 1) max_keys = 1;
   while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
