@@ -110,6 +110,18 @@ int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void
 int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cos, const void* sin,
                        const int* pos_base_dev, const int* pos_off_dev, void* k_cache, void* v_cache, int s_max,
                        const int* kv_base_dev);
+/* q|k|v projection + rotary + KV append in one pass (modeling_llama_kv.py:560-594; cnets_ours.py:362-396): qkv[:, :H*hd] receives
+   the rotated q, k (rotated) and v go straight to cache rows *kv_base_dev + i.  W is the fused [ (H+2H_kv)*hd, K ] weight packed
+   by vispec_pack_weight(_fp8); when vispec_qkv_rope_fused((H+2H_kv)*hd) is 1 the loader must first reorder its q and k rows into
+   rope order — within each head, row 32t + c takes natural row 16t + c (c < 16) or 64 + 16t + (c - 16) — so that a rotate_half
+   pair meets in one lane of the GEMM epilogue (the launch is then ONE kernel); when it is 0 the natural order is kept and the
+   library runs the split-K GEMM followed by the rotary/append kernel.  wscale NULL = bf16 weight, else fp8 + per-row scales
+   (natural order).  Positions as vispec_rope_append. */
+int vispec_qkv_rope_fused(int n_qkv_rows);
+int vispec_gemm_qkv_rope(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* wscale, const void* bias,
+                         void* qkv, int M, int H, int H_kv, int hd, int K, const void* cos, const void* sin,
+                         const int* pos_base_dev, const int* pos_off_dev, void* k_cache, void* v_cache, int s_max,
+                         const int* kv_base_dev);
 /* tree-masked attention of M query rows against cache rows [0, *prefix_dev) (all visible) + `tail` rows after
    them, of which row m sees tail key t iff bit t of mask_dev[m] is set  (cnets_ours.py:781-815 + 428-433;
    modeling_llama_kv.py:890-924 + 602-623).  q [M, H*hd] row stride ldq ; out [M, H*hd]. */

@@ -352,3 +352,66 @@ def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
     # terms, so a few elements per 10^4 sit further out (bounded at 8x)
     assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale,
                       outlier_frac=1e-3 if epi == 2 else 2e-5, outlier_mult=8 if epi == 2 else 2)
+
+
+@pytest.mark.parametrize("H,Hkv,K,M,fp8,bias", [(48, 8, 256, 30, False, True), (56, 4, 128, 7, False, False), (48, 8, 256, 30, True, True),
+                                                (2, 2, 256, 9, False, True)])
+def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
+    """One-launch q|k|v projection + rotary + KV append (EPI_ROPE, weight packed in rope order) == the GEMM followed by
+    vispec_rope_append, bit for bit, and == the oracle's linear + rope.  (2,2) is below the fused threshold: same entry
+    point, two-kernel path, natural weight order."""
+    from vispec_amd.engine import pack_weight, pack_weight_fp8, quantize_fp8, qkv_rope_order
+    rng = np.random.default_rng(H * 7 + K + M)
+    hd, S = 128, 64
+    N = (H + 2 * Hkv) * hd
+    assert bool(lib.vispec_qkv_rope_fused(N)) == (N // 32 >= 256)
+    o = vo.Ops(True)
+    cos, sin = vo.rope_tables(hd, 128, 10000.0)
+    cos, sin = synth.bf16_grid(cos), synth.bf16_grid(sin)
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((N, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(N, dtype=np.float32)) if bias else None
+    pos_off = rng.integers(0, 20, size=M).astype(np.int32)
+    base, kvb = 40, 11
+    X, W, B = tb(x), tb(w), (tb(b) if bias else None)
+    COS, SIN = tb(cos), tb(sin)
+    d_base = torch.tensor([base], dtype=torch.int32, device=dev())
+    d_kvb = torch.tensor([kvb], dtype=torch.int32, device=dev())
+    d_off = torch.from_numpy(pos_off).to(dev())
+    if fp8:
+        q_u8, sc = quantize_fp8(W)
+        P_nat, P_rope = pack_weight_fp8(q_u8), pack_weight_fp8(qkv_rope_order(q_u8, H + Hkv))
+        wo = (q_u8.view(torch.float8_e4m3fn).float().cpu().numpy(), sc.cpu().numpy())
+    else:
+        sc = None
+        P_nat, P_rope = pack_weight(W), pack_weight(qkv_rope_order(W, H + Hkv))
+        wo = w
+    # reference composition: GEMM (natural order) then the rotary/append kernel
+    Y0 = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    kc0 = torch.zeros(Hkv, S, hd, dtype=torch.bfloat16, device=dev())
+    vc0 = torch.zeros_like(kc0)
+    if fp8:
+        L.check(lib.vispec_gemm_skinny_fp8(engine.h, stream(), p(X), K, p(P_nat), p(sc), p(B), p(Y0), N, None, 0, M, N, K, 0))
+    else:
+        L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(X), K, p(P_nat), p(B), p(Y0), N, None, 0, M, N, K, 0))
+    L.check(lib.vispec_rope_append(None, stream(), p(Y0), M, H, Hkv, hd, p(COS), p(SIN), p(d_base), p(d_off), p(kc0), p(vc0), S, p(d_kvb)))
+    # fused entry point
+    Y1 = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    kc1 = torch.zeros_like(kc0)
+    vc1 = torch.zeros_like(kc0)
+    L.check(lib.vispec_gemm_qkv_rope(engine.h, stream(), p(X), K, p(P_rope), p(sc), p(B), p(Y1), M, H, Hkv, hd, K, p(COS), p(SIN),
+                                     p(d_base), p(d_off), p(kc1), p(vc1), S, p(d_kvb)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fn(Y1)[:, : H * hd], fn(Y0)[:, : H * hd])
+    np.testing.assert_array_equal(fn(kc1), fn(kc0))
+    np.testing.assert_array_equal(fn(vc1), fn(vc0))
+    # and against the oracle
+    qkv = o.linear(x, wo, b)
+    pos = base + pos_off
+    qo = o.rope(qkv[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), cos, sin, pos)
+    ko = o.rope(qkv[:, H * hd : (H + Hkv) * hd].reshape(M, Hkv, hd).transpose(1, 0, 2), cos, sin, pos)
+    vo_ = qkv[:, (H + Hkv) * hd :].reshape(M, Hkv, hd).transpose(1, 0, 2)
+    assert_bf16_close(fn(Y1)[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), qo, ulps=2, min_exact=0.9)
+    assert_bf16_close(fn(kc1)[:, kvb : kvb + M], ko, ulps=2, min_exact=0.9)
+    assert_bf16_close(fn(vc1)[:, kvb : kvb + M], vo_)
+    assert (fn(kc1)[:, :kvb] == 0).all() and (fn(kc1)[:, kvb + M :] == 0).all()

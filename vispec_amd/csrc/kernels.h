@@ -69,7 +69,30 @@ struct DevState {
 // Epilogues: NONE / RESIDUAL / SWIGLU (second stream = the matching `up` block) write bf16 with the reference's rounding
 // points; PARTIAL writes fp32 partial sums [S][32][N] that splitk_reduce_kernel finishes (bias, residual, RMSNorm fused).
 // ------------------------------------------------------------------------------------------------
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_PARTIAL = 3 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_PARTIAL = 3, EPI_ROPE = 4 };
+
+struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m : 0)) ; kv row = *kv_base + kv_add + m
+  const int* base = nullptr;
+  const int* base2 = nullptr;
+  int add = 0;
+  const int* off = nullptr;
+  int row = 1;
+  const int* kv_base = nullptr;
+  int kv_add = 0;
+};
+// EPI_ROPE: the fused q|k|v projection finishes with the rotary embedding and the KV append (modeling_llama_kv.py:575-594,
+// cnets_ours.py:104-119,393-396) instead of a separate pass over the qkv rows.  rotate_half pairs (d, d+64) of a head must
+// meet in one lane, so the q and k rows of the weight are packed in "rope order": 32-row tile t of a head holds
+// d = 16t..16t+15 followed by d+64 (qkv_rope_perm(); v rows keep their order).  q goes to Y at its natural column, k / v
+// go straight to cache row *kv_base + kv_add + m.
+struct RopeEpi {
+  const bf16_t* cosT = nullptr;
+  const bf16_t* sinT = nullptr;
+  PosSpec ps;
+  bf16_t* kc = nullptr;
+  bf16_t* vc = nullptr;
+  int s_max = 0, H = 0, H_kv = 0;
+};
 
 __global__ __launch_bounds__(64) void pack_w32_kernel(const bf16_t* __restrict__ W, int N, int K, bf16_t* __restrict__ P) {
   const int ks = blockIdx.x, tile = blockIdx.y, l = threadIdx.x;
@@ -128,7 +151,7 @@ template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false>  //
 __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
-                                                           int S, const float* __restrict__ wscale) {
+                                                           int S, const float* __restrict__ wscale, RopeEpi re) {
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
@@ -282,6 +305,62 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][t][lane][r] = acc[t][r];
   __syncthreads();
+  if (EPI == EPI_ROPE) {
+    // waves 0/1 own column groups q and q+2 of the tile: packed columns c = 8q + 4hi + r (< 16) and c + 16 = its rotate_half partner
+    if (wave < 2 && j < M) {
+      const int qq = wave;
+      float a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sa = red[0][0][lane][4 * qq + r], sb = red[0][0][lane][4 * (qq + 2) + r];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          sa += red[w][0][lane][4 * qq + r];
+          sb += red[w][0][lane][4 * (qq + 2) + r];
+        }
+        a[r] = sa;
+        b[r] = sb;
+      }
+      const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
+      const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
+      const int kvrow = (re.ps.kv_base ? *re.ps.kv_base : 0) + re.ps.kv_add + j;
+      if (h < re.H + re.H_kv) {
+        const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of a[] / b[]
+        const int pos = (re.ps.base ? *re.ps.base : 0) + (re.ps.base2 ? *re.ps.base2 : 0) + re.ps.add +
+                        (re.ps.off ? re.ps.off[j] : (re.ps.row ? j : 0));
+        float o1[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x1 = a[r], x2 = b[r];
+          if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+          if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
+          x1 = rdbf(x1);
+          x2 = rdbf(x2);
+          const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
+          o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
+          o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
+        }
+        bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)j * ldy + c1
+                                 : re.kc + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+      } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
+        float o1[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x1 = a[r], x2 = b[r];
+          if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+          if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
+          o1[r] = rdbf(x1);
+          o2[r] = rdbf(x2);
+        }
+        bf16_t* dst = re.vc + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+      }
+    }
+    return;
+  }
   constexpr int NGROUPS = (EPI == EPI_SWIGLU) ? 4 : 4 * NT;
   for (int idx = wave; idx < NGROUPS; idx += NW) {
     const int tt = (EPI == EPI_SWIGLU) ? 0 : idx >> 2, q = idx & 3;

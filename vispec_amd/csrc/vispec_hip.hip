@@ -284,10 +284,10 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
     prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
     if (o.wscale)
       hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x,
-                         ldx, w, tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
+                         ldx, w, tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
     else
       hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x, ldx, w,
-                         tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
+                         tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
     KCHK();
     prof_end(s);
     return 0;
@@ -305,16 +305,16 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
     prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
     if (epi == EPI_RESIDUAL && o.wscale)
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x,
-                         ldx, w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
+                         ldx, w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
     else if (epi == EPI_RESIDUAL)
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w,
-                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
+                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
     else if (o.wscale)
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
-                         w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale);
+                         w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
     else
       hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr);
+                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
     KCHK();
     prof_end(s);
     return 0;
@@ -324,10 +324,10 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
   if (o.wscale)
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, true>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
-                       w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, o.wscale);
+                       w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, o.wscale, RopeEpi{});
   else
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
@@ -354,16 +354,6 @@ static int launch_rmsnorm(hipStream_t s, const void* X, const void* w, void* Y, 
   KCHK();
   return 0;
 }
-
-struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m : 0)) ; kv row = *kv_base + kv_add + m
-  const int* base = nullptr;
-  const int* base2 = nullptr;
-  int add = 0;
-  const int* off = nullptr;
-  int row = 1;
-  const int* kv_base = nullptr;
-  int kv_add = 0;
-};
 
 __global__ __launch_bounds__(64) void rope_append2_kernel(bf16_t* __restrict__ qkv, int H, int H_kv,
                                                           const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
@@ -403,6 +393,35 @@ static int launch_rope(hipStream_t s, void* qkv, int M, int H, int H_kv, const v
   hipLaunchKernelGGL(rope_append2_kernel, dim3(M, H + 2 * H_kv), dim3(64), 0, s, (bf16_t*)qkv, H, H_kv, (const bf16_t*)cosT,
                      (const bf16_t*)sinT, ps, (bf16_t*)kc, (bf16_t*)vc, s_max, do_rope);
   KCHK();
+  return 0;
+}
+
+// q|k|v projection + rotary + KV append.  When the row blocks alone fill the chip (no split-K) the three run as ONE launch
+// (EPI_ROPE; the weight must have been packed in rope order — vispec_qkv_rope_fused() tells the loader); otherwise the
+// split-K GEMM is followed by rope_append2_kernel on a naturally ordered weight.
+static bool qkv_rope_fused(int n_rows) { return n_rows % 128 == 0 && n_rows / 32 >= 256; }
+static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
+                           void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, PosSpec ps, void* kc, void* vc,
+                           int s_max) {
+  const int N = (H + 2 * H_kv) * 128;
+  if (!qkv_rope_fused(N)) {
+    if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, M, N, K, EPI_NONE, wscale)) return -1;
+    return launch_rope(s, qkv, M, H, H_kv, cosT, sinT, ps, kc, vc, s_max, 1);
+  }
+  if (M < 1 || M > 32) return fail("gemm_qkv_rope: M must be in [1,32]");
+  if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
+  RopeEpi re;
+  re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT; re.ps = ps; re.kc = (bf16_t*)kc; re.vc = (bf16_t*)vc;
+  re.s_max = s_max; re.H = H; re.H_kv = H_kv;
+  prof_begin(s, 0, (double)N * K * (wscale ? 1.0 : 2.0));
+  if (wscale)
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, true>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s,
+                       (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, (const float*)wscale, re);
+  else
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, (const bf16_t*)X,
+                       ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, nullptr, re);
+  KCHK();
+  prof_end(s);
   return 0;
 }
 
@@ -513,16 +532,16 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
-                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr)
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{})
   if (dbg == 1) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 1>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
     KCHK();
     return 0;
   }
   if (dbg == 2) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
     KCHK();
     return 0;
   }
@@ -556,6 +575,18 @@ extern "C" int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, i
   ps.off = pos_off_dev;
   ps.kv_base = kv_base_dev;
   return launch_rope((hipStream_t)stream, qkv, M, H, H_kv, cosT, sinT, ps, k_cache, v_cache, s_max, 1);
+}
+extern "C" int vispec_qkv_rope_fused(int n_qkv_rows) { return qkv_rope_fused(n_qkv_rows) ? 1 : 0; }
+extern "C" int vispec_gemm_qkv_rope(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* W, const void* wscale,
+                                    const void* bias, void* qkv, int M, int H, int H_kv, int hd, int K, const void* cosT,
+                                    const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache, void* v_cache,
+                                    int s_max, const int* kv_base_dev) {
+  if (hd != 128) return fail("gemm_qkv_rope: head_dim must be 128");
+  PosSpec ps;
+  ps.base = pos_base_dev;
+  ps.off = pos_off_dev;
+  ps.kv_base = kv_base_dev;
+  return launch_qkv_rope(ctx, (hipStream_t)stream, X, ldx, W, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, ps, k_cache, v_cache, s_max);
 }
 extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* q, int ldq, const void* k_cache,
                                      const void* v_cache, int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev,
@@ -683,8 +714,9 @@ static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, con
   const int D = c.hidden_size, Hd = c.draft_heads;
   bf16_t* kc = ctx->draft_kv;
   bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
-  if (launch_gemm(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE)) return -1;
-  if (launch_rope(s, ctx->dqkv, rows, Hd, Hd, ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos, 1)) return -1;
+  if (launch_qkv_rope(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D, ctx->dw.rope_cos,
+                      ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos))
+    return -1;
   if (launch_attention(ctx, s, ctx->dqkv, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, rows, prefix_dev, tail, mask, ctx->dattn, D, 0,
                        ctx->n_hint < c.draft_max_pos ? ctx->n_hint : c.draft_max_pos))
     return -1;
@@ -848,12 +880,12 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   int last_chunk_rows = 0;
   for (int o = 0; o < Lc; o += CHUNK) {
     const int rows = std::min(CHUNK, Lc - o);
-    if (launch_gemm(ctx, s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, ctx->dqkv, 3 * D, nullptr, 0, rows, 3 * D, D, EPI_NONE))
-      return -1;
     PosSpec ps;
     ps.off = ctx->pos_c + o;
     ps.kv_add = o;
-    if (launch_rope(s, ctx->dqkv, rows, Hd, Hd, ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos, 1)) return -1;
+    if (launch_qkv_rope(ctx, s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D,
+                        ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos))
+      return -1;
     last_chunk_rows = rows;
   }
   const bf16_t* qlast = ctx->dqkv + (size_t)(last_chunk_rows - 1) * 3 * D;
@@ -896,8 +928,9 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
     const vispec_layer_weights& w = ctx->layers[l];
     bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
     bf16_t* vc = ctx->target_kv + (size_t)(2 * l + 1) * slab;
-    if (launch_gemm(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, ctx->qkv, QKV, nullptr, 0, T, QKV, D, EPI_NONE, w.sqkv)) return -1;
-    if (launch_rope(s, ctx->qkv, T, H, Hk, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc, vc, c.max_pos, 1)) return -1;
+    if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc,
+                        vc, c.max_pos))
+      return -1;
     if (launch_attention(ctx, s, ctx->qkv, QKV, kc, vc, c.max_pos, H, Hk, T, &ctx->st->n_ctx, T, ctx->tb.tree_mask, ctx->attn_o,
                          H * 128, c.eager_scores, ctx->n_hint))
       return -1;

@@ -84,6 +84,22 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def qkv_rope_order(w: torch.Tensor, n_rope_heads: int, head_dim: int = 128) -> torch.Tensor:
+    """Reorder the q and k rows of a fused q|k|v weight (or code matrix) into the "rope order" the one-launch
+    projection + rotary + KV-append kernel expects (include/vispec_hip.h: vispec_gemm_qkv_rope): within each of the first
+    `n_rope_heads` heads, row 32t + c takes natural row 16t + c (c < 16) or 64 + 16t + (c - 16).  Identity when the library
+    reports that it will run the two-kernel path for this row count (vispec_qkv_rope_fused)."""
+    lib = L.load()
+    assert head_dim == 128
+    if not lib.vispec_qkv_rope_fused(int(w.shape[0])):
+        return w
+    r = torch.arange(w.shape[0], device=w.device)
+    h, t, c = r // 128, (r % 128) // 32, r % 32
+    src = h * 128 + torch.where(c < 16, 16 * t + c, 64 + 16 * t + (c - 16))
+    src = torch.where(r < n_rope_heads * 128, src, r)
+    return w.index_select(0, src).contiguous()
+
+
 E4M3_MAX = 448.0
 
 
@@ -231,7 +247,8 @@ class Engine:
                     pk, sc, cd = {}, {}, {}
                     for k in GEMM_T:
                         q, s_ = quantize_fp8(lw[k])
-                        pk[k], sc[k], cd[k] = pack_weight_fp8(q), s_, q
+                        qp = qkv_rope_order(q, tcfg.num_heads + tcfg.num_kv_heads) if k == "wqkv" else q
+                        pk[k], sc[k], cd[k] = pack_weight_fp8(qp), s_, q
                         lw[k] = (q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16)
                     tw.packed8.append(pk)
                     tw.scales8.append(sc)
@@ -242,11 +259,12 @@ class Engine:
         elif target_weight_dtype != "bf16":
             raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
         if target_weight_dtype == "bf16" and not hasattr(tw, "packed"):
-            tw.packed = [{k: pack_weight(lw[k]) for k in GEMM_T} for lw in tw.layers]
+            nrh = tcfg.num_heads + tcfg.num_kv_heads
+            tw.packed = [{k: pack_weight(qkv_rope_order(lw[k], nrh) if k == "wqkv" else lw[k]) for k in GEMM_T} for lw in tw.layers]
             tw.p_lm_head = pack_weight(tw.lm_head)
         GEMM_D = ("fc_w", "imgfc_w", "wqkv", "wo", "wgu", "wdown", "ad_wkv", "ad_wo")
         if not hasattr(dw, "packed"):
-            dw.packed = {k: pack_weight(dw.t[k]) for k in GEMM_D}
+            dw.packed = {k: pack_weight(qkv_rope_order(dw.t[k], 2 * dcfg.num_heads) if k == "wqkv" else dw.t[k]) for k in GEMM_D}
         fp8 = target_weight_dtype == "fp8"
         for i, lw in enumerate(tw.layers):
             pk = tw.packed8[i] if fp8 else tw.packed[i]
