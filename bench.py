@@ -119,7 +119,17 @@ def run_lanes(fns):
 
 
 def make_request(tcfg, req_id, device):
-    """-> (input_ids [1,L] on the device, specgenerate kwargs)."""
+    """-> (input_ids [1,L] on the device, specgenerate kwargs).  The vision tower is not on the path (it stays PyTorch in a
+    deployment): its output — the projected image features, N(0,1)*0.05 per SURVEY §8(d) — is part of the request and, like
+    the ids, is resident in HBM before the timed region starts."""
+    ids, kw = _make_request(tcfg, req_id, device)
+    n, seed = kw["pixel_values"]
+    from vispec_amd.model.target import SyntheticVision
+    kw["pixel_values"] = SyntheticVision(tcfg.hidden_size).features(int(n), int(seed), device, torch.bfloat16)
+    return ids, kw
+
+
+def _make_request(tcfg, req_id, device):
     from vispec_amd import synth_gpu
     if MODEL == "qwen7b":  # 4 image runs of 256 merged tokens, text in between (multi-turn), 512 text tokens in total
         g = torch.Generator().manual_seed(1000 + req_id)

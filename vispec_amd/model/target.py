@@ -31,6 +31,35 @@ def _rope(x, cos, sin):
     return (x * cos[:, None, :]) + (rot * sin[:, None, :])
 
 
+_sdpa_lock = __import__("threading").Lock()
+_sdpa_ready = set()
+
+
+def _sdpa(q, k, v, gqa):
+    """Causal SDPA for the prefill.  PyTorch-ROCm's flash backend initialises its per-device kernel table lazily and not
+    thread-safely (concurrent first calls from several lanes were seen to fail with "Accelerated SDPA only supports ..."), so the
+    first call per device is serialised; if the accelerated backend is unavailable the math backend is used (still PyTorch)."""
+    dev = q.device.index
+    if dev not in _sdpa_ready:
+        with _sdpa_lock:
+            out = _sdpa_try(q, k, v, gqa)
+            torch.cuda.synchronize(q.device)
+            _sdpa_ready.add(dev)
+            return out
+    return _sdpa_try(q, k, v, gqa)
+
+
+def _sdpa_try(q, k, v, gqa):
+    try:
+        return F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=gqa)
+    except RuntimeError as e:
+        import warnings
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        warnings.warn(f"accelerated SDPA unavailable ({str(e)[:120]}); prefill attention falls back to the math backend")
+        with sdpa_kernel([SDPBackend.MATH]):
+            return F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=gqa)
+
+
 class _Head:
     """stand-in for nn.Linear lm_head: the reference passes `base_model.lm_head` into topK_genrate (utils.py:300)."""
 
@@ -125,7 +154,7 @@ class TargetLM:
             v = v.view(Ln, Hk, hd).transpose(0, 1)
             kv[2 * i, 0, :, :Ln] = k
             kv[2 * i + 1, 0, :, :Ln] = v
-            a = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True, enable_gqa=(H != Hk))[0]
+            a = _sdpa(q[None], k[None], v[None], H != Hk)[0]
             x = x + F.linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"])
             h = _rmsnorm(x, lw["ln2"], c.rms_norm_eps)
             g, u = F.linear(h, lw["wgu"]).chunk(2, dim=-1)
