@@ -480,10 +480,57 @@ def g10_qwen():
                         k0=f32(data[0, 0, :, : L + Tn]), v1=f32(data[3, 0, :, : L + Tn]))
 
 
+def g11_update_inference_inputs():
+    """utils.update_inference_inputs in isolation (SURVEY §8c "G7"): accepted ids appended, KV rows gathered from the tree
+    slots into [n, n+a+1) of EVERY cache tensor, lengths, the hidden rows handed to the draft, next token — greedy and
+    multinomial.  The draft call is intercepted (its own behaviour is pinned by g4)."""
+    rng = np.random.default_rng(1100)
+    out = {}
+    cases = [(0, 0, False), (2, 3, False), (1, 1, False), (3, 2, True)]  # (best, accept_length, sampling)
+    for ci, (best, acc, sampling) in enumerate(cases):
+        n, Tn, V, D = 11, 9, 40, 8
+        ids = rng.integers(3, V, n)
+        ri = np.array([[0, 1, 3, 7], [0, 1, 4, -1], [0, 2, 5, 8], [0, 2, 6, -1]], np.int64)
+        draft_tokens = rng.integers(3, V, Tn)
+        ext = np.concatenate([draft_tokens, [-1]])
+        cand = ext[ri]
+        data = rng.standard_normal((4, 1, 2, 32, 4)).astype(np.float32)
+        data2 = rng.standard_normal((2, 1, 2, 32, 4)).astype(np.float32)  # a second device's tensor (kv_cache.py:121-141)
+        cur = np.full(6, n + Tn, np.int64)
+        hid = rng.standard_normal((1, Tn, D)).astype(np.float32)
+        sp = np.abs(rng.standard_normal(V)).astype(np.float32)
+        sp /= sp.sum()
+        seen = {}
+
+        class Draft:
+            def topK_genrate(self, hidden, input_ids=None, head=None, logits_processor=None):
+                seen["hidden"], seen["ids"] = f32(hidden), input_ids.numpy().copy()
+                return "dt", "ri", "tm", "tp"
+
+        model = SimpleNamespace(spec_layer=Draft(), base_model=SimpleNamespace(lm_head="head"))
+        td, td2, tc = t(data.copy()), t(data2.copy()), torch.from_numpy(cur.copy())  # t() aliases its argument
+        u = 0.37
+        orig = torch.multinomial
+        torch.multinomial = lambda prob, k: torch.searchsorted(torch.cumsum(prob.double(), 0), torch.tensor([u], dtype=torch.float64) * prob.double().sum()).clamp(max=prob.numel() - 1)
+        try:
+            r = utils.update_inference_inputs(torch.from_numpy(ids)[None], torch.from_numpy(cand), torch.tensor(best), acc, torch.from_numpy(ri),
+                                              (object() if sampling else None), 5, [td, td2], tc, model, t(hid), t(sp))
+        finally:
+            torch.multinomial = orig
+        assert r[1:5] == ("dt", "ri", "tm", "tp")
+        out.update({f"ids{ci}": ids, f"ri{ci}": ri, f"cand{ci}": cand, f"best{ci}": np.int64(best), f"acc{ci}": np.int64(acc),
+                    f"sampling{ci}": np.int64(sampling), f"u{ci}": np.float64(u), f"data{ci}": data, f"data2_{ci}": data2, f"hid{ci}": hid, f"sp{ci}": sp,
+                    f"o_ids{ci}": r[0][0].numpy(), f"o_data{ci}": td.numpy(), f"o_data2_{ci}": td2.numpy(), f"o_cur{ci}": tc.numpy(),
+                    f"o_new_token{ci}": np.int64(r[5]), f"o_token{ci}": np.int64(int(r[7])), f"o_hidden{ci}": seen["hidden"][0],
+                    f"o_draft_ids{ci}": seen["ids"][0]})
+    out["n"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g11_update.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

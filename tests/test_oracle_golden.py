@@ -224,3 +224,31 @@ def test_g7_evaluate_posterior_sampling(golden_dir):
     p = np.array([0.1, 0.0, 0.6, 0.3])
     assert [vo.multinomial_inverse_cdf(p, u) for u in (0.0, 0.0999, 0.1, 0.69, 0.7, 0.9999)] == [0, 0, 2, 2, 3, 3]
     assert 0.0 <= vo.uniform_hash(1, 2, 3, 4) < 1.0 and vo.uniform_hash(1, 2, 3, 4) != vo.uniform_hash(1, 2, 3, 5)
+
+
+def test_g11_update_inference_inputs(golden_dir):
+    """utils.update_inference_inputs in isolation: appended ids, KV gather-compaction of every cache tensor, lengths, the hidden
+    rows handed to the draft, next token (argmax / multinomial with the recorded uniform), new_token."""
+    g = load(golden_dir, "g11_update.npz")
+    for i in range(int(g["n"])):
+        seen = {}
+
+        class Draft:
+            def topK_genrate(self, hidden, ids, head_w, sampling=False):
+                seen["hidden"], seen["ids"], seen["sampling"] = hidden, ids, sampling
+                return "dt", "ri", "tm", "tp"
+
+        st = vo.LoopState(g[f"ids{i}"].copy(), None, g[f"ri{i}"], None, None, new_token=5)
+        data, data2 = g[f"data{i}"].copy(), g[f"data2_{i}"].copy()
+        cur = np.zeros(6, np.int64)
+        samp = bool(g[f"sampling{i}"])
+        tok = vo.update_inference_inputs(st, g[f"cand{i}"], int(g[f"best{i}"]), int(g[f"acc{i}"]), [data, data2], cur, g[f"hid{i}"][0], g[f"sp{i}"],
+                                         Draft(), None, sample_u=float(g[f"u{i}"]) if samp else None)
+        np.testing.assert_array_equal(st.input_ids, g[f"o_ids{i}"])
+        np.testing.assert_array_equal(data, g[f"o_data{i}"])
+        np.testing.assert_array_equal(data2, g[f"o_data2_{i}"])
+        np.testing.assert_array_equal(cur, g[f"o_cur{i}"])
+        assert tok == int(g[f"o_token{i}"]) and st.new_token == int(g[f"o_new_token{i}"])
+        np.testing.assert_array_equal(seen["hidden"], g[f"o_hidden{i}"])
+        np.testing.assert_array_equal(seen["ids"], g[f"o_draft_ids{i}"])
+        assert seen["sampling"] == samp and (st.draft_tokens, st.tree_position_ids) == ("dt", "tp")
