@@ -399,3 +399,55 @@ def test_sampling_acceptance_is_distributionally_sane():
     top = int(np.argmax(p))
     freq = np.mean(np.array(firsts) == top)
     assert abs(freq - p[top]) < 4 * np.sqrt(p[top] * (1 - p[top]) / 60) + 0.02
+
+
+def test_api_errors_stop_rules_and_return_tuples(golden_dir):
+    """The reference's specgenerate contract (spec_model_ours.py:247-266, 363-370, 484-582): argument errors, the three stop
+    rules (eos in the generated ids, new_token > max_new_tokens, the max_length round cap) and the flag-dependent return
+    tuple — each against the oracle's restatement of the same rule."""
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids = g["succ0_ids"]
+    t_ids = torch.from_numpy(ids)[None]
+    sm, ot, od = build(50, 60, True)
+    with pytest.raises(ValueError):
+        sm.specgenerate(None)  # neither ids nor embeds
+    with pytest.raises(ValueError):
+        sm.specgenerate(t_ids, inputs_embeds=torch.zeros(1, len(ids), T["D"]))
+    # return tuples by flags (:555-582)
+    r = sm.specgenerate(t_ids, max_new_tokens=12)
+    assert torch.is_tensor(r) and r.shape[0] == 1
+    r = sm.specgenerate(t_ids, max_new_tokens=12, log=True)
+    assert len(r) == 3 and isinstance(r[1], int) and isinstance(r[2], int)
+    r = sm.specgenerate(t_ids, max_new_tokens=12, return_acceptance_len=True, return_decode_time=True)
+    assert len(r) == 3 and isinstance(r[1], list) and isinstance(r[2], float)
+    # new_token > max_new_tokens (:546) for several budgets, incl. 0 (one round always runs)
+    for mnt in (0, 1, 7, 23):
+        out, new_token, idx, acc = sm.specgenerate(t_ids, max_new_tokens=mnt, log=True, return_acceptance_len=True)
+        o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=mnt, max_pos=T["max_pos"])
+        np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+        assert (new_token, idx, acc) == (o_new, o_idx, o_acc) and new_token > mnt
+    # max_length round cap (:270,:484): max_length - spec_layer.total_tokens (= total_token - 1) - 10 = 4 rounds
+    out, new_token, idx, acc = sm.specgenerate(t_ids, max_new_tokens=400, max_length=30 + 10 + 3, log=True, return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=400, max_length=30 + 10 + 3, max_pos=T["max_pos"])
+    assert idx == o_idx == 3 and len(acc) == 4 and acc == o_acc
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    # eos among the generated ids (:544): pick a token the stream is known to produce and make it the eos
+    full = vo.specgenerate(ot, od, ids, max_new_tokens=40, max_pos=T["max_pos"])[0]
+    eos = int(full[len(ids) + 9])
+    sm2, ot2, od2 = build(50, 60, True)
+    sm2.base_model.cfg.eos_token_id = eos
+    sm2 = SpecModel(sm2.base_model, sm2.spec_layer, total_token=30, depth=3, top_k=8, num_q=2)  # engine config carries the eos id
+    out, new_token, idx, acc = sm2.specgenerate(t_ids, max_new_tokens=40, log=True, return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot2, od2, ids, max_new_tokens=40, eos_token_id=eos, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert (new_token, idx, acc) == (o_new, o_idx, o_acc) and len(o_out) < len(full) and eos in o_out[len(ids):]
+
+
+def test_image_feature_count_mismatch_raises():
+    """spec_model_ours.py:363-370: number of image placeholder tokens != number of image features -> ValueError."""
+    sm, _, _ = build(70, 71, True, arch="LlavaNextForConditionalGeneration")
+    ids = np.full(20, 5, np.int64)
+    ids[4:12] = IMG_TOK
+    feats = torch.zeros(7, T["D"], dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError, match="do not match"):
+        sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=feats, max_new_tokens=4)
