@@ -165,6 +165,10 @@ int vispec_set_tree_host(vispec_ctx*, void* stream, const int* tokens_T, const i
    last vispec_verify_accept. */
 int vispec_draft_round(vispec_ctx*, void* stream);
 
+/* change the tree size (nodes incl. the root, 1..64) of later rounds: what `model.spec_layer.total_tokens = total_token - 1`
+   does after the total_token=-1 autotune of SpecModel.from_pretrained (spec_model_ours.py:179-201).  Trees of more than 32 nodes
+   run every verify GEMM in two 32-row passes. */
+int vispec_set_total_token(vispec_ctx*, int total_token);
 /* Qwen2.5-VL: the rope_deltas cached by the prefill (modeling_qwen2_5_vl_kv.py) shift every decode position: tree verify and AR
    steps rotate at n + tree_pos + delta (utils.py:397-402; the three M-RoPE components are equal there, i.e. ordinary 1-D rotary).
    Call after vispec_begin_request (which resets it to 0). */

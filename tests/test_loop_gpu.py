@@ -451,3 +451,45 @@ def test_image_feature_count_mismatch_raises():
     feats = torch.zeros(7, T["D"], dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError, match="do not match"):
         sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=feats, max_new_tokens=4)
+
+
+@pytest.mark.parametrize("total_token", [40, 60, 33])
+def test_trees_larger_than_32_nodes(golden_dir, total_token):
+    """total_token in (32, 64] (spec_model_ours.py:179-201 autotunes up to 60): the verify pass runs its GEMMs in two 32-row
+    passes; token stream and accept lengths equal the oracle's with the same tree size, and greedy AR."""
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids = g["succ1_ids"]
+    sm, ot, od = build(51, 61, True, total_token=total_token)
+    od.cfg.total_token = total_token
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=36, log=True, return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=36, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert (new_token, idx, acc) == (o_new, o_idx, o_acc) and max(acc) >= 3
+    tok, pos, mask, ret = sm.engine.tree()
+    assert tok.shape[0] == total_token
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=out.shape[1] - len(ids) - 1)[0].cpu().numpy()
+    n = min(len(ar), out.shape[1])
+    np.testing.assert_array_equal(ar[:n], out[0].cpu().numpy()[:n])
+
+
+def test_total_tokens_setter_and_autotune(golden_dir):
+    """`model.spec_layer.total_tokens = T - 1` after construction (spec_model_ours.py:201) resizes the tree of later rounds; the
+    autotune picks one of the reference's candidates and leaves the model consistent with the oracle at that size."""
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids = g["succ0_ids"]
+    sm, ot, od = build(50, 60, True)
+    sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=8)  # graphs captured at 30 nodes
+    sm.spec_layer.total_tokens = 47
+    assert sm.engine.total_token == 48
+    od.cfg.total_token = 48
+    out, _, _, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=30, log=True, return_acceptance_len=True)
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=30, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc
+    best = sm.autotune_total_token(iters=3)
+    assert best in (40, 48, 50, 56, 60) and sm.spec_layer.total_tokens == best - 1 and sm.engine.total_token == best
+    od.cfg.total_token = best
+    out, _, _, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=20, log=True, return_acceptance_len=True)
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=20, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc

@@ -271,8 +271,8 @@ struct GemmOut {
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
 };
-static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
-                          int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
+static int launch_gemm_ex32(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
+                            int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
   if (M < 1 || M > 32) return fail("gemm_skinny: M must be in [1,32]");
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
@@ -337,6 +337,20 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   KCHK();
   prof_end(s);
   return 0;
+}
+
+// M in (32, 64] (total_token > 32, spec_model_ours.py:179-201 autotunes up to 60): two passes over 32-row halves, i.e. the weight is
+// streamed twice — correct and simple; the default tree (30 nodes) never takes this path.
+static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
+                          int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
+  if (M <= 32) return launch_gemm_ex32(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split, force_nw);
+  if (M > 64) return fail("gemm_skinny: M must be in [1,64]");
+  if (launch_gemm_ex32(ctx, s, X, ldx, P, bias, 32, N, K, epi, o, force_split, force_nw)) return -1;
+  GemmOut o2 = o;
+  if (o.Y) o2.Y = (bf16_t*)o.Y + (size_t)32 * o.ldy;
+  if (o.R) o2.R = (const bf16_t*)o.R + (size_t)32 * o.ldr;
+  if (o.normed) o2.normed = (bf16_t*)o.normed + (size_t)32 * o.ldn;
+  return launch_gemm_ex32(ctx, s, (const bf16_t*)X + (size_t)32 * ldx, ldx, P, bias, M - 32, N, K, epi, o2, force_split, force_nw);
 }
 
 // legacy-shaped helper used by most call sites
@@ -408,8 +422,16 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
     if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, M, N, K, EPI_NONE, wscale)) return -1;
     return launch_rope(s, qkv, M, H, H_kv, cosT, sinT, ps, kc, vc, s_max, 1);
   }
-  if (M < 1 || M > 32) return fail("gemm_qkv_rope: M must be in [1,32]");
+  if (M < 1 || M > 64) return fail("gemm_qkv_rope: M must be in [1,64]");
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
+  if (M > 32) {  // two 32-row passes (see launch_gemm_ex)
+    if (launch_qkv_rope(ctx, s, X, ldx, P, bias, wscale, qkv, 32, H, H_kv, K, cosT, sinT, ps, kc, vc, s_max)) return -1;
+    PosSpec p2 = ps;
+    if (ps.off) p2.off = ps.off + 32; else if (ps.row) p2.add = ps.add + 32;
+    p2.kv_add = ps.kv_add + 32;
+    return launch_qkv_rope(ctx, s, (const bf16_t*)X + (size_t)32 * ldx, ldx, P, bias, wscale, (bf16_t*)qkv + (size_t)32 * N, M - 32, H, H_kv, K,
+                           cosT, sinT, p2, kc, vc, s_max);
+  }
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT; re.ps = ps; re.kc = (bf16_t*)kc; re.vc = (bf16_t*)vc;
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
@@ -1019,6 +1041,16 @@ extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* to
 
 __global__ void set_rope_delta_kernel(DevState* st, int delta) {
   if (threadIdx.x == 0) st->rope_delta = delta;
+}
+// spec_model_ours.py:179-201 changes the tree size after construction (`model.spec_layer.total_tokens = total_token - 1`)
+extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
+  if (!ctx) return fail("null ctx");
+  const vispec_config& c = ctx->c;
+  if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
+  if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
+  ctx->c.total_token = total_token;
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar}) g->key = -1;  // captured launch sequences depend on the tree size
+  return 0;
 }
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
   if (!ctx) return fail("null ctx");

@@ -333,6 +333,10 @@ class Engine:
     def draft_round(self):
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
 
+    def set_total_token(self, total_token: int):
+        L.check(self.lib.vispec_set_total_token(self.h, int(total_token)))
+        self.total_token = int(total_token)
+
     def set_rope_delta(self, delta: int):
         L.check(self.lib.vispec_set_rope_delta(self.h, self._stream(), int(delta)))
 

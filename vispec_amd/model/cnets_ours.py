@@ -17,7 +17,7 @@ class Model:
     def __init__(self, config: DraftConfig, weights: DraftWeightsDev, total_tokens=30, depth=3, top_k=8, threshold=1.0, num_q=2):
         self.config, self.w = config, weights
         self.top_k = top_k
-        self.total_tokens = total_tokens - 1  # cnets_ours.py:733
+        self._total_tokens = total_tokens - 1  # cnets_ours.py:733
         self.depth = depth
         self.threshold = float(np.log(threshold))  # stored, unused by the reference too (:735)
         self.num_q = num_q
@@ -25,6 +25,17 @@ class Model:
         self.stable_kv = None
         self.tree_mask = None
         self.embed_tokens = type("E", (), {"weight": weights.t["embed"]})()
+
+    @property
+    def total_tokens(self):
+        return self._total_tokens
+
+    @total_tokens.setter
+    def total_tokens(self, v):
+        """`model.spec_layer.total_tokens = total_token - 1` (spec_model_ours.py:201) resizes the tree of later rounds."""
+        self._total_tokens = int(v)
+        if self.engine is not None:
+            self.engine.set_total_token(int(v) + 1)
 
     # cnets_ours.py:764-779 — the reference registers eye(k) / zeros(k) buffers; here the equivalents live in the ctx
     def init_tree(self):

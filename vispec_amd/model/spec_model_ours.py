@@ -68,12 +68,35 @@ class SpecModel:
         base_model_path = HF checkpoint dir of the target (config.json + *.safetensors [+ index]),
         spec_model_path = ViSpec draft dir (config.json + model.safetensors | pytorch_model.bin)."""
         from ..weights_io import load_draft_dir, load_target_dir  # imported lazily: safetensors is optional at import time
-        if total_token == -1:
-            raise NotImplementedError("total_token=-1 autotune (spec_model_ours.py:179-201) is not implemented; pass a value")
         tcfg, target_sd, tokenizer = load_target_dir(base_model_path)
         dcfg, draft_sd = load_draft_dir(spec_model_path, tcfg)
-        return cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=total_token, depth=depth, top_k=top_k,
-                                num_q=num_q, tokenizer=tokenizer)
+        model = cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=60 if total_token == -1 else total_token,
+                                 depth=depth, top_k=top_k, num_q=num_q, tokenizer=tokenizer)
+        if total_token == -1:
+            model.autotune_total_token()
+        return model
+
+    def autotune_total_token(self, cans=(40, 48, 50, 56, 60), x=(1, 1.05, 1.07, 1.1, 1.13), iters=20):
+        """spec_model_ours.py:179-201: time the target forward on `length` tokens for each candidate tree size, weight the times by
+        x, keep the cheapest.  Here the timed forward is the one the loop actually runs (the HIP verify pass on a `length`-node chain)."""
+        eng, times = self.engine, []
+        g = torch.Generator().manual_seed(0)
+        for length in cans:
+            self.spec_layer.total_tokens = length - 1
+            ids = torch.randint(0, max(2, self.vocab_size - 200), (length,), generator=g).numpy().astype(np.int32)
+            eng.begin_request(ids[:1], 8)
+            causal = np.array([(1 << (i + 1)) - 1 for i in range(length)], np.uint64)
+            eng.set_tree(ids, np.arange(length, dtype=np.int32), causal, np.zeros((1, 1), np.int32))
+            eng.target_forward()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(iters):
+                eng.target_forward()
+            torch.cuda.synchronize()
+            times.append((time.time() - t0) / x[len(times)])
+        best = cans[times.index(min(times))]
+        self.spec_layer.total_tokens = best - 1
+        return best
 
     # ------------------------------------------------------------------------------------------------
     def _first_token(self, orig: torch.Tensor) -> torch.Tensor:
