@@ -493,3 +493,58 @@ def test_total_tokens_setter_and_autotune(golden_dir):
     o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=20, max_pos=T["max_pos"])
     np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
     assert acc == o_acc
+
+
+def test_from_pretrained_real_checkpoint_dirs_with_hf_vision_tower(tmp_path):
+    """The whole drop-in surface on checkpoint DIRECTORIES: a (tiny, random) HF LLaVA-NeXT checkpoint written by transformers
+    itself + a ViSpec draft dir -> SpecModel.from_pretrained -> specgenerate(input_ids, pixel_values, image_sizes).  The vision
+    tower / projector / anyres packing run as HF modules on PyTorch-ROCm; the result equals the same model fed the
+    precomputed features, the oracle on the merged embeddings, and greedy AR."""
+    import json
+    transformers = pytest.importorskip("transformers")
+    from safetensors.torch import save_file
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaNextConfig, LlavaNextForConditionalGeneration
+    vc = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14)
+    tc = LlamaConfig(vocab_size=T["V"], hidden_size=T["D"], intermediate_size=T["I"], num_hidden_layers=T["NL"], num_attention_heads=T["H"],
+                     num_key_value_heads=T["H"], rms_norm_eps=1e-5, max_position_embeddings=T["max_pos"])
+    cfg = LlavaNextConfig(vision_config=vc, text_config=tc, image_grid_pinpoints=[[28, 56], [56, 28], [56, 56]], image_token_index=IMG_TOK)
+    torch.manual_seed(0)
+    hf = LlavaNextForConditionalGeneration(cfg).eval()
+    # give the language model the structured (successor) weights so that drafts get accepted
+    tw = synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"], seed=70, structured=True)
+    dw = synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"], seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    lm_sd = {k[len("model."):]: torch.from_numpy(v) for k, v in tw.items() if k.startswith("model.")}
+    hf.model.language_model.load_state_dict(lm_sd, strict=False)
+    hf.lm_head.weight.data.copy_(torch.from_numpy(tw["lm_head.weight"]))
+    tdir, ddir = tmp_path / "target", tmp_path / "draft"
+    hf.to(torch.bfloat16).save_pretrained(tdir)
+    ddir.mkdir()
+    save_file({k: torch.from_numpy(v).to(torch.bfloat16).contiguous() for k, v in dw.items()}, str(ddir / "model.safetensors"))
+    json.dump({"hidden_size": T["D"], "num_attention_heads": T["H"], "intermediate_size": T["I"], "vocab_size": T["V"],
+               "max_position_embeddings": T["max_pos"]}, open(ddir / "config.json", "w"))
+    sm = SpecModel.from_pretrained(base_model_path=str(tdir), spec_model_path=str(ddir), total_token=30, depth=3, top_k=8, num_q=2)
+    assert hasattr(sm.base_model.vision, "tower")
+    rng = np.random.default_rng(5)
+    pv = torch.randn(1, 5, 3, 28, 28, generator=torch.Generator().manual_seed(3))
+    sizes = torch.tensor([[50, 30]])
+    feats = sm.base_model.get_image_features(pv, sizes)  # HF modules, bf16, on the GPU
+    n_img = feats.shape[0]
+    ids = np.concatenate([rng.integers(3, 900, 6), np.full(n_img, IMG_TOK), rng.integers(3, 900, 9)])
+    t_ids = torch.from_numpy(ids)[None]
+    out, new_token, idx, acc = sm.specgenerate(t_ids, pixel_values=pv, image_sizes=sizes, max_new_tokens=24, log=True, return_acceptance_len=True)
+    out = out[0].cpu().numpy()
+    # (1) == the same model built from in-memory weights and fed the features directly
+    sm2, ot, od = build(70, 71, True, arch="LlavaNextForConditionalGeneration")
+    out2, _, _, acc2 = sm2.specgenerate(t_ids, pixel_values=feats, max_new_tokens=24, log=True, return_acceptance_len=True)
+    np.testing.assert_array_equal(out, out2[0].cpu().numpy())
+    assert acc == acc2 and max(acc) >= 2
+    # (2) == the oracle on the merged embeddings
+    emb = synth.bf16_grid(tw["model.embed_tokens.weight"])[np.where(ids == IMG_TOK, 0, ids)]
+    mask = ids == IMG_TOK
+    emb[mask] = feats.float().cpu().numpy()
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, inputs_embeds=emb, image_mask=mask, max_new_tokens=24, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out[len(ids):], o_out[len(ids):])
+    assert acc == o_acc
+    # (3) token-count mismatch is reported like the reference (:363-370)
+    with pytest.raises(ValueError, match="do not match"):
+        sm.specgenerate(torch.from_numpy(ids[:-1 - 9])[None], pixel_values=pv, image_sizes=sizes, max_new_tokens=4)

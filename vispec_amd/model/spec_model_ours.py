@@ -72,6 +72,14 @@ class SpecModel:
         dcfg, draft_sd = load_draft_dir(spec_model_path, tcfg)
         model = cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=60 if total_token == -1 else total_token,
                                  depth=depth, top_k=top_k, num_q=num_q, tokenizer=tokenizer)
+        if tcfg.architectures[0] != "LlamaForCausalLM":
+            # vision tower + projector of the checkpoint (PyTorch-ROCm, HF modules): SURVEY §8 A2
+            from .vision import HFVisionFrontEnd
+            try:
+                model.base_model.vision = HFVisionFrontEnd.from_dir(base_model_path, device, torch.bfloat16)
+            except (FileNotFoundError, ImportError) as e:
+                import warnings
+                warnings.warn(f"{base_model_path}: no usable vision weights ({e}); image prompts need precomputed features")
         if total_token == -1:
             model.autotune_total_token()
         return model
@@ -178,7 +186,7 @@ class SpecModel:
                                     (pixel_values_videos, vgrid, self.base_model.cfg.video_token_id)):
                     if pv is None:
                         continue
-                    feats = self.base_model.get_image_features(pv)
+                    feats = self.base_model.get_image_features(pv, image_grid_thw=g_)
                     mask = input_ids == tid
                     if int(mask.sum()) != feats.shape[0]:  # :403-406 / :435-438
                         raise ValueError(f"Image features and image tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")

@@ -104,10 +104,18 @@ class TargetLM:
     def get_input_embeddings(self):
         return lambda ids: F.embedding(ids, self.w.embed)
 
-    def get_image_features(self, pixel_values, image_sizes=None, **kw):
-        """Synthetic front-end: `pixel_values` is (n_image_tokens, seed) or a ready [N, D] feature tensor."""
-        if torch.is_tensor(pixel_values) and pixel_values.dim() == 2 and pixel_values.shape[-1] == self.cfg.hidden_size:
+    def get_image_features(self, pixel_values, image_sizes=None, image_grid_thw=None, **kw):
+        """-> packed image features [n_image_tokens, D] in prompt order.
+        A ready [N, D] tensor is passed through (bench / tests keep the request's features resident in HBM); with a real
+        checkpoint (`self.vision` is an HFVisionFrontEnd) `pixel_values` are the processor's pixels and the HF vision tower +
+        projector (+ anyres packing) run on PyTorch-ROCm, as in the reference (spec_model_ours.py:341-356); the synthetic
+        front-end takes (n_image_tokens, seed)."""
+        if (torch.is_tensor(pixel_values) and pixel_values.dim() == 2 and pixel_values.shape[-1] == self.cfg.hidden_size
+                and not hasattr(self.vision, "tower")):
             return pixel_values.to(self.device, self.dtype)
+        if hasattr(self.vision, "tower"):
+            kw = {k: v for k, v in kw.items() if k in ("vision_feature_layer", "vision_feature_select_strategy") and v is not None}
+            return self.vision.features(pixel_values, image_sizes=image_sizes, image_grid_thw=image_grid_thw, **kw).to(self.device, self.dtype)
         n, seed = pixel_values
         return self.vision.features(int(n), int(seed), self.device, self.dtype)
 

@@ -1,0 +1,131 @@
+"""Vision front-end of the target VLM for REAL checkpoints: vision tower + multimodal projector
+(+ LLaVA-NeXT anyres packing with `image_newline`, or Qwen2.5-VL's `visual` tower).  It stays on PyTorch-ROCm — HF's own
+modules, instantiated from the checkpoint's config and filled from its safetensors — exactly as the reference delegates to
+`base_model.get_image_features` / `pack_image_features` (spec_model_ours.py:341-356, 395-401).  Only the vision side is
+built: the language model's 7-13 B parameters are never instantiated twice.
+
+Local directories only.  Without such a checkpoint `TargetLM` falls back to `SyntheticVision` (bench / tests)."""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+from torch import nn
+
+_VISION_PREFIXES = {
+    "tower": ("model.vision_tower.", "vision_tower."),
+    "proj": ("model.multi_modal_projector.", "multi_modal_projector."),
+    "newline": ("model.image_newline", "image_newline"),
+    "visual": ("model.visual.", "visual."),
+}
+
+
+def _iter_tensors(path):
+    from safetensors import safe_open
+    idx = os.path.join(path, "model.safetensors.index.json")
+    if os.path.exists(idx):
+        wm = json.load(open(idx))["weight_map"]
+        files = sorted({f for k, f in wm.items() if "vision" in k or "visual" in k or "projector" in k or "image_newline" in k})
+    else:
+        files = [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
+    for f in files:
+        with safe_open(os.path.join(path, f), framework="pt", device="cpu") as sf:
+            for k in sf.keys():
+                if "vision" in k or "visual" in k or "projector" in k or "image_newline" in k:
+                    yield k, sf.get_tensor(k)
+
+
+def _strip(key, prefixes):
+    for p in prefixes:
+        if key.startswith(p):
+            return key[len(p):]
+    return None
+
+
+class HFVisionFrontEnd:
+    """`features(pixel_values, image_sizes=None, image_grid_thw=None)` -> [n_image_tokens, D_text] in prompt order."""
+
+    def __init__(self, arch: str, config, tower: nn.Module, projector: Optional[nn.Module], image_newline: Optional[torch.Tensor]):
+        self.arch, self.config, self.tower, self.projector, self.image_newline = arch, config, tower, projector, image_newline
+
+    # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_dir(cls, path: str, device="cpu", dtype=torch.bfloat16) -> "HFVisionFrontEnd":
+        from transformers import AutoConfig, AutoModel
+        config = AutoConfig.from_pretrained(path, local_files_only=True)
+        arch = (config.architectures or ["?"])[0]
+        buckets = {k: {} for k in _VISION_PREFIXES}
+        for k, v in _iter_tensors(path):
+            for name, pre in _VISION_PREFIXES.items():
+                s = _strip(k, pre)
+                if s is not None:
+                    buckets[name][s] = v
+                    break
+        if arch in ("LlavaNextForConditionalGeneration", "LlavaForConditionalGeneration"):
+            if arch == "LlavaNextForConditionalGeneration":
+                from transformers.models.llava_next.modeling_llava_next import LlavaNextMultiModalProjector as Proj
+            else:
+                from transformers.models.llava.modeling_llava import LlavaMultiModalProjector as Proj
+            tower = AutoModel.from_config(config.vision_config)
+            proj = Proj(config)
+            _load(tower, buckets["tower"], "vision_tower")
+            _load(proj, buckets["proj"], "multi_modal_projector")
+            newline = buckets["newline"].get("", None)
+            if arch == "LlavaNextForConditionalGeneration" and newline is None:
+                raise FileNotFoundError(f"{path}: no image_newline tensor in the checkpoint")
+            fe = cls(arch, config, tower.to(device, dtype).eval(), proj.to(device, dtype).eval(),
+                     None if newline is None else newline.to(device, dtype))
+        elif arch == "Qwen2_5_VLForConditionalGeneration":
+            from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel as Visual
+            visual = Visual._from_config(config.vision_config)
+            _load(visual, buckets["visual"], "visual")
+            fe = cls(arch, config, visual.to(device, dtype).eval(), None, None)
+        else:
+            raise NotImplementedError(f"no vision front-end for {arch}")
+        return fe
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def features(self, pixel_values, image_sizes=None, image_grid_thw=None, vision_feature_layer=None,
+                 vision_feature_select_strategy=None) -> torch.Tensor:
+        c = self.config
+        if self.arch == "Qwen2_5_VLForConditionalGeneration":
+            dev = next(self.tower.parameters())
+            out = self.tower(pixel_values.to(dev.device, dev.dtype), grid_thw=image_grid_thw.to(dev.device))
+            out = getattr(out, "pooler_output", out)  # transformers 5.x wraps the merged tokens
+            return out if torch.is_tensor(out) else torch.cat(list(out), dim=0)
+        layer = c.vision_feature_layer if vision_feature_layer is None else vision_feature_layer
+        strategy = c.vision_feature_select_strategy if vision_feature_select_strategy is None else vision_feature_select_strategy
+        dev = next(self.tower.parameters())
+        if self.arch == "LlavaNextForConditionalGeneration":
+            from transformers.models.llava_next import modeling_llava_next as M
+            n_patches = [M.image_size_to_num_patches(image_size=s, grid_pinpoints=c.image_grid_pinpoints, patch_size=c.vision_config.image_size)
+                         for s in (image_sizes.tolist() if torch.is_tensor(image_sizes) else image_sizes)]
+            if pixel_values.dim() == 5:  # [images, max_patches, C, H, W] padded -> the real patches of every image
+                pixel_values = torch.cat([pv[:n] for pv, n in zip(pixel_values, n_patches)], dim=0)
+            elif pixel_values.dim() != 4:
+                raise ValueError(f"pixel_values of shape {pixel_values.shape}, expect to be of 4 or 5 dimensions")
+        hs = self.tower(pixel_values.to(dev.device, dev.dtype), output_hidden_states=True, return_dict=True).hidden_states
+        sel = hs[layer] if isinstance(layer, int) else torch.cat([hs[i] for i in layer], dim=-1)
+        if strategy == "default":
+            sel = sel[:, 1:]  # drop CLS
+        feats = self.projector(sel)
+        if self.arch == "LlavaForConditionalGeneration":
+            return feats.reshape(-1, feats.shape[-1])
+        from transformers.models.llava_next.modeling_llava_next import LlavaNextModel
+        shim = SimpleNamespace(config=c)
+        packed, _ = LlavaNextModel.pack_image_features(shim, torch.split(feats, n_patches, dim=0), image_sizes,
+                                                       vision_feature_select_strategy=strategy, image_newline=self.image_newline)
+        return packed if torch.is_tensor(packed) else torch.cat(list(packed), dim=0)  # 4.x concatenates, 5.x returns the list
+
+
+def _load(module: nn.Module, sd: dict, what: str):
+    if not sd:
+        raise FileNotFoundError(f"no {what} tensors in the checkpoint")
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k and "inv_freq" not in k]
+    if missing or unexpected:
+        raise RuntimeError(f"{what}: missing {missing[:4]} unexpected {list(unexpected)[:4]}")

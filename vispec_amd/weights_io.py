@@ -34,12 +34,22 @@ def load_target_dir(path):
     tc = cfg.get("text_config", cfg)
     arch = cfg.get("architectures", ["LlamaForCausalLM"])[0]
     H = tc.get("num_attention_heads", 32)
+    eos = tc.get("eos_token_id", cfg.get("eos_token_id", 2))
+    kw = {}
+    if arch == "Qwen2_5_VLForConditionalGeneration":  # modeling_qwen2_5_vl_kv.py: q/k/v bias, SDPA scores, multimodal rotary sections
+        rs = tc.get("rope_scaling") or tc.get("rope_parameters") or cfg.get("rope_scaling") or {}
+        kw = dict(qkv_bias=True, attn_impl="sdpa", mrope_section=tuple(rs.get("mrope_section", (16, 24, 24))),
+                  image_token_index=cfg.get("image_token_id", 151655), video_token_id=cfg.get("video_token_id", 151656),
+                  max_position_embeddings=4096)  # kv_cache.py:88-119 sizes Qwen's cache at 4096 rows
+        rope_theta = tc.get("rope_theta") or rs.get("rope_theta") or 1e6
+    else:
+        kw = dict(image_token_index=cfg.get("image_token_index", 32000))
+        rope_theta = tc.get("rope_theta") or (tc.get("rope_parameters") or {}).get("rope_theta") or 10000.0
     tcfg = TargetConfig(
         hidden_size=tc.get("hidden_size", 4096), num_heads=H, num_kv_heads=tc.get("num_key_value_heads", H),
         intermediate_size=tc.get("intermediate_size", 11008), vocab_size=tc.get("vocab_size", 32064),
         num_layers=tc.get("num_hidden_layers", 32), rms_norm_eps=tc.get("rms_norm_eps", 1e-5),
-        rope_theta=tc.get("rope_theta", 10000.0), architectures=(arch,), image_token_index=cfg.get("image_token_index", 32000),
-        eos_token_id=tc.get("eos_token_id", 2) if isinstance(tc.get("eos_token_id", 2), int) else 2)
+        rope_theta=float(rope_theta), architectures=(arch,), eos_token_id=eos if isinstance(eos, int) else 2, **kw)
     sd = {}
     for k, v in _open_all(path):
         for pre in ("language_model.model.", "model.language_model."):
@@ -49,7 +59,7 @@ def load_target_dir(path):
         else:
             if k in ("language_model.lm_head.weight", "lm_head.weight"):
                 sd["lm_head.weight"] = v
-            elif k.startswith("model.") and "vision" not in k and "projector" not in k:
+            elif k.startswith("model.") and "vision" not in k and "visual" not in k and "projector" not in k and "image_newline" not in k:
                 sd[k] = v
     if "lm_head.weight" not in sd:
         sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
