@@ -548,3 +548,27 @@ def test_from_pretrained_real_checkpoint_dirs_with_hf_vision_tower(tmp_path):
     # (3) token-count mismatch is reported like the reference (:363-370)
     with pytest.raises(ValueError, match="do not match"):
         sm.specgenerate(torch.from_numpy(ids[:-1 - 9])[None], pixel_values=pv, image_sizes=sizes, max_new_tokens=4)
+
+
+def test_evaluation_harness_jsonl_and_speed(tmp_path, golden_dir):
+    """evaluation harness (gen_spec_answer_coco_caption.py:160-285, speed.py:56-97): JSONL record fields, one line per request,
+    speed-up = mean tokens/s (spec) / mean tokens/s (AR), tau = mean accept length; spec and AR answers carry the same tokens."""
+    import json
+    from vispec_amd.evaluation.harness import get_model_answers, speed
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    sm, _, _ = build(50, 60, True)
+    reqs = [(f"q{i}", torch.from_numpy(g[f"succ{i % 2}_ids"])[None].cuda(), {}) for i in range(3)]
+    fs, fb = str(tmp_path / "spec.jsonl"), str(tmp_path / "ar.jsonl")
+    get_model_answers(sm, reqs, fs, max_new_tokens=24, warmup=1)
+    get_model_answers(sm, reqs, fb, max_new_tokens=24, warmup=1, baseline=True)
+    recs = [json.loads(l) for l in open(fs)]
+    base = [json.loads(l) for l in open(fb)]
+    assert [r["question_id"] for r in recs] == ["q0", "q1", "q2"] and len(base) == 3
+    for r, b in zip(recs, base):
+        c, cb = r["choices"][0], b["choices"][0]
+        assert set(c) >= {"index", "turns", "idxs", "new_tokens", "wall_time", "acceptance_length"}
+        assert c["new_tokens"][0] > 24 and len(c["acceptance_length"]) == c["idxs"][0] + 1 and c["wall_time"][0] > 0
+        n = min(len(c["turns"][0]), len(cb["turns"][0]))
+        assert c["turns"][0][:n] == cb["turns"][0][:n]  # greedy invariance through the harness
+    s = speed(fs, fb)
+    assert s["speedup"] > 0 and 0 < s["tau"] <= 4 and s["spec_tokens_per_s"] > 0

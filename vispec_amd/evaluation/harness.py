@@ -22,10 +22,10 @@ def get_model_answers(model, requests: Iterable, answer_file: str, model_id: str
         if baseline:
             run(ids, kw)
         else:
-            model.specgenerate(ids, temperature=temperature, log=True, max_new_tokens=max_new_tokens, **kw)
+            model.specgenerate(ids, temperature=temperature, log=True, max_new_tokens=max_new_tokens, seed=0, **kw)
     with open(answer_file, "a") as fout:
-        for qid, ids, kw in requests:
-            torch.manual_seed(0)
+        for i, (qid, ids, kw) in enumerate(requests):
+            torch.manual_seed(i)  # :212 — the device-side sampler takes the same per-sample seed
             torch.cuda.synchronize()
             t0 = time.time()
             if baseline:
@@ -33,7 +33,7 @@ def get_model_answers(model, requests: Iterable, answer_file: str, model_id: str
                 new_token, idx, acc = out.shape[1] - ids.shape[1], out.shape[1] - ids.shape[1], []
             else:
                 out, new_token, idx, acc = model.specgenerate(ids, temperature=temperature, log=True, return_acceptance_len=True,
-                                                              max_new_tokens=max_new_tokens, **kw)
+                                                              max_new_tokens=max_new_tokens, seed=i, **kw)
             torch.cuda.synchronize()
             wall = time.time() - t0
             rec = {"question_id": qid, "model_id": model_id, "tstamp": time.time(),
