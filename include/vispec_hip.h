@@ -173,6 +173,10 @@ int vispec_set_total_token(vispec_ctx*, int total_token);
    steps rotate at n + tree_pos + delta (utils.py:397-402; the three M-RoPE components are equal there, i.e. ordinary 1-D rotary).
    Call after vispec_begin_request (which resets it to 0). */
 int vispec_set_rope_delta(vispec_ctx*, void* stream, int delta);
+/* TopKLogitsWarper (utils.py:52-53) applied after the temperature on every sampled / verified distribution; 0 = off.  Call after
+   vispec_set_sampling, which resets it.  (TopPLogitsWarper is not offered: HF's implementation raises on the 3-D tree logits the
+   reference hands it in evaluate_posterior, so the reference cannot run it either.) */
+int vispec_set_top_k(vispec_ctx*, int top_k);
 /* Sampling (temperature > 0, utils.py:453-493 + multinomial at :288,:551): enable with a temperature and a seed; verify_accept then
    runs the sequential-rejection accept and draws the next token on the device with counter-based uniforms (distributionally
    equivalent to the reference's torch RNG, bit-reproducible against the oracle).  temperature <= 1e-5 restores greedy. */

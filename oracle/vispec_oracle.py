@@ -565,9 +565,15 @@ def uniform_hash(seed: int, a: int, b: int, c: int) -> float:
     return (z >> 40) / float(1 << 24)
 
 
-def softmax_T(row: np.ndarray, temperature: float) -> np.ndarray:
-    """softmax(TemperatureLogitsWarper(row)) in fp32 — utils.py:454-455 with the default processor list of exp.sh (T only)."""
+def softmax_T(row: np.ndarray, temperature: float, top_k: int = 0) -> np.ndarray:
+    """softmax(logits_processor(row)) in fp32 — utils.py:454-455 with the processor list of utils.py:39-55:
+    TemperatureLogitsWarper, then TopKLogitsWarper when top_k > 0 (scores below the k-th largest become -inf; ties with the
+    k-th value survive, as in HF).  TopP is not restated: HF's TopPLogitsWarper scatters along dim 1 and raises on the 3-D tree
+    logits the reference hands it (RuntimeError: index out of bounds), i.e. the reference itself cannot run it."""
     x = np.asarray(row, np.float32) / np.float32(temperature)
+    if top_k and top_k > 0:
+        kth = np.sort(x)[::-1][min(int(top_k), x.shape[0]) - 1]
+        x = np.where(x < kth, np.float32(-np.inf), x)
     e = np.exp(x - x.max())
     return (e / e.sum(dtype=np.float32)).astype(np.float32)
 
@@ -579,11 +585,11 @@ def multinomial_inverse_cdf(p: np.ndarray, u: float) -> int:
     return int(min(np.searchsorted(c, u * c[-1], side="right"), len(p) - 1))
 
 
-def evaluate_posterior_sampling(logits: np.ndarray, candidates: np.ndarray, temperature: float, uni):
+def evaluate_posterior_sampling(logits: np.ndarray, candidates: np.ndarray, temperature: float, uni, top_k: int = 0):
     """utils.py:453-493 — sequential rejection over the tree's children.  `uni(j, i)` supplies uni_dist[j, i]
     (the reference draws torch.rand_like(candidates)).  -> (best, accept_length, sample_p [V])."""
     n_leaf, m = candidates.shape
-    logits_p = np.stack([[softmax_T(logits[j, c], temperature) for c in range(m)] for j in range(n_leaf)])
+    logits_p = np.stack([[softmax_T(logits[j, c], temperature, top_k) for c in range(m)] for j in range(n_leaf)])
     accept_length = 1
     accept_cand = candidates[0].copy()
     best = 0
@@ -656,7 +662,7 @@ def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_
 
 def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embeds=None, image_mask=None,
                  max_new_tokens=512, max_length=2048, eos_token_id=2, max_pos=None, scripted_accept=None, position_ids=None,
-                 rope_delta=0, temperature=0.0, seed=0):
+                 rope_delta=0, temperature=0.0, seed=0, top_k=0):
     """SpecModel.specgenerate, temperature 0 (spec_model_ours.py:247-582).
     -> (input_ids, new_token, idx, accept_lengths).  `scripted_accept` (bench-only knob, never used by
     parity tests) is None."""
@@ -675,6 +681,8 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
     sampling = temperature > 1e-5  # spec_model_ours.py:272-277
     if sampling:  # utils.py:284-288
         x = logits[-1] / np.float32(temperature)
+        if top_k and top_k > 0:
+            x = np.where(x < np.sort(x)[::-1][min(int(top_k), x.shape[0]) - 1], np.float32(-np.inf), x)
         token = multinomial_inverse_cdf(np.exp(x - x.max()), uniform_hash(seed, 0xFFFF, 0, 0))
     else:
         token = argmax_first(logits[-1])  # :290
@@ -690,7 +698,8 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
         candidates = ext[st.retrieve_indices]  # :504
         if sampling:
             rnd = len(st.accept_lengths)
-            best, acc, sample_p = evaluate_posterior_sampling(logits, candidates, temperature, lambda j, i, r=rnd: uniform_hash(seed, r, j, i))
+            best, acc, sample_p = evaluate_posterior_sampling(logits, candidates, temperature, lambda j, i, r=rnd: uniform_hash(seed, r, j, i),
+                                                              top_k)
             su = uniform_hash(seed, rnd, 255, 255)
         else:
             best, acc, sample_p = evaluate_posterior_greedy(logits, candidates)  # :505-507

@@ -265,8 +265,8 @@ def g7_posterior_sampling():
     V = 40
     n = 0
     real_rand_like = torch.rand_like
-    for T_ in (1.0, 0.7, 1.5):
-        lp = utils.prepare_logits_processor(temperature=T_)
+    for T_, K_ in ((1.0, 0), (0.7, 0), (1.5, 0), (1.0, 5), (0.8, 3), (1.3, 12)):  # K_ > 0: + TopKLogitsWarper (utils.py:52-53)
+        lp = utils.prepare_logits_processor(temperature=T_, top_k=K_)
         for rep in range(6):
             n_leaf, m = int(rng.integers(2, 9)), int(rng.integers(2, 6))
             # leaves of a small prefix tree: rows share prefixes so that is_eq / the candidate set logic is exercised
@@ -303,7 +303,7 @@ def g7_posterior_sampling():
                 b, a, p_ = utils.evaluate_posterior(t(logits), torch.from_numpy(cand), lp)
             finally:
                 torch.rand_like = real_rand_like
-            out[f"logits{n}"], out[f"cand{n}"], out[f"u{n}"], out[f"T{n}"] = logits, cand, u, np.float32(T_)
+            out[f"logits{n}"], out[f"cand{n}"], out[f"u{n}"], out[f"T{n}"], out[f"K{n}"] = logits, cand, u, np.float32(T_), np.int64(K_)
             out[f"best{n}"], out[f"acc{n}"], out[f"p{n}"] = np.int64(int(b)), np.int64(int(a)), f32(p_)
             n += 1
     out["n"] = np.int64(n)

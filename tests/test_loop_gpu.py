@@ -572,3 +572,28 @@ def test_evaluation_harness_jsonl_and_speed(tmp_path, golden_dir):
         assert c["turns"][0][:n] == cb["turns"][0][:n]  # greedy invariance through the harness
     s = speed(fs, fb)
     assert s["speedup"] > 0 and 0 < s["tau"] <= 4 and s["spec_tokens_per_s"] > 0
+
+
+@pytest.mark.parametrize("temperature,top_k,seed", [(6.0, 4, 1), (3.0, 1, 2), (8.0, 20, 5), (1.0, 50, 7)])
+def test_sampling_with_top_k_warper(temperature, top_k, seed):
+    """prepare_logits_processor(temperature, top_k) (utils.py:39-55): TopKLogitsWarper after the temperature on the first token,
+    on every verified distribution and on the bonus token — device == oracle with shared uniforms (the oracle's warped branch is
+    pinned against the reference in g7).  top_k = 1 degenerates to greedy; 0 < top_p < 1 is refused (the reference raises too)."""
+    sm, ot, od = build(50, 60, True)
+    ids = np.random.default_rng(300 + seed).integers(3, T["V"], size=16)
+    t_ids = torch.from_numpy(ids)[None]
+    out, new_token, idx, acc = sm.specgenerate(t_ids, temperature=temperature, top_k=top_k, seed=seed, max_new_tokens=28, log=True,
+                                               return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=28, max_pos=T["max_pos"], temperature=temperature, seed=seed,
+                                                 top_k=top_k)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc and new_token == o_new
+    greedy = sm.specgenerate(t_ids, temperature=0.0, max_new_tokens=28)[0].cpu().numpy()
+    n = min(len(greedy), len(o_out))
+    if top_k == 1:
+        np.testing.assert_array_equal(o_out[:n], greedy[:n])  # only the arg-max survives the warper
+    elif temperature >= 6.0:
+        unwarped = vo.specgenerate(ot, od, ids, max_new_tokens=28, max_pos=T["max_pos"], temperature=temperature, seed=seed)[0]
+        assert not np.array_equal(unwarped[: len(o_out)], o_out[: len(unwarped)])  # the warper changes the hot-temperature stream
+    with pytest.raises(NotImplementedError):
+        sm.specgenerate(t_ids, temperature=1.0, top_p=0.9, max_new_tokens=4)

@@ -215,11 +215,14 @@ def test_g7_evaluate_posterior_sampling(golden_dir):
     accs = []
     for i in range(int(g["n"])):
         u = g[f"u{i}"]
-        b, a, p = vo.evaluate_posterior_sampling(g[f"logits{i}"], g[f"cand{i}"], float(g[f"T{i}"]), lambda j, c: u[j, c])
+        K = int(g[f"K{i}"])
+        b, a, p = vo.evaluate_posterior_sampling(g[f"logits{i}"], g[f"cand{i}"], float(g[f"T{i}"]), lambda j, c: u[j, c], top_k=K)
         assert (b, a) == (int(g[f"best{i}"]), int(g[f"acc{i}"])), i
         np.testing.assert_allclose(p, g[f"p{i}"], rtol=2e-5, atol=1e-7)
-        accs.append(a)
-    assert 0 in accs and max(accs) >= 2
+        if K:  # TopKLogitsWarper: at most K tokens keep probability mass
+            assert 0 < (p > 0).sum() <= K
+        accs.append((a, K))
+    assert 0 in [a for a, _ in accs] and max(a for a, _ in accs) >= 2 and max(a for a, K in accs if K) >= 1 and int(g["n"]) == 36
     # the explicit-uniform multinomial is a proper inverse CDF
     p = np.array([0.1, 0.0, 0.6, 0.3])
     assert [vo.multinomial_inverse_cdf(p, u) for u in (0.0, 0.0999, 0.1, 0.69, 0.7, 0.9999)] == [0, 0, 2, 2, 3, 3]

@@ -1,0 +1,40 @@
+"""Do concurrent streams hide the per-launch ramp/tail of the skinny GEMM?  Aggregate TB/s of the LLaVA-7B layer's four GEMM shapes
+issued back to back on 1 / 2 / 3 / 4 streams (each stream walks its own rotation of weight buffers)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vispec_amd import lib as L, synth
+from vispec_amd.engine import DraftConfig, DraftWeightsDev, Engine, TargetConfig, TargetWeights, pack_weight
+lib = L.load(); dev = torch.device("cuda:0"); T = synth.TINY
+tcfg = TargetConfig(T["D"], T["H"], T["H"], T["I"], T["V"], T["NL"], T["max_pos"]); dcfg = DraftConfig(T["D"], T["H"], T["I"], T["V"], T["max_pos"])
+mk = lambda: Engine(tcfg, dcfg, TargetWeights.from_state_dict(tcfg, synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"]), dev),
+                    DraftWeightsDev.from_state_dict(dcfg, synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"]), 2, dev))
+NS = 4
+engs = [mk() for _ in range(NS)]  # one ctx (split-K workspace) per stream
+p = lambda t: C.c_void_p(t.data_ptr())
+M = 30
+SHAPES = [("qkv", 12288, 4096, 0), ("o_proj", 4096, 4096, 0), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 0)]
+NB = 6
+W = {n: [pack_weight((torch.randn((2 if e == 2 else 1) * N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(NB)] for n, N, K, e in SHAPES}
+X = {K: torch.randn(M, K, device=dev, dtype=torch.bfloat16) for K in (4096, 11008)}
+Y = [{n: torch.empty(M, N, device=dev, dtype=torch.bfloat16) for n, N, K, e in SHAPES} for _ in range(NS)]
+streams = [torch.cuda.Stream(dev) for _ in range(NS)]
+bytes_layer = sum((2 if e == 2 else 1) * N * K * 2 for n, N, K, e in SHAPES)
+def layer(si, it):
+    s = C.c_void_p(streams[si].cuda_stream)
+    for n, N, K, e in SHAPES:
+        L.check(lib.vispec_gemm_skinny(engs[si].h, s, p(X[K]), K, p(W[n][(it * NS + si) % NB]), None, p(Y[si][n]), N, None, 0, M, N, K, e))
+for ns in (1, 2, 3, 4):
+    for it in range(3):
+        for si in range(ns): layer(si, it)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 40
+    e0.record()
+    for si in range(ns): streams[si].wait_event(e0)
+    for it in range(iters):
+        for si in range(ns): layer(si, it)
+    for si in range(ns): torch.cuda.current_stream().wait_stream(streams[si])
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    print(f"{ns} stream(s): {us / iters / ns:7.1f} us per layer-equivalent ({bytes_layer / 1e6:.0f} MB) -> aggregate {bytes_layer * iters * ns / us / 1e6:5.2f} TB/s", flush=True)

@@ -284,8 +284,44 @@ __device__ __forceinline__ float vs_uniform(unsigned long long seed, unsigned a,
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-// block-wide (1024 threads) max and sum-exp of row/T  (softmax(TemperatureLogitsWarper(row)), fp32)
-__device__ __forceinline__ void vs_row_stats(const bf16_t* __restrict__ row, int V, float T, float* s_f, float& m, float& Z) {
+// TopKLogitsWarper threshold (utils.py:52-53): the k-th largest logit of the row; scores < thr are filtered, ties with thr survive.
+// Logits are bf16, so the k-th value is found exactly with two 256-bin histogram passes over an order-preserving 16-bit key.
+__device__ __forceinline__ unsigned vs_key(bf16_t b) { return (b & 0x8000u) ? (~(unsigned)b & 0xFFFFu) : ((unsigned)b | 0x8000u); }
+__device__ __forceinline__ float vs_topk_threshold(const bf16_t* __restrict__ row, int V, int top_k, int* s_hist) {
+  const int tid = threadIdx.x;
+  if (top_k <= 0 || top_k >= V) return NEG_INF;
+  int want = top_k, hb = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    for (int v = tid; v < V; v += 1024) {
+      const unsigned k = vs_key(row[v]);
+      if (pass == 0) atomicAdd(&s_hist[k >> 8], 1);
+      else if ((int)(k >> 8) == hb) atomicAdd(&s_hist[k & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int b = 255, acc = 0;
+      while (b > 0 && acc + s_hist[b] < want) { acc += s_hist[b]; --b; }
+      s_hist[256] = b;
+      s_hist[257] = want - acc;
+    }
+    __syncthreads();
+    const int b = s_hist[256];
+    want = s_hist[257];
+    __syncthreads();
+    if (pass == 0) hb = b;
+    else {
+      const unsigned key = ((unsigned)hb << 8) | (unsigned)b;
+      const bf16_t bits = (key & 0x8000u) ? (bf16_t)(key & 0x7FFFu) : (bf16_t)(~key & 0xFFFFu);
+      return bf2f(bits);
+    }
+  }
+  return NEG_INF;
+}
+
+// block-wide (1024 threads) max and sum-exp of logits_processor(row) = row/T restricted to row >= thr  (softmax in fp32)
+__device__ __forceinline__ void vs_row_stats(const bf16_t* __restrict__ row, int V, float T, float thr, float* s_f, float& m, float& Z) {
   const int tid = threadIdx.x;
   float mx = NEG_INF;
   for (int v = tid; v < V; v += 1024) mx = fmaxf(mx, bf2f(row[v]) / T);
@@ -296,7 +332,10 @@ __device__ __forceinline__ void vs_row_stats(const bf16_t* __restrict__ row, int
   for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_f[w]);
   __syncthreads();
   float se = 0.f;
-  for (int v = tid; v < V; v += 1024) se += expf(bf2f(row[v]) / T - mx);
+  for (int v = tid; v < V; v += 1024) {
+    const float x = bf2f(row[v]);
+    if (x >= thr) se += expf(x / T - mx);
+  }
   se = wave_sum(se);
   if ((tid & 63) == 0) s_f[tid >> 6] = se;
   __syncthreads();
@@ -308,14 +347,14 @@ __device__ __forceinline__ void vs_row_stats(const bf16_t* __restrict__ row, int
 }
 
 // one multinomial draw by inverse CDF over weights exp(row/T - m) with `nrem` removed tokens (torch.multinomial stand-in)
-__device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, int V, float T, float m, const int* removed, int nrem, float u,
-                                              double* s_d, int* s_i) {
+__device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, int V, float T, float m, float thr, const int* removed, int nrem,
+                                              float u, double* s_d, int* s_i) {
   const int tid = threadIdx.x;
   const int chunk = (V + 1023) / 1024;
   const int lo = tid * chunk, hi = min(V, lo + chunk);
   double loc = 0.0;
   for (int v = lo; v < hi; ++v) {
-    bool rem = false;
+    bool rem = bf2f(row[v]) < thr;
     for (int r = 0; r < nrem; ++r) rem |= removed[r] == v;
     if (!rem) loc += (double)expf(bf2f(row[v]) / T - m);
   }
@@ -337,7 +376,7 @@ __device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, in
     double run = s_d[tid];
     int pick = min(V, hi) - 1;
     for (int v = lo; v < hi; ++v) {
-      bool rem = false;
+      bool rem = bf2f(row[v]) < thr;
       for (int r = 0; r < nrem; ++r) rem |= removed[r] == v;
       if (!rem) run += (double)expf(bf2f(row[v]) / T - m);
       if (run > target) { pick = v; break; }
@@ -349,19 +388,22 @@ __device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, in
 }
 
 // first token: token = multinomial(softmax(lp(orig[:, -1])))   (utils.py:284-288)
-__global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restrict__ row, int V, float T, unsigned long long seed, int* out) {
+__global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restrict__ row, int V, float T, int top_k, unsigned long long seed,
+                                                          int* out) {
   __shared__ float s_f[16];
   __shared__ double s_d[1025];
   __shared__ int s_i[2];
+  __shared__ int s_hist[258];
   float m, Z;
-  vs_row_stats(row, V, T, s_f, m, Z);
-  const int tok = vs_multinomial(row, V, T, m, nullptr, 0, vs_uniform(seed, 0xFFFFu, 0u, 0u), s_d, s_i);
+  const float thr = vs_topk_threshold(row, V, top_k, s_hist);
+  vs_row_stats(row, V, T, thr, s_f, m, Z);
+  const int tok = vs_multinomial(row, V, T, m, thr, nullptr, 0, vs_uniform(seed, 0xFFFFu, 0u, 0u), s_d, s_i);
   if (threadIdx.x == 0) out[0] = tok;
 }
 
 // evaluate_posterior (sampling) + the integer half of update_inference_inputs; logits [T, V] bf16 of the verify forward
 __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
-                                                                    unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
+                                                                    int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
                                                                     int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
                                                                     int* __restrict__ draft_ids) {
   __shared__ int cand[TREE_MAX_T][TREE_RET_W];
@@ -372,6 +414,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   __shared__ float s_f[16];
   __shared__ double s_d[1025];
   __shared__ int s_i[2];
+  __shared__ int s_hist[258];
   const int tid = threadIdx.x;
   const int nl = st->n_leaf, md = st->max_depth, round = st->rounds;
   if (tid < nl)
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   __syncthreads();
   if (tid == 0) accept_cand[0] = cand[0][0];
   __syncthreads();
-  float last_m = 0.f;
+  float last_m = 0.f, last_thr = NEG_INF;
   int last_node = 0;
   for (int i = 1; i < md; ++i) {
     const int al = sh[0];
@@ -405,8 +448,10 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
     const int node = tb.retrieve[sh[4] * TREE_RET_W + (i - 1)];
     const bf16_t* row = logits + (size_t)node * V;
     float m, Z;
-    vs_row_stats(row, V, T, s_f, m, Z);
+    const float thr = vs_topk_threshold(row, V, top_k, s_hist);
+    vs_row_stats(row, V, T, thr, s_f, m, Z);
     last_m = m;
+    last_thr = thr;
     last_node = node;
     if (tid == 0) {
       float rm = 0.f;
@@ -420,7 +465,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
         for (int q = 0; q < nseen; ++q) dup |= seen[q] == x;
         if (dup) continue;
         seen[nseen++] = x;
-        const float p = expf(bf2f(row[x]) / T - m) / Z;
+        const float p = bf2f(row[x]) >= thr ? expf(bf2f(row[x]) / T - m) / Z : 0.f;
         const float px = p / (1.0f - rm);
         if (vs_uniform(seed, (unsigned)round, (unsigned)j, (unsigned)i) <= px) {
           accept_cand[al] = x;
@@ -440,16 +485,17 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   const bool use_gtp = sh[2] && accept_length != md;
   const int a = accept_length - 1;
   int node, nrem;
-  float m;
+  float m, thr;
   if (use_gtp) {
-    node = last_node; m = last_m; nrem = sh[3];
+    node = last_node; m = last_m; thr = last_thr; nrem = sh[3];
   } else {
     node = tb.retrieve[best * TREE_RET_W + a];
     float Z;
-    vs_row_stats(logits + (size_t)node * V, V, T, s_f, m, Z);
+    thr = vs_topk_threshold(logits + (size_t)node * V, V, top_k, s_hist);
+    vs_row_stats(logits + (size_t)node * V, V, T, thr, s_f, m, Z);
     nrem = 0;
   }
-  const int next = vs_multinomial(logits + (size_t)node * V, V, T, m, removed, nrem, vs_uniform(seed, (unsigned)round, 255u, 255u), s_d, s_i);
+  const int next = vs_multinomial(logits + (size_t)node * V, V, T, m, thr, removed, nrem, vs_uniform(seed, (unsigned)round, 255u, 255u), s_d, s_i);
   if (tid == 0) {
     const int* rowp = tb.retrieve + best * TREE_RET_W;
     const int n = st->n_ctx;

@@ -63,6 +63,7 @@ struct vispec_ctx {
   struct GraphSlot { hipGraphExec_t exec = nullptr; long key = -1; };
   GraphSlot g_verify, g_draft, g_ar;
   float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
+  int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
   unsigned long long seed = 0;
   bool use_graphs = true;
   long graph_replays = 0, graph_captures = 0, direct_runs = 0;
@@ -985,7 +986,7 @@ static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accep
   const int D = c.hidden_size, Hk = c.num_kv_heads;
   if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
     hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
-                       ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
+                       ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
   else
     hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
                        ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
@@ -1003,7 +1004,8 @@ extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_ac
   hipStream_t s = (hipStream_t)stream;
   unsigned tbits;
   memcpy(&tbits, &ctx->temperature, 4);
-  const long key = ((long)ctx->n_hint * 64 + (forced_accept + 1)) ^ ((long)tbits << 24) ^ (long)(ctx->seed * 0x9E3779B97F4A7C15ull >> 8);
+  const long key = ((long)ctx->n_hint * 64 + (forced_accept + 1)) ^ ((long)tbits << 24) ^ (long)(ctx->seed * 0x9E3779B97F4A7C15ull >> 8) ^
+                   ((long)ctx->sample_top_k << 44);
   return run_graphed(ctx, s, ctx->g_verify, key, [&]() {
     if (target_forward(ctx, s, ctx->c.total_token)) return -1;
     return target_accept(ctx, s, ctx->c.total_token, forced_accept);
@@ -1064,12 +1066,20 @@ extern "C" int vispec_set_sampling(vispec_ctx* ctx, float temperature, unsigned 
   if (!ctx) return fail("null ctx");
   ctx->temperature = temperature;
   ctx->seed = seed;
+  ctx->sample_top_k = 0;
   return 0;
 }
 // token = multinomial(softmax(row / T)) of one bf16 logits row (first token of a sampled request, utils.py:284-288)
+// TopKLogitsWarper of prepare_logits_processor (utils.py:52-53); call after vispec_set_sampling (which resets it to 0 = off)
+extern "C" int vispec_set_top_k(vispec_ctx* ctx, int top_k) {
+  if (!ctx || top_k < 0) return fail("set_top_k: bad arguments");
+  ctx->sample_top_k = top_k;
+  return 0;
+}
 extern "C" int vispec_sample_row(vispec_ctx* ctx, void* stream, const void* logits_row, int V, int* out_token_dev) {
   if (!ctx || ctx->temperature <= 1e-5f) return fail("sample_row: sampling not enabled (vispec_set_sampling)");
-  hipLaunchKernelGGL(sample_row_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits_row, V, ctx->temperature, ctx->seed,
+  hipLaunchKernelGGL(sample_row_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits_row, V, ctx->temperature, ctx->sample_top_k,
+                     ctx->seed,
                      out_token_dev);
   KCHK();
   return 0;

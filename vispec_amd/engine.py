@@ -340,8 +340,10 @@ class Engine:
     def set_rope_delta(self, delta: int):
         L.check(self.lib.vispec_set_rope_delta(self.h, self._stream(), int(delta)))
 
-    def set_sampling(self, temperature: float, seed: int = 0):
+    def set_sampling(self, temperature: float, seed: int = 0, top_k: int = 0):
         L.check(self.lib.vispec_set_sampling(self.h, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF))
+        if top_k:
+            L.check(self.lib.vispec_set_top_k(self.h, int(top_k)))
 
     def sample_row(self, logits_row: torch.Tensor) -> torch.Tensor:
         row = logits_row.reshape(-1).to(torch.bfloat16).contiguous()

@@ -212,14 +212,16 @@ class SpecModel:
                      is_llama3=False, inputs_embeds=None, return_acceptance_len=False, return_decode_time=False,
                      forced_accept=None, seed=0, **kwargs):
         """spec_model_ours.py:247-582.  `forced_accept` (callable round->int, bench-only) scripts the accept length.
-        temperature > 1e-5 selects the sampling path (utils.py:453-493) with device-side counter-based randomness (`seed`);
-        like the reference's default processor list (exp.sh: temperature only) top_p / top_k warpers are not applied."""
+        temperature > 1e-5 selects the sampling path (utils.py:453-493) with device-side counter-based randomness (`seed`) and the
+        processor list of utils.py:39-55: temperature, then TopK when top_k > 0.  0 < top_p < 1 raises: HF's TopPLogitsWarper fails
+        on the 3-D tree logits evaluate_posterior passes it, so the reference cannot run that setting either."""
         if (input_ids is None) ^ (inputs_embeds is not None):  # :263-266 (sic: exactly the reference's condition)
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
-        if temperature > 1e-5 and (top_p >= 1e-8 and top_p < 1.0 or top_k > 0):
-            raise NotImplementedError("TopP / TopK logits warpers (utils.py:50-53) are not implemented; temperature only")
+        if temperature > 1e-5 and 1e-8 <= top_p < 1.0:
+            raise NotImplementedError("TopPLogitsWarper (utils.py:50-51) cannot run on the tree logits (HF scatters along dim 1: "
+                                      "RuntimeError in the reference as well); use temperature / top_k")
         eng = self.engine
-        eng.set_sampling(temperature if temperature > 1e-5 else 0.0, seed)
+        eng.set_sampling(temperature if temperature > 1e-5 else 0.0, seed, top_k=int(top_k) if temperature > 1e-5 else 0)
         dev = eng.device
         max_length = max_length - self.spec_layer.total_tokens - 10  # :270
         input_ids = input_ids.clone().to(dev)
