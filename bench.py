@@ -255,6 +255,7 @@ def main():
         def f():
             tok = rnd = 0
             accs = []
+            torch.cuda.set_device(device)  # HIP's current device is per host thread; a new thread starts on device 0
             with torch.cuda.stream(streams[lane]):
                 for i in range(lo, hi):
                     ids, pix = reqs[lane][i]

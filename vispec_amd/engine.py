@@ -295,6 +295,10 @@ class Engine:
 
     # -- stream plumbing ---------------------------------------------------------------------------
     def _stream(self):
+        # HIP's current device is per host thread (a fresh thread starts on device 0) and a launch must be issued with the
+        # stream's device current: every library call goes through here, so this is where it is enforced
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- the path ------------------------------------------------------------------------------------
