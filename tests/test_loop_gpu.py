@@ -597,3 +597,29 @@ def test_sampling_with_top_k_warper(temperature, top_k, seed):
         assert not np.array_equal(unwarped[: len(o_out)], o_out[: len(unwarped)])  # the warper changes the hot-temperature stream
     with pytest.raises(NotImplementedError):
         sm.specgenerate(t_ids, temperature=1.0, top_p=0.9, max_new_tokens=4)
+
+
+def test_kv_capacity_stop_instead_of_overflow(golden_dir):
+    """Maximum sizes: a request whose generation would run past the KV cache stops (done bit 2) with everything generated so far
+    intact — the reference's KVCache.cat raises at this point (kv_cache.py:40-58).  The tokens are the oracle's / greedy AR's prefix,
+    and a prompt that cannot fit at all is refused up front."""
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    base = g["succ0_ids"]
+    ids = np.concatenate([base, np.random.default_rng(9).integers(3, 900, 330 - len(base))])  # max_pos = 512 -> guard at 512 - 128
+    sm, ot, od = build(50, 60, True)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=400, log=True, return_acceptance_len=True)
+    st = sm.engine.state()
+    assert st["done"] & 4 and not st["done"] & 3 and new_token < 400
+    # text-only: the draft KV (same 512 rows, guard = top_k_max*depth_max + 64 = 192 rows) fills first; the stop comes within one round of it
+    assert T["max_pos"] - 192 < st["n_ctx"] <= T["max_pos"] - 192 + 24
+    out = out[0].cpu().numpy()
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=len(out) - len(ids) - 1, max_pos=T["max_pos"])
+    n = min(len(out), len(o_out))
+    np.testing.assert_array_equal(out[:n], o_out[:n])
+    assert acc[: len(o_acc)] == o_acc[: len(acc)]
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=400)[0].cpu().numpy()
+    assert sm.engine.state()["done"] & 4 and len(ar) + 1 < T["max_pos"]
+    n = min(len(ar), len(out))
+    np.testing.assert_array_equal(ar[:n], out[:n])
+    with pytest.raises(RuntimeError, match="does not fit"):
+        sm.specgenerate(torch.from_numpy(np.full(T["max_pos"] - 20, 5))[None], max_new_tokens=4)

@@ -45,6 +45,7 @@ struct DevState {
   int new_token;    // generated tokens so far (spec_model_ours.py:476, utils.py:582)
   int rounds;
   int done;         // bit0: eos seen (spec_model_ours.py:544)  bit1: new_token > max_new_tokens (:546)
+                    // bit2: the next round would not fit a KV cache (the reference's KVCache.cat raises there: kv_cache.py:40-58)
   int max_new_tokens;
   int eos_token_id;
   int draft_len;    // n_c : rows of the draft's stable KV (cnets_ours.py:1108)
@@ -52,7 +53,9 @@ struct DevState {
   int n_leaf, max_depth; // shape of the current tree's retrieve table
   int tree_T;       // nodes in the current tree (total_token, or 1 for the AR baseline)
   int rope_delta;   // Qwen2.5-VL: cached rope_deltas added to every decode position (utils.py:397-402); 0 otherwise
+  int kv_cap, draft_cap;  // rows of the target / draft KV caches
 };
+#define KV_GUARD_ROWS 64  // rows kept free beyond the next tree (the AR baseline polls `done` only every 16 steps)
 
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 32; every weight byte is streamed from HBM exactly once per call)

@@ -262,6 +262,7 @@ __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __res
     st->next_token = next;
     st->new_token += a + 1;
     if (st->new_token > st->max_new_tokens) done |= 2;
+    if (st->n_ctx + TREE_MAX_T + KV_GUARD_ROWS > st->kv_cap) done |= 4;
     st->done = done;
     if (st->rounds < log_cap) accept_log[st->rounds] = a;
     st->rounds += 1;
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
     st->next_token = next;
     st->new_token += a + 1;
     if (st->new_token > st->max_new_tokens) done |= 2;
+    if (st->n_ctx + TREE_MAX_T + KV_GUARD_ROWS > st->kv_cap) done |= 4;
     st->done = done;
     if (st->rounds < log_cap) accept_log[st->rounds] = a;
     st->rounds += 1;
@@ -544,5 +546,7 @@ __global__ void draft_advance_kernel(DevState* st) {
   if (threadIdx.x == 0) {
     st->draft_len += st->accept_len + 1;
     st->draft_real_len += st->accept_len + 1;
+    // the next round appends a catch-up (<= depth+2 rows) and top_k rows per tree level behind the stable KV
+    if (st->draft_len + TREE_MAX_K * TREE_MAX_DEPTH + KV_GUARD_ROWS > st->draft_cap) st->done |= 4;
   }
 }

@@ -688,7 +688,7 @@ extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
 }
 
 // ------------------------------------------------------------------------------------------------ the path
-__global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos) {
+__global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos, int kv_cap, int draft_cap) {
   if (threadIdx.x == 0) {
     DevState z{};
     z.n_ctx = L;
@@ -696,6 +696,8 @@ __global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos) 
     z.max_new_tokens = max_new;
     z.eos_token_id = eos;
     z.tree_T = 0;
+    z.kv_cap = kv_cap;
+    z.draft_cap = draft_cap;
     *st = z;
   }
 }
@@ -713,7 +715,8 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
   const vispec_config& c = ctx->c;
   if (L < 1 || L + c.total_token + 8 > c.max_pos) return fail("prompt does not fit the KV cache");
   if (prompt_ids_host) HIPCHK(hipMemcpyAsync(ctx->tokens, prompt_ids_host, sizeof(int) * L, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(begin_request_kernel, dim3(1), dim3(64), 0, s, ctx->st, L, max_new_tokens, c.eos_token_id);
+  hipLaunchKernelGGL(begin_request_kernel, dim3(1), dim3(64), 0, s, ctx->st, L, max_new_tokens, c.eos_token_id, c.max_pos,
+                     c.draft_max_pos);
   KCHK();
   long hint = (long)L + max_new_tokens + 2 * (c.depth + 2) + c.total_token + 64;
   ctx->n_hint = (int)(hint < c.max_pos ? hint : c.max_pos);

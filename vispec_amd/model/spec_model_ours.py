@@ -265,6 +265,8 @@ class SpecModel:
                 break
             if st["new_token"] > max_new_tokens:  # :546
                 break
+            if st["done"] & 4:  # the next tree would not fit a KV cache: the reference raises in KVCache.cat here (kv_cache.py:40-58)
+                break
         n_ctx, new_token = st["n_ctx"], st["new_token"]
         self.current_length_data.fill_(n_ctx)
         toks = torch.from_numpy(eng.tokens(n_ctx).astype(np.int64)).to(dev)[None]
