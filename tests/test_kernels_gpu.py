@@ -355,7 +355,7 @@ def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
 
 
 @pytest.mark.parametrize("H,Hkv,K,M,fp8,bias", [(48, 8, 256, 30, False, True), (56, 4, 128, 7, False, False), (48, 8, 256, 30, True, True),
-                                                (2, 2, 256, 9, False, True)])
+                                                (2, 2, 256, 9, False, True), (28, 4, 3584, 30, False, True), (28, 4, 3584, 30, True, True)])
 def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
     """One-launch q|k|v projection + rotary + KV append (EPI_ROPE, weight packed in rope order) == the GEMM followed by
     vispec_rope_append, bit for bit, and == the oracle's linear + rope.  (2,2) is below the fused threshold: same entry
@@ -364,7 +364,7 @@ def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
     rng = np.random.default_rng(H * 7 + K + M)
     hd, S = 128, 64
     N = (H + 2 * Hkv) * hd
-    assert bool(lib.vispec_qkv_rope_fused(N)) == (N // 32 >= 256)
+    assert bool(lib.vispec_qkv_rope_fused(N)) == (N // 32 >= 128)
     o = vo.Ops(True)
     cos, sin = vo.rope_tables(hd, 128, 10000.0)
     cos, sin = synth.bf16_grid(cos), synth.bf16_grid(sin)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -262,6 +263,27 @@ static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
   return 0;
 }
 
+// Split-K factor from the measured launch model of the skinny GEMM (tools/gemm_balance.py, kernel alone):
+//   t ~= 5 us + 11.3 us x (workgroup bytes / 256 KiB) x (full rounds of 256 workgroups + 0.55 + 0.45 x fill of a partial round)
+// i.e. the chip runs workgroups in rounds of one per CU, a round that is barely started still costs more than half a full one, and
+// every launch pays ~5 us of ramp.  S > 1 adds the reduce launch unless a fused norm needs that launch anyway.  Ties go to the
+// decomposition closest to two workgroups per CU.
+static int choose_split(int tiles, int KS, double tile_bytes, bool reduce_is_free) {
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = reduce_is_free ? 2 : 1; S <= 8; ++S) {
+    if (S > 1 && KS / S < 8) break;
+    const int wgs = tiles * S, full = wgs / 256, part = wgs % 256;
+    const double rounds = full + (part ? 0.55 + 0.45 * part / 256.0 : 0.0);
+    double t = 5.0 + 11.3 * (tile_bytes / S / 262144.0) * rounds + (S > 1 && !reduce_is_free ? 5.5 : 0.0) + 0.05 * S;
+    if (t < best_t * 0.97 || (t < best_t * 1.03 && std::abs(wgs - 512) < std::abs(tiles * best - 512) && t < best_t * 1.03)) {
+      if (t < best_t) best_t = t;
+      best = S;
+    }
+  }
+  return best;
+}
+
 // One skinny GEMM on a W32-packed weight.  Small-N problems are split over K across workgroups (fp32 partials in
 // ctx->gemm_part) and finished by splitk_reduce_kernel, which also applies bias / residual and, when `norm_w` is given, the
 // RMSNorm that follows in the layer (one kernel boundary and one activation round trip less).
@@ -296,9 +318,7 @@ static int launch_gemm_ex32(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   // split-K when the row blocks alone cannot fill the chip, or when a fused norm is requested (the reduce kernel owns it)
   int S = 1;
   if (tiles < 256 || o.norm_w) {
-    S = (512 + tiles - 1) / tiles;
-    if (S > 8) S = 8;
-    while (S > 1 && KS / S < 8) --S;
+    S = choose_split(tiles, KS, (double)32 * K * (o.wscale ? 1.0 : 2.0), o.norm_w != nullptr);
     if (!ctx) S = 1;
   }
   if (force_split > 0) S = force_split;
@@ -411,10 +431,11 @@ static int launch_rope(hipStream_t s, void* qkv, int M, int H, int H_kv, const v
   return 0;
 }
 
-// q|k|v projection + rotary + KV append.  When the row blocks alone fill the chip (no split-K) the three run as ONE launch
+// q|k|v projection + rotary + KV append.  When split-K does not pay (>= 128 row blocks) the three run as ONE launch
 // (EPI_ROPE; the weight must have been packed in rope order — vispec_qkv_rope_fused() tells the loader); otherwise the
 // split-K GEMM is followed by rope_append2_kernel on a naturally ordered weight.
-static bool qkv_rope_fused(int n_rows) { return n_rows % 128 == 0 && n_rows / 32 >= 256; }
+// (un-split: with >= 128 row blocks one launch beats split-K + reduce + rotary launches even on a half-filled chip — choose_split)
+static bool qkv_rope_fused(int n_rows) { return n_rows % 128 == 0 && n_rows / 32 >= 128; }
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, PosSpec ps, void* kc, void* vc,
                            int s_max) {
