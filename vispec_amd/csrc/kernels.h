@@ -145,12 +145,13 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 // (8 lanes = one 128-B row segment -> 8 different 16-B bank groups) and the fragment reads are conflict-free
 #define XS_STEP 1056
 #define XS_HALF 528
-template <int NT, int UNROLL, int NW>
+// MT = 32-row activation tiles per launch (M <= 32*MT): every weight tile in registers feeds MT MFMAs
+template <int NT, int UNROLL, int NW, int MT = 1>
 constexpr int gemm_w32_lds_bytes() {
-  return (NW * 2 * UNROLL * XS_STEP) > (NW * NT * 4096) ? (NW * 2 * UNROLL * XS_STEP) : (NW * NT * 4096);
+  return (NW * MT * 2 * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * 2 * UNROLL * XS_STEP) : (NW * NT * MT * 4096);
 }
 
-template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
+template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
 __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
@@ -169,36 +170,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
   const int w_lo = ks_lo + (int)((long)len * wave / NW), w_hi = ks_lo + (int)((long)len * (wave + 1) / NW);
   const uint4* pa0 = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * 64 + lane + (size_t)w_lo * 64;
   const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P) + (size_t)(tile + tile2_off) * KS * 64 + lane + (size_t)w_lo * 64 : pa0;
-  f32x16 acc[NT];
+  f32x16 acc[NT][MT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
 
   // ---- X staging map: one instruction = (64 / (2*UNROLL)) rows x (UNROLL*32) contiguous bytes -> whole 128/256-B lines.
   // The activations are re-read by every workgroup from L2; fetching them fragment-shaped (32 rows x 32 B per instruction)
   // costs twice the L1/TA requests of the weight stream and was measured to cap the kernel at ~3.7 TB/s (tools/stream_probe).
   constexpr int SEGS = 2 * UNROLL, RPI = 64 / SEGS, NINST = 32 / RPI;
   const int seg = lane % SEGS, srow0 = lane / SEGS;
-  unsigned char* xs = smem_g + wave * (2 * UNROLL * XS_STEP);
-  const bf16_t* sx[NINST];
+  constexpr int XTILE = UNROLL * XS_STEP;  // one staged group of one activation tile; per wave: [2 buffers][MT tiles]
+  unsigned char* xs = smem_g + wave * (MT * 2 * XTILE);
+  const bf16_t* sx[MT][NINST];
   int woff[NINST];
 #pragma unroll
   for (int i = 0; i < NINST; ++i) {
     const int row = srow0 + i * RPI;
-    sx[i] = X + (size_t)(row < M ? row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;  // rows >= M read row 0, never stored
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)  // rows >= M read row 0, never stored
+      sx[mt][i] = X + (size_t)(32 * mt + row < M ? 32 * mt + row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;
     woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
   const int roff = hi * XS_HALF + j * 16;
 
   struct Regs {
     uint4 a[NT][LOADS];
-    uint4 x[NINST];
+    uint4 x[MT][NINST];
   };
   auto load = [&](Regs& g) {  // all loads unconditional plain global loads; X first (it is consumed first, through LDS)
     if (DBG != 1) {
 #pragma unroll
-      for (int i = 0; i < NINST; ++i) g.x[i] = *reinterpret_cast<const uint4*>(sx[i]);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) g.x[mt][i] = *reinterpret_cast<const uint4*>(sx[mt][i]);
     }
 #pragma unroll
     for (int u = 0; u < LOADS; ++u) {
@@ -208,38 +216,48 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     pa0 += 64 * LOADS;
     pa1 += 64 * LOADS;
 #pragma unroll
-    for (int i = 0; i < NINST; ++i) sx[i] += 16 * UNROLL;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < NINST; ++i) sx[mt][i] += 16 * UNROLL;
   };
   auto compute = [&](const Regs& g, int buf) {
-    unsigned char* xb = xs + buf * (UNROLL * XS_STEP);
+    unsigned char* xb = xs + buf * (MT * XTILE);
     if (DBG != 1) {
 #pragma unroll
-      for (int i = 0; i < NINST; ++i) *reinterpret_cast<uint4*>(xb + woff[i]) = g.x[i];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) *reinterpret_cast<uint4*>(xb + mt * XTILE + woff[i]) = g.x[mt][i];
     }
     // same-wave LDS traffic is processed in issue order: the fragment reads below see the writes above
     if (!W8) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const uint4 bv = (DBG == 1) ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
-                                    : *reinterpret_cast<const uint4*>(xb + u * XS_STEP + roff);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          const uint4 bv = (DBG == 1) ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                      : *reinterpret_cast<const uint4*>(xb + mt * XTILE + u * XS_STEP + roff);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t][mt], 0, 0, 0);
+        }
       }
     } else {
       // fp8 tile c holds k = 32c + 16*hi + [0,16) for this lane: its two 8-k halves pair with the staged bf16 step (2c + hi),
       // half 0 / half 1 of the activation image
 #pragma unroll
       for (int c = 0; c < LOADS; ++c) {
-        const unsigned char* xstep = xb + (2 * c + hi) * XS_STEP + j * 16;
-        const uint4 b0 = *reinterpret_cast<const uint4*>(xstep);
-        const uint4 b1 = *reinterpret_cast<const uint4*>(xstep + XS_HALF);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           uint4 a_lo, a_hi;
           fp8x16_to_bf16(g.a[t][c], a_lo, a_hi);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[t], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const unsigned char* xstep = xb + mt * XTILE + (2 * c + hi) * XS_STEP + j * 16;
+            const uint4 b0 = *reinterpret_cast<const uint4*>(xstep);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(xstep + XS_HALF);
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), acc[t][mt], 0, 0, 0);
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[t][mt], 0, 0, 0);
+          }
         }
       }
     }
@@ -269,115 +287,126 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     }
   }
   {  // leftover steps (less than a group): fragment-shaped X loads straight from global
-    const bf16_t* px = X + (size_t)(j < M ? j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
+    const bf16_t* px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      px[mt] = X + (size_t)(32 * mt + j < M ? 32 * mt + j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
     for (int rstep = n_groups * LOADS; rstep < n_steps; ++rstep) {
       const uint4 av = pa0[0];
-      const uint4 bv = *reinterpret_cast<const uint4*>(px);
-      if (!W8) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0], 0, 0, 0);
-        if (NT == 2) {
-          const uint4 av1 = pa1[0];
-          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
+      const uint4 av1 = pa1[0];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const uint4 bv = *reinterpret_cast<const uint4*>(px[mt]);
+        if (!W8) {
+          acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0][mt], 0, 0, 0);
+          if (NT == 2) acc[NT - 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1][mt], 0, 0, 0);
+        } else {
+          const uint4 bv1 = *reinterpret_cast<const uint4*>(px[mt] + 8);
+          uint4 a_lo, a_hi;
+          fp8x16_to_bf16(av, a_lo, a_hi);
+          acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[0][mt], 0, 0, 0);
+          acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[0][mt], 0, 0, 0);
+          if (NT == 2) {
+            fp8x16_to_bf16(av1, a_lo, a_hi);
+            acc[NT - 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[NT - 1][mt], 0, 0, 0);
+            acc[NT - 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[NT - 1][mt], 0, 0, 0);
+          }
         }
-      } else {
-        const uint4 bv1 = *reinterpret_cast<const uint4*>(px + 8);
-        uint4 a_lo, a_hi;
-        fp8x16_to_bf16(av, a_lo, a_hi);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[0], 0, 0, 0);
-        if (NT == 2) {
-          fp8x16_to_bf16(pa1[0], a_lo, a_hi);
-          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[NT - 1], 0, 0, 0);
-          acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[NT - 1], 0, 0, 0);
-        }
+        px[mt] += KSTEP;
       }
       pa0 += 64;
       pa1 += 64;
-      px += KSTEP;
     }
   }
   if (DBG == 2) {
-    if (acc[0][0] == 12345.f) reinterpret_cast<float*>(Yv)[0] = acc[0][1];
+    if (acc[0][0][0] == 12345.f) reinterpret_cast<float*>(Yv)[0] = acc[0][0][1];
     return;
   }
   // cross-wave reduction through LDS (aliases the X staging area), fixed order wave 0 + 1 + ... (deterministic)
-  float(*red)[NT][64][16] = reinterpret_cast<float(*)[NT][64][16]>(smem_g);
+  float(*red)[NT][MT][64][16] = reinterpret_cast<float(*)[NT][MT][64][16]>(smem_g);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][t][lane][r] = acc[t][r];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][t][mt][lane][r] = acc[t][mt][r];
   __syncthreads();
   if (EPI == EPI_ROPE) {
     // waves 0/1 own column groups q and q+2 of the tile: packed columns c = 8q + 4hi + r (< 16) and c + 16 = its rotate_half partner
-    if (wave < 2 && j < M) {
-      const int qq = wave;
-      float a[4], b[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sa = red[0][0][lane][4 * qq + r], sb = red[0][0][lane][4 * (qq + 2) + r];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-          sa += red[w][0][lane][4 * qq + r];
-          sb += red[w][0][lane][4 * (qq + 2) + r];
-        }
-        a[r] = sa;
-        b[r] = sb;
-      }
-      const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
-      const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
-      const int kvrow = (re.ps.kv_base ? *re.ps.kv_base : 0) + re.ps.kv_add + j;
-      if (h < re.H + re.H_kv) {
-        const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of a[] / b[]
-        const int pos = (re.ps.base ? *re.ps.base : 0) + (re.ps.base2 ? *re.ps.base2 : 0) + re.ps.add +
-                        (re.ps.off ? re.ps.off[j] : (re.ps.row ? j : 0));
-        float o1[4], o2[4];
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = 32 * mt + j;
+      if (wave < 2 && m < M) {
+        const int qq = wave;
+        float a[4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x1 = a[r], x2 = b[r];
-          if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
-          if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
-          x1 = rdbf(x1);
-          x2 = rdbf(x2);
-          const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
-          o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
-          o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
-        }
-        bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)j * ldy + c1
-                                 : re.kc + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-        *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
-      } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
-        float o1[4], o2[4];
+          float sa = red[0][0][mt][lane][4 * qq + r], sb = red[0][0][mt][lane][4 * (qq + 2) + r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x1 = a[r], x2 = b[r];
-          if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
-          if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
-          o1[r] = rdbf(x1);
-          o2[r] = rdbf(x2);
+          for (int w = 1; w < NW; ++w) {
+            sa += red[w][0][mt][lane][4 * qq + r];
+            sb += red[w][0][mt][lane][4 * (qq + 2) + r];
+          }
+          a[r] = sa;
+          b[r] = sb;
         }
-        bf16_t* dst = re.vc + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
+        const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
+        const int kvrow = (re.ps.kv_base ? *re.ps.kv_base : 0) + re.ps.kv_add + m;
+        if (h < re.H + re.H_kv) {
+          const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of a[] / b[]
+          const int pos = (re.ps.base ? *re.ps.base : 0) + (re.ps.base2 ? *re.ps.base2 : 0) + re.ps.add +
+                          (re.ps.off ? re.ps.off[m] : (re.ps.row ? m : 0));
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = a[r], x2 = b[r];
+            if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+            if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
+            x1 = rdbf(x1);
+            x2 = rdbf(x2);
+            const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
+            o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
+            o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
+          }
+          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
+                                   : re.kc + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = a[r], x2 = b[r];
+            if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+            if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
+            o1[r] = rdbf(x1);
+            o2[r] = rdbf(x2);
+          }
+          bf16_t* dst = re.vc + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        }
       }
     }
     return;
   }
-  constexpr int NGROUPS = (EPI == EPI_SWIGLU) ? 4 : 4 * NT;
+  constexpr int NGROUPS = ((EPI == EPI_SWIGLU) ? 4 : 4 * NT) * MT;
   for (int idx = wave; idx < NGROUPS; idx += NW) {
-    const int tt = (EPI == EPI_SWIGLU) ? 0 : idx >> 2, q = idx & 3;
+    const int q = idx & 3, tm = idx >> 2;
+    const int mt = tm % MT, tt = (EPI == EPI_SWIGLU) ? 0 : tm / MT;
+    const int m = 32 * mt + j;
     float v[4], u2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float sum = red[0][tt][lane][4 * q + r];
+      float sum = red[0][tt][mt][lane][4 * q + r];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) sum += red[w][tt][lane][4 * q + r];
+      for (int w = 1; w < NW; ++w) sum += red[w][tt][mt][lane][4 * q + r];
       v[r] = sum;
       if (EPI == EPI_SWIGLU) {
-        float su = red[0][NT - 1][lane][4 * q + r];
+        float su = red[0][NT - 1][mt][lane][4 * q + r];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) su += red[w][NT - 1][lane][4 * q + r];
+        for (int w = 1; w < NW; ++w) su += red[w][NT - 1][mt][lane][4 * q + r];
         u2[r] = su;
       }
     }
@@ -389,9 +418,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
         if (EPI == EPI_SWIGLU) u2[r] *= wscale[tile2_off * 32 + n + r];
       }
     }
-    if (j < M && n < N) {
+    if (m < M && n < N) {
       if (EPI == EPI_PARTIAL) {
-        float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * 32 + j) * N + n;
+        float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * (32 * MT) + m) * N + n;
         *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
@@ -408,10 +437,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
             float act = rdbf(y / (1.0f + __expf(-y)));
             y = rdbf(act * u);
           }
-          if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)j * ldr + n + r]) + y);
+          if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
           o[r] = y;
         }
-        *reinterpret_cast<uint2*>(Y + (size_t)j * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
       }
     }
   }
@@ -419,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
 
 // Finishes a split-K GEMM: y = bf16(sum_s part[s] + bias) ; h = bf16(R + y) if R ; optional fused RMSNorm of h
 // (cnets_ours.py:513-527) written to `normed`.  One workgroup per row m; every stage rounds where the reference's graph does.
-__global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int N,
+__global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int Mpad, int N,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                             bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
                                                             bf16_t* __restrict__ normed, int ldn, float eps) {
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     float4 a = *reinterpret_cast<const float4*>(part + (size_t)m * N + n);
     for (int s = 1; s < S; ++s) {
-      const float4 b = *reinterpret_cast<const float4*>(part + ((size_t)s * 32 + m) * N + n);
+      const float4 b = *reinterpret_cast<const float4*>(part + ((size_t)s * Mpad + m) * N + n);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     float o[4] = {a.x, a.y, a.z, a.w};

@@ -154,7 +154,7 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
     size_t nmax = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
     if (nmax < (size_t)3 * c.hidden_size) nmax = (size_t)3 * c.hidden_size;
     if (nmax < 16384) nmax = 16384;
-    ctx->gemm_part_elems = (size_t)8 * 32 * nmax;
+    ctx->gemm_part_elems = (size_t)8 * 64 * nmax;
     A(gemm_part, ctx->gemm_part_elems);
     A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
   }
@@ -294,23 +294,25 @@ struct GemmOut {
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
 };
-static int launch_gemm_ex32(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
-                            int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
-  if (M < 1 || M > 32) return fail("gemm_skinny: M must be in [1,32]");
+// MT = number of 32-row activation tiles (M <= 32*MT): each weight tile held in registers feeds MT MFMAs, so trees of 33..64
+// nodes (and two requests sharing a launch) still stream every weight once.
+template <int MT>
+static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
+                          int epi, const GemmOut& o, int force_split) {
+  if (M < 1 || M > 32 * MT) return fail("gemm_skinny: M out of range");
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
   const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
+#define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
+  hipLaunchKernelGGL((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
+                     T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{})
   if (epi == EPI_SWIGLU) {
     if (N % 32) return fail("gemm_skinny: SwiGLU needs N %% 32 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
     prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
-    if (o.wscale)
-      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x,
-                         ldx, w, tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
-    else
-      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_SWIGLU, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4>()), s, x, ldx, w,
-                         tiles, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
+    if (o.wscale) VISPEC_GEMM(2, EPI_SWIGLU, true, dim3(tiles, 1), tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM(2, EPI_SWIGLU, false, dim3(tiles, 1), tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
@@ -324,54 +326,37 @@ static int launch_gemm_ex32(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   if (force_split > 0) S = force_split;
   if (S == 1 && !o.norm_w) {
     prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
-    if (epi == EPI_RESIDUAL && o.wscale)
-      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x,
-                         ldx, w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
-    else if (epi == EPI_RESIDUAL)
-      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_RESIDUAL, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w,
-                         0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
-    else if (o.wscale)
-      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4, 0, true>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
-                         w, 0, b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, o.wscale, RopeEpi{});
-    else
-      hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_NONE, 4, 4>), dim3(tiles, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                         b, o.Y, o.ldy, r, o.ldr, M, N, K, 1, nullptr, RopeEpi{});
+    if (epi == EPI_RESIDUAL && o.wscale) VISPEC_GEMM(1, EPI_RESIDUAL, true, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (epi == EPI_RESIDUAL) VISPEC_GEMM(1, EPI_RESIDUAL, false, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    else if (o.wscale) VISPEC_GEMM(1, EPI_NONE, true, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM(1, EPI_NONE, false, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
   }
   if (!ctx) return fail("gemm_skinny: split-K needs a ctx (partial workspace)");
-  if ((size_t)S * 32 * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
+  if ((size_t)S * 32 * MT * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
   prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
-  if (o.wscale)
-    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, true>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx,
-                       w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, o.wscale, RopeEpi{});
-  else
-    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
+  if (o.wscale) VISPEC_GEMM(1, EPI_PARTIAL, true, dim3(tiles, S), 0, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
+  else VISPEC_GEMM(1, EPI_PARTIAL, false, dim3(tiles, S), 0, nullptr, ctx->gemm_part, 0, nullptr, 0, S, nullptr);
+#undef VISPEC_GEMM
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, N, b,
-                     epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn,
-                     o.eps);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
+                     N, b, epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed,
+                     o.ldn, o.eps);
   KCHK();
   prof_end(s);
   return 0;
 }
 
-// M in (32, 64] (total_token > 32, spec_model_ours.py:179-201 autotunes up to 60): two passes over 32-row halves, i.e. the weight is
-// streamed twice — correct and simple; the default tree (30 nodes) never takes this path.
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
-  if (M <= 32) return launch_gemm_ex32(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split, force_nw);
-  if (M > 64) return fail("gemm_skinny: M must be in [1,64]");
-  if (launch_gemm_ex32(ctx, s, X, ldx, P, bias, 32, N, K, epi, o, force_split, force_nw)) return -1;
-  GemmOut o2 = o;
-  if (o.Y) o2.Y = (bf16_t*)o.Y + (size_t)32 * o.ldy;
-  if (o.R) o2.R = (const bf16_t*)o.R + (size_t)32 * o.ldr;
-  if (o.normed) o2.normed = (bf16_t*)o.normed + (size_t)32 * o.ldn;
-  return launch_gemm_ex32(ctx, s, (const bf16_t*)X + (size_t)32 * ldx, ldx, P, bias, M - 32, N, K, epi, o2, force_split, force_nw);
+  (void)force_nw;
+  if (M <= 32) return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
+  if (M <= 64) return launch_gemm_mt<2>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
+  return fail("gemm_skinny: M must be in [1,64]");
 }
 
 // legacy-shaped helper used by most call sites
@@ -446,24 +431,16 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   }
   if (M < 1 || M > 64) return fail("gemm_qkv_rope: M must be in [1,64]");
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
-  if (M > 32) {  // two 32-row passes (see launch_gemm_ex)
-    if (launch_qkv_rope(ctx, s, X, ldx, P, bias, wscale, qkv, 32, H, H_kv, K, cosT, sinT, ps, kc, vc, s_max)) return -1;
-    PosSpec p2 = ps;
-    if (ps.off) p2.off = ps.off + 32; else if (ps.row) p2.add = ps.add + 32;
-    p2.kv_add = ps.kv_add + 32;
-    return launch_qkv_rope(ctx, s, (const bf16_t*)X + (size_t)32 * ldx, ldx, P, bias, wscale, (bf16_t*)qkv + (size_t)32 * N, M - 32, H, H_kv, K,
-                           cosT, sinT, p2, kc, vc, s_max);
-  }
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT; re.ps = ps; re.kc = (bf16_t*)kc; re.vc = (bf16_t*)vc;
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
   prof_begin(s, 0, (double)N * K * (wscale ? 1.0 : 2.0));
-  if (wscale)
-    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, true>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s,
-                       (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, (const float*)wscale, re);
-  else
-    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, (const bf16_t*)X,
-                       ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, nullptr, re);
+#define VISPEC_QKV(W8_, MT_)                                                                                                              \
+  hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, MT_>()), s, \
+                     (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, (const float*)wscale, re)
+  if (M <= 32) { if (wscale) VISPEC_QKV(true, 1); else VISPEC_QKV(false, 1); }
+  else { if (wscale) VISPEC_QKV(true, 2); else VISPEC_QKV(false, 2); }
+#undef VISPEC_QKV
   KCHK();
   prof_end(s);
   return 0;
@@ -601,7 +578,7 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #undef V
   KCHK();
   if (no_reduce) return 0;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), 0, s, ctx->gemm_part, S, N, nullptr, nullptr, 0, (bf16_t*)Y, ldy, nullptr,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), 0, s, ctx->gemm_part, S, 32, N, nullptr, nullptr, 0, (bf16_t*)Y, ldy, nullptr,
                      nullptr, 0, 0.f);
   KCHK();
   return 0;
