@@ -227,6 +227,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("VISPEC_FORCE_DEVICE"):  # dry run of the N > 1 control flow on a 1-GPU box (with VISPEC_DIST_BACKEND=gloo)
+        local = int(os.environ["VISPEC_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     torch.cuda.set_device(local)
@@ -235,7 +237,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("VISPEC_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:
