@@ -165,6 +165,9 @@ int vispec_set_tree_host(vispec_ctx*, void* stream, const int* tokens_T, const i
    last vispec_verify_accept. */
 int vispec_draft_round(vispec_ctx*, void* stream);
 
+/* second stop token of the current request (`is_llama3`: "<|eot_id|>", spec_model_ours.py:268-269,540-542); call after
+   vispec_begin_request, which clears it; -1 = none */
+int vispec_set_stop_token(vispec_ctx*, void* stream, int token_id);
 /* change the tree size (nodes incl. the root, 1..64) of later rounds: what `model.spec_layer.total_tokens = total_token - 1`
    does after the total_token=-1 autotune of SpecModel.from_pretrained (spec_model_ours.py:179-201).  Trees of more than 32 nodes
    run every verify GEMM in two 32-row passes. */

@@ -662,7 +662,7 @@ def update_inference_inputs(st: LoopState, candidates, best, accept_length, pkv_
 
 def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embeds=None, image_mask=None,
                  max_new_tokens=512, max_length=2048, eos_token_id=2, max_pos=None, scripted_accept=None, position_ids=None,
-                 rope_delta=0, temperature=0.0, seed=0, top_k=0):
+                 rope_delta=0, temperature=0.0, seed=0, top_k=0, stop_token_id=None):
     """SpecModel.specgenerate, temperature 0 (spec_model_ours.py:247-582).
     -> (input_ids, new_token, idx, accept_lengths).  `scripted_accept` (bench-only knob, never used by
     parity tests) is None."""
@@ -706,6 +706,8 @@ def specgenerate(target: TargetLlama, draft: DraftModel, input_ids, inputs_embed
             su = None
         st.accept_lengths.append(acc)
         update_inference_inputs(st, candidates, best, acc, pkv_data, cur_len, hidden_new, sample_p, draft, target.lm_head, sample_u=su)
+        if stop_token_id is not None and stop_token_id in st.input_ids[input_len:].tolist():  # is_llama3, :540-542
+            break
         if eos_token_id in st.input_ids[input_len:].tolist():  # :544
             break
         if st.new_token > max_new_tokens:  # :546

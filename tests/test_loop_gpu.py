@@ -623,3 +623,21 @@ def test_kv_capacity_stop_instead_of_overflow(golden_dir):
     np.testing.assert_array_equal(ar[:n], out[:n])
     with pytest.raises(RuntimeError, match="does not fit"):
         sm.specgenerate(torch.from_numpy(np.full(T["max_pos"] - 20, 5))[None], max_new_tokens=4)
+
+
+def test_is_llama3_second_stop_token(golden_dir):
+    """is_llama3=True (spec_model_ours.py:268-269, 540-542): "<|eot_id|>" among the generated ids ends the request like eos."""
+    from types import SimpleNamespace
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids = g["succ1_ids"]
+    sm, ot, od = build(51, 61, True)
+    full = vo.specgenerate(ot, od, ids, max_new_tokens=40, max_pos=T["max_pos"])[0]
+    eot = int(full[len(ids) + 13])
+    sm.tokenizer = SimpleNamespace(eos_token_id=2, convert_tokens_to_ids=lambda t: eot if t == "<|eot_id|>" else -1)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=40, is_llama3=True, log=True, return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=40, max_pos=T["max_pos"], stop_token_id=eot)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert (new_token, idx, acc) == (o_new, o_idx, o_acc) and len(o_out) < len(full) and eot in o_out[len(ids):]
+    # without the flag the same token does not stop the request
+    out2 = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=40)
+    np.testing.assert_array_equal(out2[0].cpu().numpy(), full)

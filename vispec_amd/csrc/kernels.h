@@ -54,6 +54,7 @@ struct DevState {
   int tree_T;       // nodes in the current tree (total_token, or 1 for the AR baseline)
   int rope_delta;   // Qwen2.5-VL: cached rope_deltas added to every decode position (utils.py:397-402); 0 otherwise
   int kv_cap, draft_cap;  // rows of the target / draft KV caches
+  int stop2;        // second stop token (llama-3 "<|eot_id|>", spec_model_ours.py:268-269,540-542); -1 = none
 };
 #define KV_GUARD_ROWS 64  // rows kept free beyond the next tree (the AR baseline polls `done` only every 16 steps)
 

@@ -248,7 +248,7 @@ __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __res
       sel[jj] = node;
       const int tok = tb.tree_tokens[node];
       if (n + jj < tokens_cap) tokens[n + jj] = tok;
-      if (tok == st->eos_token_id) done |= 1;
+      if (tok == st->eos_token_id || tok == st->stop2) done |= 1;
     }
     for (int jj = a + 1; jj < TREE_RET_W; ++jj) sel[jj] = row[a];
     const int next = am[row[a]];  // token = argmax(sample_p), sample_p = logits[best, accept_length]
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
       sel[jj] = nd;
       const int tok = tb.tree_tokens[nd];
       if (n + jj < tokens_cap) tokens[n + jj] = tok;
-      if (tok == st->eos_token_id) done |= 1;
+      if (tok == st->eos_token_id || tok == st->stop2) done |= 1;
     }
     for (int jj = a + 1; jj < TREE_RET_W; ++jj) sel[jj] = rowp[a];
     for (int jj = 0; jj < TREE_RET_W; ++jj) draft_ids[jj] = jj < a ? tb.tree_tokens[rowp[jj + 1]] : next;

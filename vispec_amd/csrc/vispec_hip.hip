@@ -695,6 +695,7 @@ __global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos, 
     z.eos_token_id = eos;
     z.tree_T = 0;
     z.kv_cap = kv_cap;
+    z.stop2 = -1;
     z.draft_cap = draft_cap;
     *st = z;
   }
@@ -1042,6 +1043,16 @@ extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* to
   return 0;
 }
 
+__global__ void set_stop2_kernel(DevState* st, int tok) {
+  if (threadIdx.x == 0) st->stop2 = tok;
+}
+// is_llama3: "<|eot_id|>" among the generated ids also ends the request (spec_model_ours.py:268-269, 540-542); after begin_request
+extern "C" int vispec_set_stop_token(vispec_ctx* ctx, void* stream, int token_id) {
+  if (!ctx) return fail("null ctx");
+  hipLaunchKernelGGL(set_stop2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, token_id);
+  KCHK();
+  return 0;
+}
 __global__ void set_rope_delta_kernel(DevState* st, int delta) {
   if (threadIdx.x == 0) st->rope_delta = delta;
 }

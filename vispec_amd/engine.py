@@ -341,6 +341,9 @@ class Engine:
         L.check(self.lib.vispec_set_total_token(self.h, int(total_token)))
         self.total_token = int(total_token)
 
+    def set_stop_token(self, token_id: int):
+        L.check(self.lib.vispec_set_stop_token(self.h, self._stream(), int(token_id)))
+
     def set_rope_delta(self, delta: int):
         L.check(self.lib.vispec_set_rope_delta(self.h, self._stream(), int(delta)))
 

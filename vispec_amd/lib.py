@@ -57,6 +57,7 @@ SIGNATURES = {
     "vispec_rmsnorm": (c_int, [P, P, P, P, P, c_int, c_int, c_float]),
     "vispec_set_total_token": (c_int, [P, c_int]),
     "vispec_set_top_k": (c_int, [P, c_int]),
+    "vispec_set_stop_token": (c_int, [P, P, c_int]),
     "vispec_qkv_rope_fused": (c_int, [c_int]),
     "vispec_gemm_qkv_rope": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P]),
     "vispec_rope_append": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P]),

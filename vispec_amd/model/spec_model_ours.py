@@ -240,6 +240,8 @@ class SpecModel:
         eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
         if rope_delta:
             eng.set_rope_delta(rope_delta)
+        if is_llama3:  # :268-269, 540-542
+            eng.set_stop_token(int(self.tokenizer.convert_tokens_to_ids("<|eot_id|>")))
         if draft_embeds is None:
             ids1 = torch.cat([input_ids[0], first.long()])
             demb = torch.nn.functional.embedding(ids1[:-1], self.spec_layer.w.t["embed"]).contiguous()
