@@ -83,7 +83,9 @@ int  vispec_set_kv(vispec_ctx*, void* target_kv, void* draft_kv);
 /* Every GEMM weight the library streams (all pointers in the three weight structs above except embed / norm vectors /
    ad_q / rope tables) is in the "W32" layout: 32-row x 16-k tiles stored as the 1 KiB A-operand image of
    v_mfma_f32_32x32x16_bf16, tiles of a row block contiguous along k (csrc/kernels.h).  vispec_pack_weight converts a
-   row-major nn.Linear weight [N, K] once at load; P must hold vispec_packed_elems(N, K) bf16 elements. */
+   row-major nn.Linear weight [N, K] once at load; P must hold vispec_packed_elems(N, K) bf16 elements.    A gate|up weight used with epilogue 2 (SwiGLU) must be handed over in "SwiGLU order": packed row 32t + c is natural gate row
+   16t + c for c < 16 and natural up row I + 16t + (c - 16) otherwise (I = rows of one half, I % 16 == 0), so that the gate and up
+   values of an output meet in one lane of the epilogue and the GEMM is I/16 equal single-tile workgroups. */
 int vispec_pack_weight(vispec_ctx*, void* stream, const void* W_rowmajor, int N, int K, void* P);
 long long vispec_packed_elems(int N, int K);
 /* fp8 weights (W8A16): Wq is a row-major uint8 matrix of OCP e4m3fn codes; the GEMM computes bf16(scale[n]·(X·Wqᵀ)+bias) with bf16

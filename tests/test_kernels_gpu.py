@@ -79,9 +79,9 @@ def engine():
     return Engine(tcfg, dcfg, tw, dw)
 
 
-def packed(w):
-    from vispec_amd.engine import pack_weight
-    return pack_weight(tb(w))
+def packed(w, swiglu=False):
+    from vispec_amd.engine import pack_weight, swiglu_order
+    return pack_weight(swiglu_order(tb(w)) if swiglu else tb(w))
 
 
 def test_pack_weight_layout(lib):
@@ -104,8 +104,8 @@ def test_pack_weight_layout(lib):
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("bias", [False, True])
 def test_gemm_skinny(lib, engine, M, N, K, epi, bias):
-    if epi == 2 and N % 32:
-        pytest.skip("SwiGLU needs N % 32 == 0")
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
     rng = np.random.default_rng(M * 131 + N * 7 + K + epi)
     o = vo.Ops(bf16=True)
     x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
@@ -123,7 +123,7 @@ def test_gemm_skinny(lib, engine, M, N, K, epi, bias):
     else:
         gu = o.linear(x, w, b)
         want = o.silu_mul(gu[:, :N], gu[:, N:])
-    X, W, B, R = tb(x), packed(w), (tb(b) if bias else None), tb(r)
+    X, W, B, R = tb(x), packed(w, swiglu=(epi == 2)), (tb(b) if bias else None), tb(r)
     Y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev())
     L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(X), K, p(W), p(B), p(Y), N, p(R), N, M, N, K, epi))
     torch.cuda.synchronize()
@@ -132,7 +132,7 @@ def test_gemm_skinny(lib, engine, M, N, K, epi, bias):
     # ... and a SwiGLU output that is itself ~0 (|gate| ~ 1e-5 after cancelling O(1) products over K terms) has no relative
     # accuracy to speak of in ANY summation order: absolute floor of 1e-4 against outputs of O(1)
     assert_bf16_close(fn(Y), want, min_exact=0.90 if epi == 2 else 0.97, ulps=2 if epi == 2 else 1, scale=scale,
-                      outlier_mult=3 if epi == 2 else 2, atol=1e-4 if epi == 2 else 1e-6)
+                      outlier_mult=3 if epi == 2 else 2, atol=1e-4 if epi == 2 else 1e-6, outlier_frac=5e-5 if epi == 2 else 2e-5)
 
 
 def test_gemm_strided_output_and_padding_rows_untouched(lib, engine):
@@ -324,8 +324,8 @@ def test_gemm_other_model_shapes(lib, engine, M, N, K):
 def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
     """W8A16: e4m3 weights (per-output-channel scale), bf16 activations; Y = bf16(scale * (X · q^T) + b) (+ epilogue)."""
     from vispec_amd.engine import pack_weight_fp8, quantize_fp8
-    if epi == 2 and N % 32:
-        pytest.skip("SwiGLU needs N % 32 == 0")
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
     rng = np.random.default_rng(N * 3 + K + M + epi)
     o = vo.Ops(bf16=True)
     x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
@@ -341,7 +341,8 @@ def test_gemm_fp8_weights(lib, engine, M, N, K, epi):
     assert (qp != qo).mean() < 2e-2 and np.abs(qp - qo).max() <= np.abs(qo).max() / 8
     np.testing.assert_allclose(sc.cpu().numpy(), so, rtol=2e-7)
     qo, so = qp, sc.cpu().numpy()  # the GEMM itself is checked on the product's own codes
-    P8 = pack_weight_fp8(q_u8)
+    from vispec_amd.engine import swiglu_order
+    P8 = pack_weight_fp8(swiglu_order(q_u8) if epi == 2 else q_u8)
     scale = None
     if epi == 0:
         want = o.linear(x, (qo, so), b)

@@ -307,12 +307,12 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
   hipLaunchKernelGGL((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
                      T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{})
-  if (epi == EPI_SWIGLU) {
-    if (N % 32) return fail("gemm_skinny: SwiGLU needs N %% 32 == 0");
+  if (epi == EPI_SWIGLU) {  // weight in "SwiGLU order" (vispec_pack_weight docs): N/16 workgroups of one 32-row tile each
+    if (N % 16) return fail("gemm_skinny: SwiGLU needs N %% 16 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
     prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
-    if (o.wscale) VISPEC_GEMM(2, EPI_SWIGLU, true, dim3(tiles, 1), tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else VISPEC_GEMM(2, EPI_SWIGLU, false, dim3(tiles, 1), tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    if (o.wscale) VISPEC_GEMM(1, EPI_SWIGLU, true, dim3(N / 16, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM(1, EPI_SWIGLU, false, dim3(N / 16, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;

@@ -100,6 +100,17 @@ def qkv_rope_order(w: torch.Tensor, n_rope_heads: int, head_dim: int = 128) -> t
     return w.index_select(0, src).contiguous()
 
 
+def swiglu_order(w: torch.Tensor) -> torch.Tensor:
+    """gate|up weight (or code matrix) [2I, K] -> "SwiGLU order" (include/vispec_hip.h: vispec_pack_weight): packed row 32t + c is
+    gate row 16t + c (c < 16) or up row I + 16t + (c - 16)."""
+    I = w.shape[0] // 2
+    assert w.shape[0] == 2 * I and I % 16 == 0
+    r = torch.arange(2 * I, device=w.device)
+    t, c = r // 32, r % 32
+    src = torch.where(c < 16, 16 * t + c, I + 16 * t + (c - 16))
+    return w.index_select(0, src).contiguous()
+
+
 E4M3_MAX = 448.0
 
 
@@ -247,7 +258,7 @@ class Engine:
                     pk, sc, cd = {}, {}, {}
                     for k in GEMM_T:
                         q, s_ = quantize_fp8(lw[k])
-                        qp = qkv_rope_order(q, tcfg.num_heads + tcfg.num_kv_heads) if k == "wqkv" else q
+                        qp = qkv_rope_order(q, tcfg.num_heads + tcfg.num_kv_heads) if k == "wqkv" else (swiglu_order(q) if k == "wgu" else q)
                         pk[k], sc[k], cd[k] = pack_weight_fp8(qp), s_, q
                         lw[k] = (q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16)
                     tw.packed8.append(pk)
@@ -260,11 +271,13 @@ class Engine:
             raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
         if target_weight_dtype == "bf16" and not hasattr(tw, "packed"):
             nrh = tcfg.num_heads + tcfg.num_kv_heads
-            tw.packed = [{k: pack_weight(qkv_rope_order(lw[k], nrh) if k == "wqkv" else lw[k]) for k in GEMM_T} for lw in tw.layers]
+            order = lambda k, w: qkv_rope_order(w, nrh) if k == "wqkv" else (swiglu_order(w) if k == "wgu" else w)
+            tw.packed = [{k: pack_weight(order(k, lw[k])) for k in GEMM_T} for lw in tw.layers]
             tw.p_lm_head = pack_weight(tw.lm_head)
         GEMM_D = ("fc_w", "imgfc_w", "wqkv", "wo", "wgu", "wdown", "ad_wkv", "ad_wo")
         if not hasattr(dw, "packed"):
-            dw.packed = {k: pack_weight(qkv_rope_order(dw.t[k], 2 * dcfg.num_heads) if k == "wqkv" else dw.t[k]) for k in GEMM_D}
+            dorder = lambda k, w: qkv_rope_order(w, 2 * dcfg.num_heads) if k == "wqkv" else (swiglu_order(w) if k == "wgu" else w)
+            dw.packed = {k: pack_weight(dorder(k, dw.t[k])) for k in GEMM_D}
         fp8 = target_weight_dtype == "fp8"
         for i, lw in enumerate(tw.layers):
             pk = tw.packed8[i] if fp8 else tw.packed[i]
