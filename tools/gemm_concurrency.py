@@ -12,7 +12,7 @@ mk = lambda: Engine(tcfg, dcfg, TargetWeights.from_state_dict(tcfg, synth.make_t
 NS = 4
 engs = [mk() for _ in range(NS)]  # one ctx (split-K workspace) per stream
 p = lambda t: C.c_void_p(t.data_ptr())
-M = 30
+M = int(os.environ.get("M", "30"))
 SHAPES = [("qkv", 12288, 4096, 0), ("o_proj", 4096, 4096, 0), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 0)]
 NB = 6
 W = {n: [pack_weight((torch.randn((2 if e == 2 else 1) * N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(NB)] for n, N, K, e in SHAPES}

@@ -59,7 +59,7 @@ struct DevState {
 #define KV_GUARD_ROWS 64  // rows kept free beyond the next tree (the AR baseline polls `done` only every 16 steps)
 
 // ------------------------------------------------------------------------------------------------
-// Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 32; every weight byte is streamed from HBM exactly once per call)
+// Skinny GEMM  Y[M,N] = X[M,K] · W[N,K]^T   (M <= 32·MT, MT in {1,2}; every weight byte is streamed from HBM exactly once per call)
 //
 // Weight layout "W32" (built once at load by pack_w32_kernel): the matrix is cut into tiles of 32 rows x 16 k; a tile is
 // stored as the 1 KiB image of the A operand of v_mfma_f32_32x32x16_bf16 — lane l holds W[32t + (l&31)][16c + 8(l>>5) .. +8] —
@@ -68,10 +68,15 @@ struct DevState {
 //   grid  = (row blocks, S)   S = split-K over workgroups (small N would otherwise leave most of the 256 CUs idle)
 //   block = NW waves, each owning a contiguous K range of the workgroup's split; register double-buffering keeps UNROLL
 //           loads per operand in flight behind the MFMAs; waves are reduced through LDS in a fixed order (deterministic).
-//   X (activations, L2-resident) is read as the B operand directly: lane (m = l&31, hi) loads X[m][16c + 8hi .. +8].
+//   X (activations, L2-resident) is fetched in whole 128-B lines and re-shaped into the B operand through a per-wave LDS image
+//   (MT images when M > 32: the weight tile in registers then feeds MT MFMAs).
 //   D[i = n][j = m]: a lane ends with 4 groups of 4 consecutive n for its m -> 8-byte bf16 / 16-byte fp32 stores.
-// Epilogues: NONE / RESIDUAL / SWIGLU (second stream = the matching `up` block) write bf16 with the reference's rounding
-// points; PARTIAL writes fp32 partial sums [S][32][N] that splitk_reduce_kernel finishes (bias, residual, RMSNorm fused).
+// Epilogues (bf16 results carry the reference's rounding points):
+//   NONE / RESIDUAL   plain
+//   SWIGLU            NT = 1: weight in "SwiGLU order" (16 gate rows + the 16 up rows of the same outputs per tile), act closes in-lane;
+//                     NT = 2 (unused by the library now): second stream = the matching `up` block
+//   PARTIAL           fp32 partial sums [S][32·MT][N] that splitk_reduce_kernel finishes (bias, residual, RMSNorm fused)
+//   ROPE              q|k|v projection: rotary + KV append (weight in "rope order", see RopeEpi)
 // ------------------------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_PARTIAL = 3, EPI_ROPE = 4 };
 

@@ -352,8 +352,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 }
 
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
-                          int epi, const GemmOut& o, int force_split = -1, int force_nw = 0) {
-  (void)force_nw;
+                          int epi, const GemmOut& o, int force_split = -1) {
   if (M <= 32) return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   if (M <= 64) return launch_gemm_mt<2>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   return fail("gemm_skinny: M must be in [1,64]");
