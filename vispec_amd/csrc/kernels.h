@@ -613,6 +613,7 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
   const int nchunk = (key_end - key0 + ATT_CHUNK - 1) / ATT_CHUNK;
   const float scale = 0.08838834764831845f;  // 1/sqrt(128)
   const float sqrt_hd = 11.313708498984761f;
+  const float rsqrt_hd = 1.0f / sqrt_hd;
   // staging map: thread -> 4 x 16 B of K and of V per chunk (row = s>>4, 16-B column = s&15), rows past the end are
   // clamped to the last valid key (never visible: masked by key >= n_total) so every load stays unconditional
   const int last_key = n_total - 1;
@@ -676,15 +677,42 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
           S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
         }
         float mx = NEG_INF;
+        // eager scores: bf16(bf16(S) / sqrt(hd)).  The quotient comes from one FMA-corrected reciprocal multiply — bit-identical to
+        // the IEEE division for every bf16 input in the normal range (tools/div_check.hip, exhaustive) at a third of the instructions.
+        if (kbase + 32 <= n_prefix) {  // wave-uniform: the whole 32-key tile lies in the committed context, every key visible
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float sc = EAGER ? rdbf(rdbf(S[r]) / sqrt_hd) : S[r] * scale;
-          bool vis = key < n_prefix;
-          if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
-          sc = vis ? sc : NEG_INF;
-          S[r] = sc;
-          mx = fmaxf(mx, sc);
+          for (int r = 0; r < 16; ++r) {
+            float sc;
+            if (EAGER) {
+              const float xb = rdbf(S[r]);
+              float q = xb * rsqrt_hd;
+              q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+              sc = rdbf(q);
+            } else {
+              sc = S[r] * scale;
+            }
+            S[r] = sc;
+            mx = fmaxf(mx, sc);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float sc;
+            if (EAGER) {
+              const float xb = rdbf(S[r]);
+              float q = xb * rsqrt_hd;
+              q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+              sc = rdbf(q);
+            } else {
+              sc = S[r] * scale;
+            }
+            bool vis = key < n_prefix;
+            if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
+            sc = vis ? sc : NEG_INF;
+            S[r] = sc;
+            mx = fmaxf(mx, sc);
+          }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
