@@ -13,13 +13,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NEG_INF (-__builtin_huge_valf())
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// fp32 -> bf16 round-to-nearest-even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction); the casts below
+// compile to it.  (The bit-twiddling form costs 4-5 VALU instructions per value and sat in every epilogue and attention chunk.)
+typedef __attribute__((ext_vector_type(2))) float f32x2_cvt;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cvt;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return *reinterpret_cast<const bf16_t*>(&b);
 }
-__device__ __forceinline__ float rdbf(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float rdbf(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const f32x2_cvt v = {lo, hi};
+  const bf16x2_cvt r = __builtin_convertvector(v, bf16x2_cvt);
+  return *reinterpret_cast<const unsigned*>(&r);
+}
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return *reinterpret_cast<bf16x8*>(&v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
