@@ -726,20 +726,23 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
         const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
         float psum = 0.f;
         unsigned pb[8];
+        const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;  // a row with nothing visible yet: exp(-inf - 0) = 0, never inf - inf
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float p0 = (S[r] == NEG_INF) ? 0.f : __expf(S[r] - m_new);
-          const float p1 = (S[r + 1] == NEG_INF) ? 0.f : __expf(S[r + 1] - m_new);
+          const float p0 = __expf(S[r] - m_sub);
+          const float p1 = __expf(S[r + 1] - m_sub);
           psum += p0 + p1;
           pb[r >> 1] = pack2(p0, p1);
         }
         psum += __shfl_xor(psum, 32);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__any(alpha != 1.0f)) {  // the running maximum settles after the first chunks: most chunks rescale nothing
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
+          for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) O[hb][r] *= alpha;
+            for (int r = 0; r < 16; ++r) O[hb][r] *= alpha;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
           const uint4 pB = make_uint4(pb[kb * 4 + 0], pb[kb * 4 + 1], pb[kb * 4 + 2], pb[kb * 4 + 3]);
