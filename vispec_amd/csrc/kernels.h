@@ -502,30 +502,51 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                             bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
                                                             bf16_t* __restrict__ normed, int ldn, float eps) {
+  // Latency-bound (a few MB out of L2 per launch, 80 launches per round): every load of a row chunk — up to 8 partial slabs with
+  // clamped (always valid) slab indices, residual, bias, norm weight — is issued before the first use, and a row that fits one
+  // pass of the block (N <= 4 x threads: every model here) keeps its values in registers across the block-wide sum of squares.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-  float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable) when a norm follows
+  float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable): only for rows longer than one pass
   __shared__ float partsum[16];
   const int m = blockIdx.x;
   const int nthreads = blockDim.x;
+  const bool one_pass = N <= nthreads * 4;
   float ss = 0.f;
+  float keep[4] = {0.f, 0.f, 0.f, 0.f};
+  uint2 wkeep = make_uint2(0, 0);
   for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
-    float4 a = *reinterpret_cast<const float4*>(part + (size_t)m * N + n);
-    for (int s = 1; s < S; ++s) {
-      const float4 b = *reinterpret_cast<const float4*>(part + ((size_t)s * Mpad + m) * N + n);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    float4 p[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) p[sl] = *reinterpret_cast<const float4*>(part + ((size_t)min(sl, S - 1) * Mpad + m) * N + n);
+    uint2 rv = make_uint2(0, 0), bv = make_uint2(0, 0);
+    if (R) rv = *reinterpret_cast<const uint2*>(R + (size_t)m * ldr + n);
+    if (bias) bv = *reinterpret_cast<const uint2*>(bias + n);
+    if (normed && one_pass) wkeep = *reinterpret_cast<const uint2*>(norm_w + n);
+    float4 a = p[0];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl)
+      if (sl < S) { a.x += p[sl].x; a.y += p[sl].y; a.z += p[sl].z; a.w += p[sl].w; }  // fixed order s = 0, 1, ... (deterministic)
+    for (int sl = 8; sl < S; ++sl) {  // (never taken by the library: S <= 8)
+      const float4 q = *reinterpret_cast<const float4*>(part + ((size_t)sl * Mpad + m) * N + n);
+      a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
     }
+    const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
+    const bf16_t* be = reinterpret_cast<const bf16_t*>(&bv);
     float o[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y = o[r];
-      if (bias) y += bf2f(bias[n + r]);
+      if (bias) y += bf2f(be[r]);
       y = rdbf(y);
-      if (R) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+      if (R) y = rdbf(bf2f(re[r]) + y);
       o[r] = y;
       ss += y * y;
     }
     if (Y) *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-    if (normed) *reinterpret_cast<float4*>(hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if (normed) {
+      if (one_pass) { keep[0] = o[0]; keep[1] = o[1]; keep[2] = o[2]; keep[3] = o[3]; }
+      else *reinterpret_cast<float4*>(hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
   if (!normed) return;
   ss = wave_sum(ss);
@@ -534,6 +555,16 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   float tot = 0.f;
   for (int w = 0; w < (nthreads >> 6); ++w) tot += partsum[w];
   const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+  if (one_pass) {
+    const int n = threadIdx.x * 4;
+    if (n < N) {
+      const bf16_t* we = reinterpret_cast<const bf16_t*>(&wkeep);
+      const float o0 = bf2f(we[0]) * rdbf(keep[0] * inv), o1 = bf2f(we[1]) * rdbf(keep[1] * inv);
+      const float o2 = bf2f(we[2]) * rdbf(keep[2] * inv), o3 = bf2f(we[3]) * rdbf(keep[3] * inv);
+      *reinterpret_cast<uint2*>(normed + (size_t)m * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
+    }
+    return;
+  }
   for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     const float4 h = *reinterpret_cast<const float4*>(hrow + n);
     const uint2 wv = *reinterpret_cast<const uint2*>(norm_w + n);
