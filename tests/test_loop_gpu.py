@@ -641,3 +641,43 @@ def test_is_llama3_second_stop_token(golden_dir):
     # without the flag the same token does not stop the request
     out2 = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=40)
     np.testing.assert_array_equal(out2[0].cpu().numpy(), full)
+
+
+@pytest.mark.parametrize("temperature,top_k", [(0.0, 0), (1.0, 0), (5.0, 6)])
+def test_stagewise_helpers_reproduce_the_reference_loop_body(golden_dir, temperature, top_k):
+    """The reference's loop written against vispec.model.utils (initialize_tree -> [tree_decoding -> evaluate_posterior ->
+    update_inference_inputs]*, spec_model_ours.py:455-547) runs unchanged on vispec_amd.model.utils and yields the tokens of
+    the fused specgenerate (and of the oracle), greedy and sampling."""
+    from vispec_amd.model import utils as U
+    from vispec_amd.model.kv_cache import initialize_past_key_values
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    ids = g["succ0_ids"]
+    sm, ot, od = build(50, 60, True)
+    want, _, _, want_acc = sm.specgenerate(torch.from_numpy(ids)[None], temperature=temperature, top_k=top_k, seed=3, max_new_tokens=24, log=True,
+                                           return_acceptance_len=True)
+    o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=24, max_pos=T["max_pos"], temperature=temperature, seed=3, top_k=top_k)
+    np.testing.assert_array_equal(want[0].cpu().numpy(), o_out)
+    # ---- the reference's loop body, verbatim in structure
+    lp = U.prepare_logits_processor(temperature=temperature, top_k=top_k, seed=3) if temperature > 1e-5 else None
+    input_ids = torch.from_numpy(ids)[None].cuda()
+    sm.spec_layer.reset_kv()
+    pkv, pkv_data, cur = initialize_past_key_values(sm.base_model)
+    input_len = input_ids.shape[1]
+    U.reset_tree_mode(sm)
+    draft_tokens, retrieve_indices, tree_mask, tree_position_ids, logits, hidden_state, sample_token = U.initialize_tree(input_ids, sm, pkv, lp)
+    new_token, acc = 0, []
+    for idx in range(40):
+        sm.base_model.model.tree_mask = tree_mask
+        draft_tokens = draft_tokens.to(input_ids.device)
+        logits, hidden_state_new, outputs = U.tree_decoding(sm, draft_tokens, pkv, tree_position_ids, input_ids, retrieve_indices)
+        padding = torch.zeros(1, 1, dtype=torch.long, device=input_ids.device) - 1
+        dt = torch.cat((draft_tokens, padding), dim=1)
+        candidates = dt[0, retrieve_indices]
+        best_candidate, accept_length, sample_p = U.evaluate_posterior(logits, candidates, lp, model=sm)
+        acc.append(int(accept_length))
+        input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state, sample_token = U.update_inference_inputs(
+            input_ids, candidates, best_candidate, accept_length, retrieve_indices, lp, new_token, pkv_data, cur, sm, hidden_state_new, sample_p)
+        if sm.tokenizer.eos_token_id in input_ids[0, input_len:].tolist() or new_token > 24:
+            break
+    np.testing.assert_array_equal(input_ids[0].cpu().numpy(), want[0].cpu().numpy())
+    assert acc == want_acc == o_acc and int(cur[0]) == input_ids.shape[1]

@@ -1124,6 +1124,15 @@ extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
   out[5] = h.next_token; out[6] = h.draft_len; out[7] = h.n_leaf;
   return 0;
 }
+extern "C" int vispec_get_last_accept_host(vispec_ctx* ctx, void* stream, int* out2) {
+  if (!ctx || !out2) return fail("null");
+  DevState h;
+  HIPCHK(hipMemcpyAsync(&h, ctx->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  out2[0] = h.best;
+  out2[1] = h.accept_len;
+  return 0;
+}
 extern "C" int vispec_get_tokens_host(vispec_ctx* ctx, void* stream, int* out, int n) {
   if (!ctx || !out || n < 0 || n > ctx->tokens_cap) return fail("bad args");
   HIPCHK(hipMemcpyAsync(out, ctx->tokens, sizeof(int) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -411,6 +411,12 @@ class Engine:
         k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
         return dict(zip(k, list(out)))
 
+    def last_accept(self):
+        """(best_candidate, accept_length) of the last accept."""
+        out = (C.c_int * 2)()
+        L.check(self.lib.vispec_get_last_accept_host(self.h, self._stream(), out))
+        return int(out[0]), int(out[1])
+
     def tokens(self, n: int) -> np.ndarray:
         out = np.zeros(n, np.int32)
         L.check(self.lib.vispec_get_tokens_host(self.h, self._stream(), out.ctypes.data_as(C.c_void_p), int(n)))

@@ -8,8 +8,30 @@ import numpy as np
 import torch
 
 
-def prepare_logits_processor(temperature=0.0, repetition_penalty=0.0, top_p=0.0, top_k=0):
-    raise NotImplementedError("sampling path (utils.py:39-55, 453-493) is a later row of SURVEY.md §8(f); use temperature=0")
+class LogitsProcessorConfig:
+    """What utils.py:39-55 builds as a LogitsProcessorList, as plain numbers for the device-side sampler: temperature, then
+    TopK when top_k > 0.  `seed` selects the counter-based random stream (the reference draws from torch's global generator)."""
+
+    def __init__(self, temperature, top_k, seed=0):
+        self.temperature, self.top_k, self.seed = float(temperature), int(top_k), int(seed)
+
+
+def prepare_logits_processor(temperature=0.0, repetition_penalty=0.0, top_p=0.0, top_k=0, seed=0):
+    """utils.py:39-55.  The reference calls it only for temperature > 1e-5 and passes None (greedy) otherwise."""
+    if repetition_penalty > 1.0:
+        raise NotImplementedError("RepetitionPenaltyLogitsProcessor needs input_ids; the reference calls its list with None (utils.py:286,454)")
+    if 1e-8 <= top_p < 1.0:
+        raise NotImplementedError("TopPLogitsWarper cannot run on the 3-D tree logits (HF scatters along dim 1; the reference raises too)")
+    return LogitsProcessorConfig(temperature if temperature > 1e-5 else 0.0, top_k if temperature > 1e-5 else 0, seed)
+
+
+def _enable(model, logits_processor):
+    eng = model.engine
+    if logits_processor is None or logits_processor.temperature <= 1e-5:
+        eng.set_sampling(0.0, 0)
+        return False
+    eng.set_sampling(logits_processor.temperature, logits_processor.seed, top_k=logits_processor.top_k)
+    return True
 
 
 def reset_tree_mode(model):  # utils.py:330-338
@@ -27,10 +49,12 @@ def reset_past_key_values(passed_key_values):  # utils.py:341-358
 def initialize_tree(input_ids, model, past_key_values, logits_processor, inputs_embeds=None, embed_weights=None,
                     image_mask=None, **kwargs):
     """utils.py:266-327: target prefill -> first token -> first topK_genrate."""
-    if logits_processor is not None:
-        prepare_logits_processor()
+    sampling = _enable(model, logits_processor)
     outputs, orig, hidden_states = model(input_ids, past_key_values=past_key_values, output_orig=True, inputs_embeds=inputs_embeds)
-    token = model._first_token(orig)  # argmax(orig[:, -1]) on the device, first max wins
+    # argmax(orig[:, -1]) on the device, first max wins (:290) / multinomial(softmax(lp(orig[:, -1]))) (:284-288)
+    token = model.engine.sample_row(orig.reshape(-1, orig.shape[-1])[-1]) if sampling else model._first_token(orig)
+    # the device-side round state starts here (the reference keeps it in Python locals): prompt ids, n = L, new_token = 0
+    model.engine.begin_request(input_ids[0].cpu().numpy(), int(kwargs.get("max_new_tokens", 1 << 20)))
     input_ids = torch.cat((input_ids, token.to(input_ids.device).long()[None]), dim=1)
     embeds = inputs_embeds if inputs_embeds is not None else model._last_embeds
     draft_tokens, retrieve_indices, tree_mask, tree_position_ids = model.spec_layer.topK_genrate(
@@ -60,11 +84,18 @@ def tree_decoding(model, tree_candidates, past_key_values, tree_position_ids, in
     return logits, hidden[None], None
 
 
-def evaluate_posterior(logits, candidates, logits_processor):
-    """utils.py:415-451 (greedy).  Pure function of its arguments, evaluated with torch integer ops on the device the
-    logits live on; the fused loop uses the HIP verify_accept kernel instead."""
-    if logits_processor is not None:
-        prepare_logits_processor()
+def evaluate_posterior(logits, candidates, logits_processor, model=None):
+    """utils.py:415-493.  Greedy: a pure function of its arguments (torch integer ops; the fused loop uses the HIP verify_accept
+    kernel instead).  Sampling: the sequential rejection runs on the device over the logits of the last tree_decoding — pass
+    `model`; the accept step is then already done when update_inference_inputs is called (sample_p stays on the device: None)."""
+    if logits_processor is not None and logits_processor.temperature > 1e-5:
+        if model is None:
+            raise ValueError("the sampling branch of evaluate_posterior runs on the device: pass model=")
+        eng = model.engine
+        eng.accept()
+        model._accept_done = True
+        best, acc = eng.last_accept()
+        return torch.tensor(best), acc, None
     posterior_mask = (candidates[:, 1:].to(logits.device) == torch.argmax(logits[:, :-1], dim=-1)).int()
     cal = torch.cumprod(posterior_mask, dim=1).sum(dim=1)
     accept_length = cal.max()
@@ -78,7 +109,9 @@ def update_inference_inputs(input_ids, candidates, best_candidate, accept_length
     """utils.py:496-593: commit the accepted path (tokens, KV compaction, lengths), sample the next token and run the
     next topK_genrate — on the device (vispec_accept + vispec_draft_round)."""
     eng = model.engine
-    eng.accept()
+    if not getattr(model, "_accept_done", False):
+        eng.accept()
+    model._accept_done = False
     eng.draft_round()
     st = eng.state()
     a = int(st["accept_len"])
