@@ -527,10 +527,30 @@ def g11_update_inference_inputs():
     np.savez_compressed(os.path.join(OUT, "g11_update.npz"), **out)
 
 
+def g12_kvcache():
+    """KVCache.cat / .copy / .shape / current_length (kv_cache.py:4-66) on a CPU slab: a cat of the prompt rows, a cat of T tree
+    rows, then the compaction copy of an accepted path."""
+    rng = np.random.default_rng(1200)
+    data = torch.zeros(1, 2, 16, 4)
+    cur = torch.zeros((), dtype=torch.long)
+    kv = KVCache(data, cur)
+    a = t(rng.standard_normal((1, 2, 5, 4)).astype(np.float32))
+    b = t(rng.standard_normal((1, 2, 6, 4)).astype(np.float32))
+    v1 = kv.cat(a).numpy().copy()  # the returned views alias the slab: snapshot them before the next in-place op
+    s1 = tuple(kv.shape)
+    v2 = kv.cat(b).numpy().copy()
+    s2 = tuple(kv.shape)
+    d2 = data.clone()
+    idx = torch.tensor([5, 7, 10])
+    kv.copy(idx, 5)
+    np.savez_compressed(os.path.join(OUT, "g12_kvcache.npz"), a=a.numpy(), b=b.numpy(), v1=v1, s1=np.array(s1), v2=v2,
+                        s2=np.array(s2), d2=d2.numpy(), idx=idx.numpy(), d3=data.numpy().copy(), len3=np.int64(int(cur)), s3=np.array(tuple(kv.shape)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

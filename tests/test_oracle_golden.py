@@ -255,3 +255,24 @@ def test_g11_update_inference_inputs(golden_dir):
         np.testing.assert_array_equal(seen["hidden"], g[f"o_hidden{i}"])
         np.testing.assert_array_equal(seen["ids"], g[f"o_draft_ids{i}"])
         assert seen["sampling"] == samp and (st.draft_tokens, st.tree_position_ids) == ("dt", "tp")
+
+
+def test_g12_kvcache_class_matches_reference(golden_dir):
+    """vispec_amd.model.kv_cache.KVCache (the host-side mirror of kv_cache.py:4-66) against the reference's own class on a CPU slab:
+    cat returns the [0, len) view and advances the length, copy gathers the accepted rows behind prev_length."""
+    torch = pytest.importorskip("torch")
+    from vispec_amd.model.kv_cache import KVCache
+    g = load(golden_dir, "g12_kvcache.npz")
+    data = torch.zeros(1, 2, 16, 4)
+    cur = torch.zeros((), dtype=torch.long)
+    kv = KVCache(data, cur)
+    v1 = kv.cat(torch.from_numpy(g["a"]))
+    np.testing.assert_array_equal(v1.numpy(), g["v1"])
+    assert tuple(kv.shape) == tuple(g["s1"])
+    v2 = kv.cat(torch.from_numpy(g["b"]))
+    np.testing.assert_array_equal(v2.numpy(), g["v2"])
+    assert tuple(kv.shape) == tuple(g["s2"])
+    np.testing.assert_array_equal(data.numpy(), g["d2"])
+    kv.copy(torch.from_numpy(g["idx"]), 5)
+    np.testing.assert_array_equal(data.numpy(), g["d3"])
+    assert int(cur) == int(g["len3"]) and tuple(kv.shape) == tuple(g["s3"])
