@@ -107,6 +107,9 @@ int vispec_gemm_skinny_tune(vispec_ctx*, int variant, void* stream, const void* 
                             int M, int N, int K);
 /* LlamaRMSNorm (cnets_ours.py:513-527, modeling_llama_kv.py:104-133) */
 int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps);
+/* SwiGLU activation of a gate|up block [M, 2I] (row stride ld): out[M, I] = bf16(bf16(silu(gate)) * up) — the prefill side of
+   LlamaMLP (modeling_llama_kv.py:240-262), where the projections themselves are library GEMMs; any M */
+int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I);
 /* rotary (cnets_ours.py:104-119) on fused qkv rows + append K,V to a [H_kv, S_max, hd] cache at rows
    *kv_base_dev + i ; positions = *pos_base_dev + pos_off_dev[i] (pos_off_dev may be NULL = i). Q is rotated in place. */
 int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cos, const void* sin,

@@ -575,6 +575,25 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   }
 }
 
+// SwiGLU activation of a [M, 2I] gate|up row block (prefill side: the projections there are library GEMMs):
+// out = bf16( bf16(silu(gate)) * up ), the rounding points of F.silu(g) * u on bf16 tensors.  8 outputs per thread.
+__global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict__ gu, int ld, bf16_t* __restrict__ out, int ldo, int I) {
+  const bf16_t* g = gu + (size_t)blockIdx.y * ld;
+  bf16_t* o = out + (size_t)blockIdx.y * ldo;
+  const int d = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (d >= I) return;
+  const uint4 gv = *reinterpret_cast<const uint4*>(g + d), uv = *reinterpret_cast<const uint4*>(g + I + d);
+  const bf16_t* ge = reinterpret_cast<const bf16_t*>(&gv);
+  const bf16_t* ue = reinterpret_cast<const bf16_t*>(&uv);
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float y = bf2f(ge[j]);
+    r[j] = rdbf(y / (1.0f + __expf(-y))) * bf2f(ue[j]);
+  }
+  *reinterpret_cast<uint4*>(o + d) = make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // RMSNorm: y = w * bf16( x * rsqrt(mean(x^2) + eps) )     one workgroup per row
 // ------------------------------------------------------------------------------------------------

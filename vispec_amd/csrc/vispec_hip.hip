@@ -586,6 +586,13 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 extern "C" int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps) {
   return launch_rmsnorm((hipStream_t)stream, X, w, Y, M, D, eps);
 }
+extern "C" int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I) {
+  if (M < 1 || I % 8 || ld % 8 || ldo % 8) return fail("silu_mul: I, ld, ldo must be multiples of 8");
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((I / 8 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gate_up, ld, (bf16_t*)out,
+                     ldo, I);
+  KCHK();
+  return 0;
+}
 extern "C" int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cosT,
                                   const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache,
                                   void* v_cache, int s_max, const int* kv_base_dev) {

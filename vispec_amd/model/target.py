@@ -15,20 +15,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import ctypes as C
+
+from .. import lib as L
 from ..engine import Engine, TargetConfig, TargetWeights
-
-
-def _rmsnorm(x, w, eps):
-    xf = x.float()
-    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
-    return w * xf.to(x.dtype)
-
-
-def _rope(x, cos, sin):
-    # x [S, H, hd]; cos/sin [S, hd] in the model dtype: (x*cos) + (rotate_half(x)*sin), every op rounding to bf16
-    half = x.shape[-1] // 2
-    rot = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
-    return (x * cos[:, None, :]) + (rot * sin[:, None, :])
 
 
 _sdpa_lock = __import__("threading").Lock()
@@ -143,31 +133,46 @@ class TargetLM:
     def prefill(self, inputs_embeds: torch.Tensor, all_logits: bool = False, position_ids: Optional[torch.Tensor] = None):
         """inputs_embeds [L, D] bf16 -> (logits fp32 [L or 1, V], hidden [L, D] post-final-norm); K/V rows [0, L)
         of every layer are written into the engine's KV buffer (KVCache.cat semantics, modeling_llama_kv.py:583-594).
-        position_ids: None (0..L-1) or [3, L] multimodal rotary positions (Qwen2.5-VL)."""
+        position_ids: None (0..L-1) or [3, L] multimodal rotary positions (Qwen2.5-VL).
+
+        The prefill is MFMA-bound: its GEMMs (hipBLASLt) and attention (SDPA) stay PyTorch ops.  The element-wise steps between
+        them — RMSNorm, rotary + KV append, SwiGLU — run as the library's kernels (one launch each instead of ~6 / ~12 / 2 torch ops,
+        same rounding points as the decode path): 11 launches per layer instead of ~35, which also keeps the host thread of a lane
+        from holding the interpreter while other lanes wait to issue their rounds."""
         c, eng = self.cfg, self.engine
-        x = inputs_embeds.to(self.dtype)
+        lib, st = eng.lib, eng._stream()
+        x = inputs_embeds.to(self.dtype).contiguous()
         Ln = x.shape[0]
         H, Hk, hd = c.num_heads, c.num_kv_heads, c.head_dim
+        QKV = (H + 2 * Hk) * hd
         if position_ids is not None and position_ids.dim() == 2:
-            cos, sin = self.mrope_cos_sin(position_ids)
+            cos, sin = self.mrope_cos_sin(position_ids)  # per-request tables [L, hd]: row m is the rotary of prompt position m
+            cos, sin = cos.contiguous(), sin.contiguous()
         else:
-            cos, sin = eng.t_cos[:Ln], eng.t_sin[:Ln]
+            cos, sin = eng.t_cos, eng.t_sin
         kv = eng.target_kv
+        S = kv.shape[3]
+        p = lambda t: C.c_void_p(t.data_ptr())
+
+        def rmsnorm(t, w):
+            out = torch.empty_like(t)
+            L.check(lib.vispec_rmsnorm(eng.h, st, p(t), p(w), p(out), Ln, c.hidden_size, c.rms_norm_eps))
+            return out
+
         for i, lw in enumerate(self.w.layers):
-            h = _rmsnorm(x, lw["ln1"], c.rms_norm_eps)
-            qkv = F.linear(h, lw["wqkv"], lw["bqkv"])
-            q, k, v = qkv.split([H * hd, Hk * hd, Hk * hd], dim=-1)
-            q = _rope(q.view(Ln, H, hd), cos, sin).transpose(0, 1)  # [H, L, hd]
-            k = _rope(k.view(Ln, Hk, hd), cos, sin).transpose(0, 1)
-            v = v.view(Ln, Hk, hd).transpose(0, 1)
-            kv[2 * i, 0, :, :Ln] = k
-            kv[2 * i + 1, 0, :, :Ln] = v
-            a = _sdpa(q[None], k[None], v[None], H != Hk)[0]
+            h = rmsnorm(x, lw["ln1"])
+            qkv = F.linear(h, lw["wqkv"], lw["bqkv"])  # [L, QKV]
+            # rotary at position m (bf16 rounding points of the reference) on q in place; k (rotated) and v -> cache rows [0, L)
+            L.check(lib.vispec_rope_append(eng.h, st, p(qkv), Ln, H, Hk, hd, p(cos), p(sin), None, None, p(kv[2 * i]), p(kv[2 * i + 1]), S, None))
+            q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
+            a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0]
             x = x + F.linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"])
-            h = _rmsnorm(x, lw["ln2"], c.rms_norm_eps)
-            g, u = F.linear(h, lw["wgu"]).chunk(2, dim=-1)
-            x = x + F.linear(F.silu(g) * u, lw["wdown"])
-        hidden = _rmsnorm(x, self.w.norm, c.rms_norm_eps)
+            h = rmsnorm(x, lw["ln2"])
+            gu = F.linear(h, lw["wgu"])
+            act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
+            L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
+            x = x + F.linear(act, lw["wdown"])
+        hidden = rmsnorm(x, self.w.norm)
         logits = F.linear(hidden if all_logits else hidden[-1:], self.w.lm_head).float()
         return logits, hidden.contiguous()
 
