@@ -286,6 +286,11 @@ def test_logsoftmax_topk(lib, engine, M, V, k):
     o = vo.Ops(True)
     x = synth.bf16_grid(rng.standard_normal((M, V), dtype=np.float32) * 3)
     x[0, 7] = x[0, 900] = x[0, 901] = 30.0  # ties inside the top-k
+    if M >= 3:  # massive ties: a constant row, and a row whose k-th value is shared by many entries spread over all chunks
+        x[1, :] = 0.5
+        x[2, :] = -1.0
+        x[2, ::97] = 2.0
+        x[2, 500] = 3.0
     X = tb(x)
     idx = torch.zeros(M, k, dtype=torch.int32, device=dev())
     lp = torch.zeros(M, k, dtype=torch.float32, device=dev())
@@ -303,6 +308,10 @@ def test_logsoftmax_topk(lib, engine, M, V, k):
         assert len(set(got_idx[r].tolist())) == k
         assert (np.diff(got_lp[r]) <= 0).all()
     assert got_idx[0, :3].tolist() == [7, 900, 901]
+    if M >= 3:  # ties resolve to the lowest indices, in index order
+        assert got_idx[1].tolist() == list(range(k))
+        mult = [i for i in range(0, V, 97)]
+        assert got_idx[2].tolist() == ([500] + mult + [i for i in range(V) if i % 97 and i != 500])[:k]
 
 
 @pytest.mark.parametrize("M,N,K", [(30, 5120, 5120), (30, 2 * 13824, 5120), (8, 5120, 13824), (30, 3584 + 2 * 512, 3584), (8, 18944 * 2, 3584)])
