@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the N>1 path: weight replication (scatter + all-gather) and request sharding."""
+"""world_size-2 gloo tests (CPU) of the N>1 path: weight replication (broadcast, and the scatter + all-gather variant) and request sharding."""
 import os
 import sys
 
@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 from helpers import ROOT
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
                torch.randn(17, generator=g), torch.randn((1 << 19) + 3, generator=g)]
     before = parallel.checksum(tensors)
     same_before = parallel.all_equal(before)
-    nbytes = parallel.replicate_weights(tensors, src=0)
+    nbytes = parallel.replicate_weights(tensors, src=0, mode=mode)
     after = parallel.checksum(tensors)
     ok = parallel.all_equal(after)
     ref = torch.Generator().manual_seed(100)
@@ -29,12 +29,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_replicate_weights_world2():
+@pytest.mark.parametrize("mode", ["broadcast", "scatter"])
+def test_replicate_weights_world2(mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + os.getpid() % 2000 + (7 if mode == "scatter" else 0)
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=120) for _ in range(world))
     [p.join(60) for p in ps]

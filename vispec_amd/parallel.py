@@ -1,7 +1,9 @@
 """Multi-GPU: one process per GPU, independent (image, prompt) requests per replica, NO data-path collective
-(SURVEY.md §8e — "replicas only").  The only communication is the one-time replication of the weights from rank 0:
-scatter (each peer link carries 1/G of the payload) followed by all-gather, so that every xGMI link of every GPU is
-busy instead of the root's egress alone (xGMI is point-to-point, a flat broadcast is root-egress bound)."""
+(SURVEY.md §8e — "replicas only").  The only communication is the one-time replication of the weights from rank 0
+at start-up: by default one RCCL broadcast per tensor (what BASELINE.json's north star names; 14 GB is a fraction of a
+second of xGMI time either way).  `mode="scatter"` (env VISPEC_REPLICATE=scatter) splits every large tensor into G shards —
+scatter, so each peer link of the root carries 1/G of the payload, then all-gather — which keeps every xGMI link busy
+instead of the root's egress alone; it is exercised by the gloo test but has not run on RCCL hardware yet, hence opt-in."""
 from __future__ import annotations
 
 from typing import Iterable
@@ -12,14 +14,19 @@ import torch.distributed as dist
 SMALL = 1 << 20
 
 
-def replicate_weights(tensors: Iterable[torch.Tensor], src: int = 0, group=None) -> int:
+def replicate_weights(tensors: Iterable[torch.Tensor], src: int = 0, group=None, mode: str = None) -> int:
     """In-place: after the call every rank holds rank `src`'s values.  Returns the number of bytes replicated."""
+    import os
+    mode = mode or os.environ.get("VISPEC_REPLICATE", "broadcast")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = 0
     for t in tensors:
         assert t.is_contiguous()
         total += t.numel() * t.element_size()
         if world == 1:
+            continue
+        if mode != "scatter":
+            dist.broadcast(t, src, group=group)
             continue
         flat = t.view(-1)
         n = flat.numel()
