@@ -681,3 +681,34 @@ def test_stagewise_helpers_reproduce_the_reference_loop_body(golden_dir, tempera
             break
     np.testing.assert_array_equal(input_ids[0].cpu().numpy(), want[0].cpu().numpy())
     assert acc == want_acc == o_acc and int(cur[0]) == input_ids.shape[1]
+
+
+def test_concurrent_lanes_give_the_sequential_results(golden_dir):
+    """Two lanes (own ctx, KV cache, host thread and HIP stream; shared packed weights) running different requests at the same time
+    return exactly what each request returns alone — the library keeps no cross-request state outside its ctx."""
+    import threading
+    from vispec_amd.model.cnets_ours import Model
+    from vispec_amd.model.target import TargetLM
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    sm0, _, _ = build(50, 60, True)
+    sm1 = SpecModel(TargetLM(sm0.base_model.cfg, sm0.base_model.w), Model(sm0.spec_layer.config, sm0.spec_layer.w, total_tokens=30, depth=3, top_k=8, num_q=2),
+                    total_token=30, depth=3, top_k=8, num_q=2)  # second lane on the same weights
+    reqs = [torch.from_numpy(g[f"succ{i % 2}_ids"][: 30 - 3 * i])[None].cuda() for i in range(6)]
+    alone = [sm0.specgenerate(r, max_new_tokens=30, log=True, return_acceptance_len=True) for r in reqs]
+    out = [None] * len(reqs)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def lane(sm, k):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(streams[k]):
+            for i in range(k, len(reqs), 2):
+                out[i] = sm.specgenerate(reqs[i], max_new_tokens=30, log=True, return_acceptance_len=True)
+            streams[k].synchronize()
+
+    th = [threading.Thread(target=lane, args=(sm, k)) for k, sm in enumerate((sm0, sm1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for a, b in zip(alone, out):
+        np.testing.assert_array_equal(a[0].cpu().numpy(), b[0].cpu().numpy())
+        assert a[1:] == b[1:]
+    assert sm1.engine.graph_stats()["replays"] > 0  # the lanes ran on capturable streams: rounds were replayed as hipGraphs
