@@ -230,11 +230,16 @@ def main():
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
+    ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
     ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
     args = ap.parse_args()
-    global MODEL
+    global MODEL, N_IMG
     MODEL = args.model
+    if args.n_img:
+        N_IMG = args.n_img
+        for k in ("llava7b", "llava13b"):
+            MODELS[k]["desc"] = f"1 image ({N_IMG} image tokens) + 512 text + 48 template tokens per request (L={N_PRE + N_IMG + N_POST})"
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
