@@ -527,6 +527,30 @@ def g11_update_inference_inputs():
     np.savez_compressed(os.path.join(OUT, "g11_update.npz"), **out)
 
 
+def g13_real_dims():
+    """Single ops at the REAL LLaVA-7B dims (D=4096, V=32064; SURVEY §8c "G9"): LM-head -> LogSoftmax -> top-k as topK_genrate does it
+    (cnets_ours.py:1109-1123), and the draft's input fusion fc(cat(emb, img_fc(cat(h, g)))) (cnets_ours.py:982-988) — torch fp32 on CPU.
+    Weights are seed-derived (numpy PCG64) and NOT stored; only inputs and results are."""
+    D, V, k = 4096, 32064, 8
+    rng = np.random.default_rng(1300)
+    W = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.02)
+    h = synth.bf16_grid(rng.standard_normal((8, D), dtype=np.float32))
+    logits = torch.nn.functional.linear(t(h), t(W))
+    logp = nn.LogSoftmax(dim=-1)(logits)
+    top = torch.topk(logp, k, dim=-1)
+    rng2 = np.random.default_rng(1301)
+    fc_w, fc_b = rng2.standard_normal((D, 2 * D), dtype=np.float32) * np.float32(0.02), rng2.standard_normal(D, dtype=np.float32) * np.float32(0.02)
+    ifc_w, ifc_b = rng2.standard_normal((D, 2 * D), dtype=np.float32) * np.float32(0.02), rng2.standard_normal(D, dtype=np.float32) * np.float32(0.02)
+    emb = synth.bf16_grid(rng2.standard_normal((5, D), dtype=np.float32) * 0.05)
+    hid = synth.bf16_grid(rng2.standard_normal((5, D), dtype=np.float32))
+    g = synth.bf16_grid(rng2.standard_normal((1, D), dtype=np.float32))
+    fc, ifc = nn.Linear(2 * D, D), nn.Linear(2 * D, D)
+    fc.weight.data, fc.bias.data, ifc.weight.data, ifc.bias.data = t(fc_w), t(fc_b), t(ifc_w), t(ifc_b)
+    fused = fc(torch.cat((t(emb), ifc(torch.cat((t(hid), t(g).expand(5, D)), dim=-1))), dim=-1))
+    np.savez_compressed(os.path.join(OUT, "g13_real_dims.npz"), h=h, top_idx=top.indices.numpy(), top_logp=top.values.numpy(),
+                        lse=torch.logsumexp(logits, -1).numpy(), emb=emb, hid=hid, g=g, fused=fused.detach().numpy())
+
+
 def g12_kvcache():
     """KVCache.cat / .copy / .shape / current_length (kv_cache.py:4-66) on a CPU slab: a cat of the prompt rows, a cat of T tree
     rows, then the compaction copy of an accepted path."""
@@ -548,9 +572,9 @@ def g12_kvcache():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

@@ -276,3 +276,27 @@ def test_g12_kvcache_class_matches_reference(golden_dir):
     kv.copy(torch.from_numpy(g["idx"]), 5)
     np.testing.assert_array_equal(data.numpy(), g["d3"])
     assert int(cur) == int(g["len3"]) and tuple(kv.shape) == tuple(g["s3"])
+
+
+def test_g13_real_dims_lmhead_topk_and_fusion(golden_dir):
+    """The oracle at the REAL LLaVA-7B dims (D=4096, V=32064): LM-head -> log-softmax -> top-k and the draft's input fusion against
+    the reference's torch ops; weights re-derived from the seeds the fixture generator used."""
+    g = load(golden_dir, "g13_real_dims.npz")
+    D, V, k = 4096, 32064, 8
+    rng = np.random.default_rng(1300)
+    W = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.02)
+    o = vo.Ops(bf16=False)
+    logp = o.log_softmax(o.linear(g["h"], W))
+    for r in range(logp.shape[0]):
+        wv, wi = vo.topk_desc(logp[r], k)
+        np.testing.assert_array_equal(wi, g["top_idx"][r])
+        np.testing.assert_allclose(wv, g["top_logp"][r], rtol=0, atol=2e-5)
+    del W
+    rng2 = np.random.default_rng(1301)
+    w = {"fc.weight": rng2.standard_normal((D, 2 * D), dtype=np.float32) * np.float32(0.02)}
+    w["fc.bias"] = rng2.standard_normal(D, dtype=np.float32) * np.float32(0.02)
+    w["img_fc.weight"] = rng2.standard_normal((D, 2 * D), dtype=np.float32) * np.float32(0.02)
+    w["img_fc.bias"] = rng2.standard_normal(D, dtype=np.float32) * np.float32(0.02)
+    h2 = o.linear(np.concatenate([g["hid"], np.broadcast_to(g["g"], g["hid"].shape)], -1), w["img_fc.weight"], w["img_fc.bias"])
+    fused = o.linear(np.concatenate([g["emb"], h2], -1), w["fc.weight"], w["fc.bias"])
+    np.testing.assert_allclose(fused, g["fused"], rtol=0, atol=2e-5 * np.abs(g["fused"]).max())
