@@ -717,3 +717,29 @@ def test_concurrent_lanes_give_the_sequential_results(golden_dir):
         np.testing.assert_array_equal(a[0].cpu().numpy(), b[0].cpu().numpy())
         assert a[1:] == b[1:]
     assert sm1.engine.graph_stats()["replays"] > 0  # the lanes ran on capturable streams: rounds were replayed as hipGraphs
+
+
+def test_qwen2_text_target_with_qkv_bias_and_gqa():
+    """Qwen2ForCausalLM targets (spec_model_ours.py:124-125, modeling_qwen2_kv.py): the Llama decoder with q/k/v bias, GQA and eager
+    scores — text-only loop == oracle == greedy AR."""
+    Q = synth.QWEN_TINY
+    tw = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=93, structured=True, qkv_bias=True, H_kv=Q["Hkv"])
+    dw = synth.make_draft_weights(Q["D"], Q["H"], Q["I"], Q["V"], seed=94, structured=True, qkv_bias=True,
+                                  target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    tcfg = TargetConfig(hidden_size=Q["D"], num_heads=Q["H"], num_kv_heads=Q["Hkv"], intermediate_size=Q["I"], vocab_size=Q["V"], num_layers=Q["NL"],
+                        max_position_embeddings=Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True,
+                        architectures=("Qwen2ForCausalLM",))
+    dcfg = DraftConfig(hidden_size=Q["D"], num_heads=Q["H"], intermediate_size=Q["I"], vocab_size=Q["V"], max_position_embeddings=Q["max_pos"],
+                       rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw)
+    ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]),
+                        tw, bf16=True)
+    od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)
+    ids = np.random.default_rng(23).integers(3, Q["V"] - 2, size=21)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=28, log=True, return_acceptance_len=True)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=28, max_pos=Q["max_pos"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert (new_token, idx, acc) == (o_new, o_idx, o_acc) and max(acc) >= 2
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=20)[0].cpu().numpy()
+    n = min(len(ar), len(o_out))
+    np.testing.assert_array_equal(ar[:n], o_out[:n])

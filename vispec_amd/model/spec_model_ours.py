@@ -72,7 +72,7 @@ class SpecModel:
         dcfg, draft_sd = load_draft_dir(spec_model_path, tcfg)
         model = cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=60 if total_token == -1 else total_token,
                                  depth=depth, top_k=top_k, num_q=num_q, tokenizer=tokenizer)
-        if tcfg.architectures[0] != "LlamaForCausalLM":
+        if tcfg.architectures[0] not in ("LlamaForCausalLM", "Qwen2ForCausalLM"):
             # vision tower + projector of the checkpoint (PyTorch-ROCm, HF modules): SURVEY §8 A2
             from .vision import HFVisionFrontEnd
             try:
@@ -200,8 +200,8 @@ class SpecModel:
             pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), tok_id, grids)
             position_ids = torch.from_numpy(pos3)
             self.base_model.rope_deltas = torch.tensor([[rope_delta]], device=input_ids.device)
-        elif arch == "LlamaForCausalLM":
-            pass  # text target: the draft embeds the ids itself (cnets_ours.py:1099-1107)
+        elif arch in ("LlamaForCausalLM", "Qwen2ForCausalLM"):
+            pass  # text targets (Qwen2 = the same decoder with q/k/v bias, modeling_qwen2_kv.py): the draft embeds the ids itself (cnets_ours.py:1099-1107)
         else:
             raise NotImplementedError(f"target architecture {arch}")
         return inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta

@@ -44,6 +44,8 @@ def load_target_dir(path):
         rope_theta = tc.get("rope_theta") or rs.get("rope_theta") or 1e6
     else:
         kw = dict(image_token_index=cfg.get("image_token_index", 32000))
+        if arch == "Qwen2ForCausalLM":  # modeling_qwen2_kv.py: Llama decoder with q/k/v bias, eager scores
+            kw["qkv_bias"] = True
         rope_theta = tc.get("rope_theta") or (tc.get("rope_parameters") or {}).get("rope_theta") or 10000.0
     tcfg = TargetConfig(
         hidden_size=tc.get("hidden_size", 4096), num_heads=H, num_kv_heads=tc.get("num_key_value_heads", H),
