@@ -316,85 +316,92 @@ def main():
 
     extra = {}
     if rank == 0:
-        # ---- clean (un-instrumented) split of one request into prefill and decode wall time
-        ids, pix = reqs[0][W]
-        torch.cuda.synchronize()
-        t1 = time.time()
-        with torch.cuda.stream(streams[0]):
-            out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
-                                                                    return_decode_time=True, **pix)
-        torch.cuda.synchronize()
-        t_req = time.time() - t1
-        extra["single_lane"] = dict(tokens_per_s=round(int(new_token) / t_req, 2))
-        extra["request_split"] = dict(wall_s=round(t_req, 4), prefill_s=round(t_req - t_dec_clean, 4), decode_s=round(t_dec_clean, 4),
-                                      rounds=idx + 1, ms_per_round=round(1e3 * t_dec_clean / (idx + 1), 3))
-        # ---- decode-only rate + roofline leg: one more request with HIP events around every skinny-GEMM / attention launch
-        torch.cuda.synchronize()
-        eng.prof_enable(True)
-        t1 = time.time()
-        out, new_token, idx, acc, t_dec = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
-                                                          return_decode_time=True, **pix)
-        rep = eng.prof_report()
-        eng.prof_enable(False)
-        st = eng.state()
-        gemm = {k: v for k, v in rep.items() if k.startswith("gemm")}
-        # dominant kernel = the instantiation that moves the most bytes (it is also the one with the largest total duration in the
-        # rocprofv3 summary under profiles/; a HIP-event pair adds ~2 us per launch, which would bias a by-time choice towards the
-        # kernels with many short launches)
-        dom = max(gemm, key=lambda k: gemm[k]["bytes"])
-        d = gemm[dom]
-        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        all_b = sum(v["bytes"] for v in gemm.values())
-        all_ms = sum(v["ms"] for v in gemm.values())
-        n_mid = (ids.shape[1] + st["n_ctx"]) // 2
-        n_img = int((ids == tcfg.image_token_index).sum())
-        b_round = algorithmic_bytes_per_round(tcfg, n_mid, n_mid - n_img + 1)
-        # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
-        # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
-        traffic = None
-        try:
-            if MODEL != "llava7b":
-                raise KeyError("the committed PMC pass was collected on the headline config only")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
-            key = {"gemm_swiglu": "<1, 2,", "gemm_none": "<1, 0,", "gemm_splitk_partial": "<1, 3,"}.get(dom)
-            for k, v in pmc.items():
-                if key and "gemm_w32_kernel" + key in k:
-                    traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
-        except Exception:
-            pass
-        extra["roofline"] = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
-                                 kernel=f"gemm_skinny_kernel[{dom}]", launches=int(d["launches"]), avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
-                                 algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                                 all_skinny_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
-                                 by_kernel={k: dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
-                                                    GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in gemm.items() if v["bytes"] > 0})
-        rounds_prof = idx + 1
-        extra["round"] = dict(rounds_per_s=round(rounds / dt, 2), decode_only_rounds_per_s=round(rounds_prof / t_dec, 2),
-                              algorithmic_GB_per_round=round(b_round / 1e9, 2),
-                              round_roofline_frac_of_8TBps=round((b_round * rounds_prof / t_dec) / 8e12, 4),
-                              kernel_ms_per_round={k: round(v["ms"] / rounds_prof, 4) for k, v in rep.items()})
-        # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
-        #      once on a single lane (latency) and once with the same lane concurrency as the timed region (throughput)
-        if not args.no_ar:
+        try:  # the legs below only annotate the line: a failure in one of them must not lose the measured value
+            # ---- clean (un-instrumented) split of one request into prefill and decode wall time
+            ids, pix = reqs[0][W]
             torch.cuda.synchronize()
             t1 = time.time()
             with torch.cuda.stream(streams[0]):
-                ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
+                out, new_token, idx, acc, t_dec_clean = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                                        return_decode_time=True, **pix)
             torch.cuda.synchronize()
-            t_ar = time.time() - t1
-            n_ar = ar.shape[1] - ids.shape[1]
-            extra["single_lane"].update(ar_tokens_per_s=round(n_ar / t_ar, 2), speedup_vs_ar=round(extra["single_lane"]["tokens_per_s"] / (n_ar / t_ar), 3))
-            # greedy invariance at full size: speculative tokens == AR tokens of the same target
-            nmin = min(ar.shape[1], out.shape[1])
-            extra["spec_equals_ar_prefix"] = int((ar[0, :nmin] == out[0, :nmin]).long().cumprod(0).sum().item()) - ids.shape[1]
+            t_req = time.time() - t1
+            extra["single_lane"] = dict(tokens_per_s=round(int(new_token) / t_req, 2))
+            extra["request_split"] = dict(wall_s=round(t_req, 4), prefill_s=round(t_req - t_dec_clean, 4), decode_s=round(t_dec_clean, 4),
+                                          rounds=idx + 1, ms_per_round=round(1e3 * t_dec_clean / (idx + 1), 3))
+            # ---- decode-only rate + roofline leg: one more request with HIP events around every skinny-GEMM / attention launch
             torch.cuda.synchronize()
+            eng.prof_enable(True)
             t1 = time.time()
-            res_ar = run_lanes([lane_fn(l, W, W + 1, ar=True) for l in range(R)])
-            torch.cuda.synchronize()
-            t_arR = time.time() - t1
-            ar_rate = sum(r[0] for r in res_ar) / t_arR
-            extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, new_tokens=int(sum(r[0] for r in res_ar)), wall_s=round(t_arR, 3))
-            extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
+            out, new_token, idx, acc, t_dec = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
+                                                              return_decode_time=True, **pix)
+            rep = eng.prof_report()
+            eng.prof_enable(False)
+            st = eng.state()
+            gemm = {k: v for k, v in rep.items() if k.startswith("gemm")}
+            # dominant kernel = the instantiation that moves the most bytes (it is also the one with the largest total duration in the
+            # rocprofv3 summary under profiles/; a HIP-event pair adds ~2 us per launch, which would bias a by-time choice towards the
+            # kernels with many short launches)
+            dom = max(gemm, key=lambda k: gemm[k]["bytes"])
+            d = gemm[dom]
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            all_b = sum(v["bytes"] for v in gemm.values())
+            all_ms = sum(v["ms"] for v in gemm.values())
+            n_mid = (ids.shape[1] + st["n_ctx"]) // 2
+            n_img = int((ids == tcfg.image_token_index).sum())
+            b_round = algorithmic_bytes_per_round(tcfg, n_mid, n_mid - n_img + 1)
+            # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
+            # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
+            traffic = None
+            try:
+                if MODEL != "llava7b":
+                    raise KeyError("the committed PMC pass was collected on the headline config only")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
+                key = {"gemm_swiglu": "<1, 2,", "gemm_none": "<1, 0,", "gemm_splitk_partial": "<1, 3,"}.get(dom)
+                for k, v in pmc.items():
+                    if key and "gemm_w32_kernel" + key in k:
+                        traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
+            except Exception:
+                pass
+            extra["roofline"] = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
+                                     kernel=f"gemm_skinny_kernel[{dom}]", launches=int(d["launches"]), avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                                     algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                                     all_skinny_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
+                                     by_kernel={k: dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                                                        GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in gemm.items() if v["bytes"] > 0})
+            rounds_prof = idx + 1
+            extra["round"] = dict(rounds_per_s=round(rounds / dt, 2), decode_only_rounds_per_s=round(rounds_prof / t_dec, 2),
+                                  algorithmic_GB_per_round=round(b_round / 1e9, 2),
+                                  round_roofline_frac_of_8TBps=round((b_round * rounds_prof / t_dec) / 8e12, 4),
+                                  kernel_ms_per_round={k: round(v["ms"] / rounds_prof, 4) for k, v in rep.items()})
+            # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
+            #      once on a single lane (latency) and once with the same lane concurrency as the timed region (throughput)
+            if not args.no_ar:
+                torch.cuda.synchronize()
+                t1 = time.time()
+                with torch.cuda.stream(streams[0]):
+                    ar = sm.baseline_generate(ids, inputs_embeds=None, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
+                torch.cuda.synchronize()
+                t_ar = time.time() - t1
+                n_ar = ar.shape[1] - ids.shape[1]
+                extra["single_lane"].update(ar_tokens_per_s=round(n_ar / t_ar, 2), speedup_vs_ar=round(extra["single_lane"]["tokens_per_s"] / (n_ar / t_ar), 3))
+                # greedy invariance at full size: speculative tokens == AR tokens of the same target
+                nmin = min(ar.shape[1], out.shape[1])
+                extra["spec_equals_ar_prefix"] = int((ar[0, :nmin] == out[0, :nmin]).long().cumprod(0).sum().item()) - ids.shape[1]
+                torch.cuda.synchronize()
+                t1 = time.time()
+                res_ar = run_lanes([lane_fn(l, W, W + 1, ar=True) for l in range(R)])
+                torch.cuda.synchronize()
+                t_arR = time.time() - t1
+                ar_rate = sum(r[0] for r in res_ar) / t_arR
+                extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, new_tokens=int(sum(r[0] for r in res_ar)), wall_s=round(t_arR, 3))
+                extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
+        except Exception as e:
+            extra["extra_legs_error"] = f"{type(e).__name__}: {e}"[:300]
+            try:
+                eng.prof_enable(False)
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 extra["cpu_baseline"] = cpu_baseline_leg()
