@@ -38,6 +38,9 @@ typedef struct {
   int total_token, depth, top_k, num_q;
   int eos_token_id;
   int eager_scores;       /* 1: target attention rounds scores to bf16 like modeling_llama_kv.py:602-604 */
+  int draft_rope_rows;    /* rows of the draft's rope_cos / rope_sin tables; 0 = draft_max_pos.  Draft rows are rotated at their
+                             UNCOMPRESSED position (cnets_ours.py:845-868), which runs up to the target's context length, so the loader
+                             should build max(max_pos, draft_max_pos) rows (the reference regrows its cache on demand, cnets_ours.py:157-162) */
 } vispec_config;
 
 /* per-layer target weights; wqkv = rows [q | k | v] fused, wgu = rows [gate | up] fused, all W32-packed (done once at load) */
@@ -64,7 +67,7 @@ typedef struct {            /* SURVEY §8 A0 state-dict contract */
   const void *ad_q;         /* imadpt.q [num_q, H, hd] */
   const void *ad_wkv, *ad_bkv; /* imadpt.{k,v}_proj fused [2D, D] */
   const void *ad_wo;        /* imadpt.o_proj [D, D] */
-  const void *rope_cos, *rope_sin; /* [draft_max_pos, head_dim] */
+  const void *rope_cos, *rope_sin; /* [draft_rope_rows, head_dim] */
 } vispec_draft_weights;
 
 const char* vispec_last_error(void);
@@ -165,6 +168,10 @@ int vispec_accept(vispec_ctx*, void* stream, int forced_accept);
    draft produced — what utils.tree_decoding does with arbitrary tree_candidates / tree_mask.  Blocking. */
 int vispec_set_tree_host(vispec_ctx*, void* stream, const int* tokens_T, const int* pos_T, const uint64_t* mask_T,
                          const int* retrieve, int n_leaf, int max_depth);
+/* The retrieve table alone (`retrieve` may be NULL in vispec_set_tree_host): SpecModel.forward's verify form
+   (spec_model_ours.py:226-245 called by utils.tree_decoding, utils.py:404-409) receives tokens / positions / mask only; the
+   table reaches the library when evaluate_posterior / update_inference_inputs are given it (utils.py:415,496).  Blocking. */
+int vispec_set_retrieve_host(vispec_ctx*, void* stream, const int* retrieve, int n_leaf, int max_depth);
 
 /* One decode call of topK_genrate (cnets_ours.py:1043-1238, stable_kv branch) on the hidden states accepted by the
    last vispec_verify_accept. */

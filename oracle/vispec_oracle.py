@@ -362,7 +362,7 @@ class DraftModel:
             in_ids = ti.reshape(-1)[cs_idx]  # :1159
             ss_token.append(ti.reshape(-1))
             scores_list.append(cu.reshape(-1))
-            tmask = np.concatenate([tmask[:, out_ids], np.eye(k, dtype=bool)], axis=1)  # :1163-1165
+            tmask = np.concatenate([tmask[out_ids], np.eye(k, dtype=bool)], axis=1)  # :1163-1165 (dim 2 of [1,1,k,w] = the ROWS: node j inherits its parent's row)
             self.level_debug.append(dict(out=out, cu=cu, tok=ti, cs_idx=cs_idx.copy()))
         scores_all = np.concatenate(scores_list)  # :1167
         tokens_all = np.concatenate(ss_token)  # :1168

@@ -196,6 +196,41 @@ def g4_topk():
     np.savez_compressed(os.path.join(OUT, "g4_topk.npz"), **out)
 
 
+def g14_tree_levels():
+    """Float outputs of every draft forward inside topK_genrate (prefill call with an image run, then a decode call): the hidden
+    rows of each tree level depend on how the level mask EVOLVES (cnets_ours.py:1163-1165, `tree_mask[:, :, out_ids]` = the parent's
+    ROW), which the integer outputs of g4 are not sensitive to.  Captured with a forward hook on the reference's draft."""
+    out = {}
+    base, _ = build_target(seed=20)
+    head = base.lm_head
+    m, _ = build_draft(num_q=2, seed=14)
+    m.reset_kv()
+    rec = []
+    hook = m.register_forward_hook(lambda mod, inp, res: rec.append(f32(res[0])[0]))
+    rng = np.random.default_rng(401)
+    L = 37
+    hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+    embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+    mask = np.zeros((1, L), bool)
+    mask[0, 6:27] = True
+    ids = rng.integers(3, T["V"], size=(1, L + 1))
+    r = m.topK_genrate(t(hidden), torch.from_numpy(ids), head, None, inputs_embeds=t(embeds), image_mask=torch.from_numpy(mask))
+    n_a = len(rec)
+    h2 = synth.bf16_grid(rng.standard_normal((1, 4, T["D"]), dtype=np.float32))
+    ids2 = np.concatenate([ids, rng.integers(3, T["V"], size=(1, 4))], axis=1)
+    r2 = m.topK_genrate(t(h2), torch.from_numpy(ids2), head, None)
+    hook.remove()
+    assert n_a == 4 and len(rec) == 8  # 1 prefill/catch-up forward + depth level forwards per call
+    out.update(hidden=hidden[0], embeds=embeds[0], mask=mask[0], ids=ids[0], h2=h2[0], ids2=ids2[0])
+    for c, (nm, rr) in enumerate((("a", r), ("b", r2))):
+        out[f"{nm}_first_last_row"] = rec[4 * c][-1]
+        for lvl in range(3):
+            out[f"{nm}_level{lvl}_out"] = rec[4 * c + 1 + lvl]
+        out[f"{nm}_tokens"] = rr[0][0].numpy()
+        out[f"{nm}_mask"] = rr[2][0, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "g14_tree_levels.npz"), **out)
+
+
 def g5_verify():
     """target prefill then tree verify with a tree mask; logits, hidden, KV lengths."""
     base, _ = build_target(seed=21)
@@ -572,8 +607,8 @@ def g12_kvcache():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
-    fns = dict(g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    fns = dict(g14=g14_tree_levels, g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
                g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims)
     for k in which:
         print("generating", k, flush=True)

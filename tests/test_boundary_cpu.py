@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_symbol():
 def test_ctypes_structs_match_header_layout():
     import ctypes as C
     from vispec_amd import lib as L
-    assert C.sizeof(L.VispecConfig) == 22 * 4
+    assert C.sizeof(L.VispecConfig) == 23 * 4
     assert C.sizeof(L.LayerWeights) == 11 * 8 and C.sizeof(L.TargetMisc) == 6 * 8 and C.sizeof(L.DraftWeights) == 17 * 8
 
 

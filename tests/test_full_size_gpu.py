@@ -1,7 +1,9 @@
-"""Full BASELINE size (LLaVA-v1.6-vicuna-7B shapes, L = 2704 = 48 + 2144 image + 512 text tokens): size-independent properties.
-The numpy oracle cannot run at this size in seconds, so parity here is: (1) the reference's own invariant — speculative output ==
-greedy AR output of the same target, token for token; (2) exact integer logic replayed by the oracle on the device's buffers;
-(3) bookkeeping identities of the compressed draft KV and of the accept log."""
+"""Full BASELINE sizes — every model of BASELINE.json's configs (bench.MODELS): LLaVA-v1.6-vicuna-7B (L = 2704 = 48 + 2144 image +
+512 text tokens), LLaVA-v1.6-vicuna-13B (40 layers, 40 heads: the 8-GPU config's replica), Qwen2.5-VL-7B with a 4-image multi-turn
+prompt (GQA 28/4, q/k/v bias, V = 152 064, multimodal rotary prefill, rope_delta) and Qwen2.5-VL-7B with fp8 target weights on a
+1280x960 image.  The numpy oracle cannot run at these sizes in seconds, so parity here is size-independent properties: (1) the
+reference's own invariant — speculative output == greedy AR output of the same target, token for token; (2) exact integer logic
+replayed by the oracle on the device's buffers; (3) bookkeeping identities of the compressed draft KV and of the accept log."""
 import numpy as np
 import pytest
 
@@ -11,25 +13,38 @@ torch = pytest.importorskip("torch")
 from helpers import vo  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def model7b():
+# model -> (prompt length, image tokens, image runs)
+SHAPES = {"llava7b": (2704, 2144, 1), "llava13b": (2704, 2144, 1), "qwen7b": (1584, 1024, 4), "qwen7b-fp8": (2124, 1564, 1)}
+
+
+@pytest.fixture(scope="module", params=list(SHAPES))
+def model_full(request):
+    import gc
     import bench
+    bench.MODEL = request.param
     sms, tcfg, _ = bench.build_models(torch.device("cuda:0"), 0, 0, 1, 1)
-    return sms[0], tcfg
+    yield sms[0], tcfg, request.param
+    bench.MODEL = "llava7b"
+    del sms
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
-def test_speculative_equals_greedy_ar_at_full_size(model7b):
+def test_speculative_equals_greedy_ar_at_full_size(model_full):
     import bench
-    sm, tcfg = model7b
+    sm, tcfg, name = model_full
+    bench.MODEL = name
     ids, pix = bench.make_request(tcfg, 3, torch.device("cuda:0"))
     out, new_token, idx, acc = sm.specgenerate(ids, max_new_tokens=96, log=True, return_acceptance_len=True, **pix)
     L = ids.shape[1]
-    assert L == 2704 and new_token > 96 and len(acc) == idx + 1
+    L_want, n_img, n_runs = SHAPES[name]
+    assert L == L_want and int((ids == tcfg.image_token_index).sum()) == n_img
+    assert new_token > 96 and len(acc) == idx + 1
     assert out.shape[1] == L + sum(a + 1 for a in acc) == L + new_token            # accept log <-> token count
     assert 0 <= min(acc) and max(acc) <= sm.engine.depth + 1
     st = sm.engine.state()
     assert st["n_ctx"] == out.shape[1]
-    assert st["draft_len"] == st["n_ctx"] - bench.N_IMG + (sm.engine.num_q - 1)  # image tokens compressed to num_q-1 draft rows
+    assert st["draft_len"] == st["n_ctx"] - n_img + n_runs * (sm.engine.num_q - 1)  # every image run compressed to num_q-1 draft rows
     # exact tree logic on the device's own candidate lists at full vocabulary
     k, d = sm.engine.top_k, sm.engine.depth
     n_all = k + d * k * k
@@ -49,11 +64,12 @@ def test_speculative_equals_greedy_ar_at_full_size(model7b):
     assert np.mean(acc) > 1.5  # the structured synthetic pair really exercises multi-token acceptance
 
 
-def test_idempotent_and_request_independent(model7b):
+def test_idempotent_and_request_independent(model_full):
     """Running the same request twice (KV buffers reused, state reset on the device) gives identical tokens; an interleaved
     different request does not leak into it."""
     import bench
-    sm, tcfg = model7b
+    sm, tcfg, name = model_full
+    bench.MODEL = name
     dev = torch.device("cuda:0")
     a_ids, a_pix = bench.make_request(tcfg, 5, dev)
     b_ids, b_pix = bench.make_request(tcfg, 6, dev)

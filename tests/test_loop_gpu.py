@@ -314,10 +314,8 @@ def test_qwen25vl_target_loop_matches_oracle():
     np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])
 
 
-def test_fp8_target_weights_loop_matches_oracle():
-    """BASELINE config 5 shape of model: Qwen2.5-VL-like target with fp8 (e4m3, per-output-channel) weights in every streamed
-    GEMM incl. lm_head; bf16 draft.  Oracle = same quantised model (numpy e4m3).  The product prefill runs on the dequantised
-    bf16 weights (torch), so KV differs from the oracle's at the rounding level; the structured pair keeps tokens identical."""
+def build_qwen_fp8():
+    """Qwen2.5-VL-tiny with fp8 (e4m3, per-output-channel) target weights + the oracle built on the product's own codes and scales."""
     Q = synth.QWEN_TINY
     IMG = Q["V"] - 1
     tw = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=91, structured=True, qkv_bias=True, H_kv=Q["Hkv"])
@@ -346,6 +344,15 @@ def test_fp8_target_weights_loop_matches_oracle():
     ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
                                         attn_impl="sdpa", mrope_section=Q["mrope_section"]), tw, bf16=True, fp8=codes)
     od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)
+    return sm, ot, od, IMG
+
+
+def test_fp8_target_weights_loop_matches_oracle():
+    """BASELINE config 5 shape of model: Qwen2.5-VL-like target with fp8 (e4m3, per-output-channel) weights in every streamed
+    GEMM incl. lm_head; bf16 draft.  Oracle = same quantised model (numpy e4m3).  The product prefill runs on the dequantised
+    bf16 weights (torch), so KV differs from the oracle's at the rounding level; the structured pair keeps tokens identical."""
+    sm, ot, od, IMG = build_qwen_fp8()
+    Q = synth.QWEN_TINY
     rng = np.random.default_rng(19)
     grids = [(1, 6, 8)]
     ids = np.concatenate([rng.integers(3, IMG, 6), np.full(12, IMG), rng.integers(3, IMG, 8)])
@@ -615,8 +622,8 @@ def test_kv_capacity_stop_instead_of_overflow(golden_dir):
     out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=400, log=True, return_acceptance_len=True)
     st = sm.engine.state()
     assert st["done"] & 4 and not st["done"] & 3 and new_token < 400
-    # text-only: the draft KV (same 512 rows, guard = top_k_max*depth_max + 64 = 192 rows) fills first; the stop comes within one round of it
-    assert T["max_pos"] - 192 < st["n_ctx"] <= T["max_pos"] - 192 + 24
+    # the target guard (one maximal tree + 64 rows) comes first; the stop comes within one round of it
+    assert T["max_pos"] - 128 < st["n_ctx"] <= T["max_pos"] - 128 + 24
     out = out[0].cpu().numpy()
     o_out, _, _, o_acc = vo.specgenerate(ot, od, ids, max_new_tokens=len(out) - len(ids) - 1, max_pos=T["max_pos"])
     n = min(len(out), len(o_out))

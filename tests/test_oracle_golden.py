@@ -84,6 +84,23 @@ def test_g4_topk_genrate(golden_dir, tag):
         np.testing.assert_array_equal(rr[3], g[f"{tag}_{nm}_pos"])
 
 
+def test_g14_tree_level_hidden_rows(golden_dir):
+    """Every draft forward inside topK_genrate against the reference's own (forward hook): the last row of the prefill / catch-up
+    forward and the k hidden rows of each tree level.  Levels >= 1 depend on the evolution of the level mask — a node inherits its
+    PARENT'S row (cnets_ours.py:1163-1165) — which the integer outputs pinned by g4 do not feel."""
+    g = load(golden_dir, "g14_tree_levels.npz")
+    t, _ = oracle_target(seed=20)
+    d, _ = oracle_draft(num_q=2, seed=14)
+    d.reset_kv()
+    for nm, args, kw in (("a", (g["hidden"], g["ids"]), dict(inputs_embeds=g["embeds"], image_mask=g["mask"])), ("b", (g["h2"], g["ids2"]), {})):
+        r = d.topK_genrate(args[0], args[1], t.lm_head, **kw)
+        np.testing.assert_array_equal(r[0], g[f"{nm}_tokens"])
+        np.testing.assert_array_equal(r[2], g[f"{nm}_mask"] > 0)
+        assert len(d.level_debug) == 3
+        for lvl in range(3):
+            close(d.level_debug[lvl]["out"], g[f"{nm}_level{lvl}_out"])
+
+
 def test_g5_target_verify(golden_dir):
     g = load(golden_dir, "g5_verify.npz")
     t, _ = oracle_target(seed=21)

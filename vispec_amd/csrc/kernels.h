@@ -62,6 +62,8 @@ struct DevState {
   int rope_delta;   // Qwen2.5-VL: cached rope_deltas added to every decode position (utils.py:397-402); 0 otherwise
   int kv_cap, draft_cap;  // rows of the target / draft KV caches
   int stop2;        // second stop token (llama-3 "<|eot_id|>", spec_model_ours.py:268-269,540-542); -1 = none
+  int draft_rope_rows;  // rows of the draft's rotary tables: draft rows rotate at their UNCOMPRESSED position (cnets_ours.py:845-868)
+  int draft_round_rows; // draft KV rows one round appends behind the stable KV: catch-up (<= depth+2) + top_k per tree level
 };
 #define KV_GUARD_ROWS 64  // rows kept free beyond the next tree (the AR baseline polls `done` only every 16 steps)
 

@@ -547,6 +547,8 @@ __global__ void draft_advance_kernel(DevState* st) {
     st->draft_len += st->accept_len + 1;
     st->draft_real_len += st->accept_len + 1;
     // the next round appends a catch-up (<= depth+2 rows) and top_k rows per tree level behind the stable KV
-    if (st->draft_len + TREE_MAX_K * TREE_MAX_DEPTH + KV_GUARD_ROWS > st->draft_cap) st->done |= 4;
+    if (st->draft_len + st->draft_round_rows + KV_GUARD_ROWS > st->draft_cap) st->done |= 4;
+    // ... and rotates its rows at the real (uncompressed) positions draft_real_len .. + depth + 1: they must stay inside the tables
+    if (st->draft_real_len + TREE_MAX_DEPTH + 2 + KV_GUARD_ROWS > st->draft_rope_rows) st->done |= 4;
   }
 }

@@ -3,6 +3,7 @@
 #include "../../include/vispec_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -60,8 +61,22 @@ struct vispec_ctx {
   size_t gemm_part_elems = 0;
   size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
   int n_hint = 0;             // upper bound of keys any attention call of this request can see
+  int scr_rows = 0;           // rows of the prefill-only scratch (a prompt may be as long as the TARGET cache; only its compressed form must fit the draft's)
+  int rope_rows = 0;          // rows of the draft rotary tables
   // hipGraph cache: the launch sequence of a round is static for a given (n_hint, forced_accept) — see run_graphed()
-  struct GraphSlot { hipGraphExec_t exec = nullptr; long key = -1; };
+  // A captured graph bakes its kernel arguments in, so the cache key is the full tuple of everything that reaches a launch as an
+  // argument or shapes the launch sequence — compared field by field (a hashed single integer could collide and replay a graph
+  // with the wrong sampling parameters).
+  struct GraphKey {
+    int n_hint = -1, forced_accept = 0, total_token = 0, sample_top_k = 0;
+    float temperature = 0.f;
+    unsigned long long seed = 0;
+    bool operator==(const GraphKey& o) const {
+      return n_hint == o.n_hint && forced_accept == o.forced_accept && total_token == o.total_token && sample_top_k == o.sample_top_k &&
+             memcmp(&temperature, &o.temperature, sizeof(float)) == 0 && seed == o.seed;
+    }
+  };
+  struct GraphSlot { hipGraphExec_t exec = nullptr; GraphKey key; };
   GraphSlot g_verify, g_draft, g_ar;
   float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
   int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
@@ -98,6 +113,7 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   if (c.total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
   if (c.hidden_size != c.draft_heads * c.head_dim) return fail("draft must be MHA with head_dim 128 over hidden_size");
   if (c.num_heads % c.num_kv_heads) return fail("num_heads %% num_kv_heads != 0");
+  if (c.draft_rope_rows < 0) return fail("draft_rope_rows must be >= 0");
   vispec_ctx* ctx = new vispec_ctx();
   ctx->c = c;
   ctx->layers.resize(c.num_layers);
@@ -119,11 +135,14 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   A(dx1, ROWS * 2 * D); A(dx2, ROWS * 2 * D); A(dx, ROWS * D); A(dqkv, ROWS * 3 * D); A(dattn, ROWS * D);
   A(dh, ROWS * D); A(dn, ROWS * D); A(dact, ROWS * Id); A(dout, ROWS * D); A(dlast, 16 * D); A(in_h, 16 * D);
   A(dlogits, 16 * V); A(dg, D);
-  A(xc, (size_t)c.draft_max_pos * D); A(emb_shift, (size_t)c.draft_max_pos * D);
-  A(ad_kv, (size_t)2 * c.draft_max_pos * D); A(ad_out, 16 * D); A(ad_tmp, ROWS * 2 * D);
-  A(top_idx, TREE_MAX_K * TREE_MAX_K); A(top_logp, TREE_MAX_K * TREE_MAX_K); A(pos_c, c.draft_max_pos);
-  A(idx_tmp, c.draft_max_pos); A(idx_img, c.draft_max_pos); A(scratch_int, 4);
-  if (hipHostMalloc((void**)&ctx->h_pin, sizeof(int) * 3 * (size_t)c.draft_max_pos) != hipSuccess) {
+  const int scr = c.max_pos > c.draft_max_pos ? c.max_pos : c.draft_max_pos;
+  ctx->scr_rows = scr;
+  ctx->rope_rows = c.draft_rope_rows > 0 ? c.draft_rope_rows : c.draft_max_pos;
+  A(xc, (size_t)scr * D); A(emb_shift, (size_t)scr * D);
+  A(ad_kv, (size_t)2 * scr * D); A(ad_out, 16 * D); A(ad_tmp, ROWS * 2 * D);
+  A(top_idx, TREE_MAX_K * TREE_MAX_K); A(top_logp, TREE_MAX_K * TREE_MAX_K); A(pos_c, scr);
+  A(idx_tmp, scr); A(idx_img, scr); A(scratch_int, 4);
+  if (hipHostMalloc((void**)&ctx->h_pin, sizeof(int) * 3 * (size_t)scr) != hipSuccess) {
     vispec_ctx_destroy(ctx);
     return fail("hipHostMalloc failed");
   }
@@ -203,17 +222,21 @@ extern "C" int vispec_set_kv(vispec_ctx* ctx, void* target_kv, void* draft_kv) {
 }
 
 // ------------------------------------------------------------------------------------------------ in-library profiling
-// HIP-event pairs recorded on the launch stream around each kernel of a "kind"; used by bench.py for the roofline
-// object (per-launch duration of the dominant kernel measured on the stream it runs on).  Off by default.
-enum { PROF_KINDS = 16, PROF_ATT_PARTIAL = 9, PROF_ATT_REDUCE = 10, PROF_OTHER = 11 };  // 0..4: gemm none/residual/swiglu/splitK-partial/splitK-reduce
+// Per-dispatch device timestamps of the kernels of a "kind", used by bench.py for the roofline object: in profiling mode every
+// skinny-GEMM / attention launch goes through hipExtLaunchKernel with a start/stop event pair, which carry the begin/end timestamps
+// of THAT dispatch on the stream it runs on (what rocprofv3 --kernel-trace reports; a plain hipEventRecord pair around a launch
+// would also see the dispatch gap in front of it).  Off by default; profiling disables graph replay.
+enum { PROF_KINDS = 16, PROF_QKV_ROPE = 5, PROF_ATT_PARTIAL = 9, PROF_ATT_REDUCE = 10, PROF_ATT_PARTIAL_DRAFT = 12, PROF_ATT_REDUCE_DRAFT = 13 };
+// 0..4: skinny GEMM none / residual / swiglu / split-K partial / split-K reduce(+norm); 5: q|k|v + rotary + KV append
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> ev;  // 2 per record
   std::vector<int> kind;
   std::vector<double> bytes;
   size_t used = 0;
+  hipEvent_t cur_a = nullptr, cur_b = nullptr;  // events of the launch being bracketed
 } g_prof;
-static void prof_begin(hipStream_t s, int kind, double bytes) {
+static void prof_begin(hipStream_t, int kind, double bytes) {
   if (!g_prof.on) return;
   if (g_prof.used * 2 + 2 > g_prof.ev.size()) {
     for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; g_prof.ev.push_back(e); }
@@ -222,16 +245,24 @@ static void prof_begin(hipStream_t s, int kind, double bytes) {
   g_prof.bytes.resize(g_prof.used + 1);
   g_prof.kind[g_prof.used] = kind;
   g_prof.bytes[g_prof.used] = bytes;
-  (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  g_prof.cur_a = g_prof.ev[2 * g_prof.used];
+  g_prof.cur_b = g_prof.ev[2 * g_prof.used + 1];
 }
-static void prof_end(hipStream_t s) {
-  if (!g_prof.on) return;
-  (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+static void prof_end(hipStream_t) {
+  if (!g_prof.on || !g_prof.cur_a) return;
+  g_prof.cur_a = g_prof.cur_b = nullptr;
   ++g_prof.used;
 }
+// launch inside a prof_begin / prof_end bracket
+#define PLAUNCH(kernel, grid, block, lds, s, ...)                                                                          \
+  do {                                                                                                                      \
+    if (g_prof.cur_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_prof.cur_a, g_prof.cur_b, 0, __VA_ARGS__);       \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                                      \
+  } while (0)
 extern "C" int vispec_prof_enable(vispec_ctx*, int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;
+  g_prof.cur_a = g_prof.cur_b = nullptr;
   return 0;
 }
 // out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic bytes}; blocking.
@@ -305,7 +336,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
   const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
-  hipLaunchKernelGGL((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
+  PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
                      T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{})
   if (epi == EPI_SWIGLU) {  // weight in "SwiGLU order" (vispec_pack_weight docs): N/16 workgroups of one 32-row tile each
     if (N % 16) return fail("gemm_skinny: SwiGLU needs N %% 16 == 0");
@@ -343,7 +374,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
+  PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
                      N, b, epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed,
                      o.ldn, o.eps);
   KCHK();
@@ -433,9 +464,9 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT; re.ps = ps; re.kc = (bf16_t*)kc; re.vc = (bf16_t*)vc;
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
-  prof_begin(s, 0, (double)N * K * (wscale ? 1.0 : 2.0));
+  prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
 #define VISPEC_QKV(W8_, MT_)                                                                                                              \
-  hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, MT_>()), s, \
+  PLAUNCH((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, MT_>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, (const float*)wscale, re)
   if (M <= 32) { if (wscale) VISPEC_QKV(true, 1); else VISPEC_QKV(false, 1); }
   else { if (wscale) VISPEC_QKV(true, 2); else VISPEC_QKV(false, 2); }
@@ -462,17 +493,17 @@ static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int l
   if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
   const int lds = ATT_LDS_BYTES;
   dim3 grid(nsplit, H_kv, NQT), block(256);
-  prof_begin(s, PROF_ATT_PARTIAL, 0.0);
+  prof_begin(s, eager ? PROF_ATT_PARTIAL : PROF_ATT_PARTIAL_DRAFT, 0.0);
   if (eager)
-    hipLaunchKernelGGL(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
+    PLAUNCH(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
                        (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
   else
-    hipLaunchKernelGGL(tree_attn_partial_kernel<false>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
+    PLAUNCH(tree_attn_partial_kernel<false>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
                        (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
   KCHK();
   prof_end(s);
-  prof_begin(s, PROF_ATT_REDUCE, 0.0);
-  hipLaunchKernelGGL(tree_attn_reduce_kernel, dim3(H * MT, 4), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
+  prof_begin(s, eager ? PROF_ATT_REDUCE : PROF_ATT_REDUCE_DRAFT, 0.0);
+  PLAUNCH(tree_attn_reduce_kernel, dim3(H * MT, 4), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
                      tail, kpw, nsplit, (bf16_t*)out, ldo);
   KCHK();
   prof_end(s);
@@ -597,6 +628,7 @@ extern "C" int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, i
                                   const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache,
                                   void* v_cache, int s_max, const int* kv_base_dev) {
   if (hd != 128) return fail("rope_append: head_dim must be 128");
+  if (M < 1 || (!kv_base_dev && M > s_max)) return fail("rope_append: the rows do not fit the cache (M > s_max)");
   PosSpec ps;
   ps.base = pos_base_dev;
   ps.off = pos_off_dev;
@@ -640,7 +672,7 @@ extern "C" int vispec_logsoftmax_topk(vispec_ctx* ctx, void* stream, const void*
 // (the round is GPU-bound on one stream) but removes ~1.4 ms of host launch time per round, which is what limits several
 // concurrent batch-1 lanes per GPU.  The legacy null stream cannot be captured: calls on it launch directly.
 template <class F>
-static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& slot, long key, F body) {
+static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& slot, const vispec_ctx::GraphKey& key, F body) {
   if (!ctx->use_graphs || g_prof.on || s == nullptr) {
     ++ctx->direct_runs;
     return body();
@@ -653,7 +685,7 @@ static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& sl
   if (slot.exec) {
     (void)hipGraphExecDestroy(slot.exec);
     slot.exec = nullptr;
-    slot.key = -1;
+    slot.key = vispec_ctx::GraphKey{};
   }
   if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
@@ -679,6 +711,19 @@ static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& sl
   HIPCHK(hipGraphLaunch(slot.exec, s));
   return 0;
 }
+// sampling = the launch sequence reads temperature / seed / top_k (verify's sampling accept); the draft only switches the row order
+// of its retrieve table on temperature > 0, the AR step uses none of them
+static vispec_ctx::GraphKey graph_key(const vispec_ctx* ctx, int forced_accept, bool sampling_args) {
+  vispec_ctx::GraphKey k;
+  k.n_hint = ctx->n_hint;
+  k.forced_accept = forced_accept;
+  k.total_token = ctx->c.total_token;
+  const bool sampling = ctx->temperature > 1e-5f;
+  k.temperature = sampling_args ? (sampling ? ctx->temperature : 0.f) : (sampling ? 1.f : 0.f);
+  k.seed = sampling_args && sampling ? ctx->seed : 0;
+  k.sample_top_k = sampling_args && sampling ? ctx->sample_top_k : 0;
+  return k;
+}
 // out[0..2] = {graph replays, graph captures, direct (un-graphed) runs} of the round functions since ctx creation
 extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
   if (!ctx || !out3) return fail("null");
@@ -692,7 +737,7 @@ extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
 }
 
 // ------------------------------------------------------------------------------------------------ the path
-__global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos, int kv_cap, int draft_cap) {
+__global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos, int kv_cap, int draft_cap, int rope_rows, int round_rows) {
   if (threadIdx.x == 0) {
     DevState z{};
     z.n_ctx = L;
@@ -703,6 +748,8 @@ __global__ void begin_request_kernel(DevState* st, int L, int max_new, int eos, 
     z.kv_cap = kv_cap;
     z.stop2 = -1;
     z.draft_cap = draft_cap;
+    z.draft_rope_rows = rope_rows;
+    z.draft_round_rows = round_rows;
     *st = z;
   }
 }
@@ -721,7 +768,7 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
   if (L < 1 || L + c.total_token + 8 > c.max_pos) return fail("prompt does not fit the KV cache");
   if (prompt_ids_host) HIPCHK(hipMemcpyAsync(ctx->tokens, prompt_ids_host, sizeof(int) * L, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(begin_request_kernel, dim3(1), dim3(64), 0, s, ctx->st, L, max_new_tokens, c.eos_token_id, c.max_pos,
-                     c.draft_max_pos);
+                     c.draft_max_pos, ctx->rope_rows, c.top_k * c.depth + c.depth + 2);
   KCHK();
   long hint = (long)L + max_new_tokens + 2 * (c.depth + 2) + c.total_token + 64;
   ctx->n_hint = (int)(hint < c.max_pos ? hint : c.max_pos);
@@ -799,7 +846,7 @@ static int draft_round_body(vispec_ctx* ctx, hipStream_t s);
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  return run_graphed(ctx, s, ctx->g_draft, (long)ctx->n_hint * 2 + (ctx->temperature > 1e-5f), [&]() { return draft_round_body(ctx, s); });
+  return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(ctx, s); });
 }
 static int draft_round_body(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
@@ -824,7 +871,10 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
-  if (L < 1 || L > c.draft_max_pos) return fail("draft_prefill: L exceeds draft_max_pos");
+  // the prompt may be as long as the target cache allows (the reference's draft handles it, cnets_ours.py:879-975); what must fit the
+  // draft's own cache is the COMPRESSED sequence (checked below), and every row is rotated at its real position < rope_rows
+  if (L < 1 || L > ctx->scr_rows) return fail("draft_prefill: prompt does not fit the prefill scratch (max(max_pos, draft_max_pos) rows)");
+  if (L + c.depth + 2 > ctx->rope_rows) return fail("draft_prefill: prompt does not fit the draft rotary tables (draft_rope_rows)");
   // inputs_embeds shifted by one, last row = embed(sampled token)  (cnets_ours.py:1081-1082)
   if (L > 1)
     HIPCHK(hipMemcpyAsync(ctx->emb_shift, (const bf16_t*)embeds + D, (size_t)(L - 1) * D * sizeof(bf16_t),
@@ -837,8 +887,8 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   struct Op { int is_adapt, c_row, n, off; };
   std::vector<Op> plan;
   int* h_src = ctx->h_pin;
-  int* h_img = ctx->h_pin + c.draft_max_pos;
-  int* h_pos = ctx->h_pin + 2 * c.draft_max_pos;
+  int* h_img = ctx->h_pin + ctx->scr_rows;
+  int* h_pos = ctx->h_pin + 2 * ctx->scr_rows;
   int c_row = 0, img_off = 0;
   {
     int start = 0;
@@ -865,12 +915,16 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     text_rows(start, L, nullptr);  // :944-950 (the trailing segment is all text by construction)
   }
   const int Lc = c_row;
-  if (Lc < 1 || Lc > c.draft_max_pos) return fail("draft_prefill: bad compressed length");
+  if (Lc < 1) return fail("draft_prefill: bad compressed length");
+  // the first round appends a catch-up (<= depth+2 rows) and top_k rows per tree level behind the compressed prompt
+  if (Lc + c.top_k * c.depth + c.depth + 2 > c.draft_max_pos)
+    return fail("draft_prefill: the compressed prompt does not fit the draft KV cache (draft_max_pos)");
   HIPCHK(hipMemcpyAsync(ctx->idx_tmp, h_src, sizeof(int) * Lc, hipMemcpyHostToDevice, s));
   if (img_off) HIPCHK(hipMemcpyAsync(ctx->idx_img, h_img, sizeof(int) * img_off, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(ctx->pos_c, h_pos, sizeof(int) * Lc, hipMemcpyHostToDevice, s));
   bf16_t* akc = ctx->ad_kv;
-  bf16_t* avc = ctx->ad_kv + (size_t)Hd * c.draft_max_pos * 128;
+  const int ad_cap = ctx->scr_rows;  // row capacity of the adaptor's scratch K/V (one image run can be as long as the prompt)
+  bf16_t* avc = ctx->ad_kv + (size_t)Hd * ad_cap * 128;
   for (const Op& op : plan) {
     if (!op.is_adapt) {
       for (int o = 0; o < op.n; o += CHUNK) {
@@ -890,12 +944,12 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
         return -1;
       PosSpec ps;
       ps.kv_add = o;
-      if (launch_rope(s, ctx->ad_tmp, rows, 0, Hd, nullptr, nullptr, ps, akc, avc, c.draft_max_pos, 0)) return -1;
+      if (launch_rope(s, ctx->ad_tmp, rows, 0, Hd, nullptr, nullptr, ps, akc, avc, ad_cap, 0)) return -1;
     }
     // ... then num_q learned queries attend over all N rows (non-causal), o_proj
     hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, (const int*)nullptr, N, ctx->scratch_int);
     KCHK();
-    if (launch_attention(ctx, s, ctx->dw.ad_q, D, akc, avc, c.draft_max_pos, Hd, Hd, q, ctx->scratch_int, 0, nullptr, ctx->dattn, D,
+    if (launch_attention(ctx, s, ctx->dw.ad_q, D, akc, avc, ad_cap, Hd, Hd, q, ctx->scratch_int, 0, nullptr, ctx->dattn, D,
                          0, N))
       return -1;
     if (launch_gemm(ctx, s, ctx->dattn, D, ctx->dw.ad_wo, nullptr, ctx->ad_out, D, nullptr, 0, q, D, D, EPI_NONE)) return -1;
@@ -1010,11 +1064,7 @@ static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accep
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  unsigned tbits;
-  memcpy(&tbits, &ctx->temperature, 4);
-  const long key = ((long)ctx->n_hint * 64 + (forced_accept + 1)) ^ ((long)tbits << 24) ^ (long)(ctx->seed * 0x9E3779B97F4A7C15ull >> 8) ^
-                   ((long)ctx->sample_top_k << 44);
-  return run_graphed(ctx, s, ctx->g_verify, key, [&]() {
+  return run_graphed(ctx, s, ctx->g_verify, graph_key(ctx, forced_accept, true), [&]() {
     if (target_forward(ctx, s, ctx->c.total_token)) return -1;
     return target_accept(ctx, s, ctx->c.total_token, forced_accept);
   });
@@ -1030,23 +1080,35 @@ extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
 __global__ void set_tree_meta_kernel(DevState* st, int n_leaf, int max_depth, int T) {
   if (threadIdx.x == 0) { st->n_leaf = n_leaf; st->max_depth = max_depth; st->tree_T = T; }
 }
-extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* tokens_T, const int* pos_T, const uint64_t* mask_T,
-                                    const int* retrieve, int n_leaf, int max_depth) {
-  if (!ctx || !tokens_T || !pos_T || !mask_T || !retrieve) return fail("null");
+static int upload_retrieve(vispec_ctx* ctx, hipStream_t s, const int* retrieve, int n_leaf, int max_depth, int T) {
   if (n_leaf < 1 || n_leaf > TREE_MAX_T || max_depth < 1 || max_depth > TREE_RET_W) return fail("bad tree shape");
-  hipStream_t s = (hipStream_t)stream;
-  const int T = ctx->c.total_token;
   std::vector<int> ret(TREE_MAX_T * TREE_RET_W, -1);
   for (int r = 0; r < n_leaf; ++r)
-    for (int j = 0; j < max_depth; ++j) ret[r * TREE_RET_W + j] = retrieve[r * max_depth + j];
-  HIPCHK(hipMemcpyAsync(ctx->tb.tree_tokens, tokens_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(ctx->tb.tree_pos, pos_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(ctx->tb.tree_mask, mask_T, sizeof(uint64_t) * T, hipMemcpyHostToDevice, s));
+    for (int j = 0; j < max_depth; ++j) {
+      const int v = retrieve[r * max_depth + j];
+      if (v < -1 || v >= T) return fail("retrieve index out of range");
+      ret[r * TREE_RET_W + j] = v;
+    }
   HIPCHK(hipMemcpyAsync(ctx->tb.retrieve, ret.data(), sizeof(int) * ret.size(), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));  // `ret` is a local
   hipLaunchKernelGGL(set_tree_meta_kernel, dim3(1), dim3(64), 0, s, ctx->st, n_leaf, max_depth, T);
   KCHK();
   return 0;
+}
+extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* tokens_T, const int* pos_T, const uint64_t* mask_T,
+                                    const int* retrieve, int n_leaf, int max_depth) {
+  if (!ctx || !tokens_T || !pos_T || !mask_T) return fail("null");
+  hipStream_t s = (hipStream_t)stream;
+  const int T = ctx->c.total_token;
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_tokens, tokens_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_pos, pos_T, sizeof(int) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tb.tree_mask, mask_T, sizeof(uint64_t) * T, hipMemcpyHostToDevice, s));
+  const int root_only = 0;  // retrieve == NULL: a single path holding the root (the forward needs no retrieve table; see vispec_set_retrieve_host)
+  return retrieve ? upload_retrieve(ctx, s, retrieve, n_leaf, max_depth, T) : upload_retrieve(ctx, s, &root_only, 1, 1, T);
+}
+extern "C" int vispec_set_retrieve_host(vispec_ctx* ctx, void* stream, const int* retrieve, int n_leaf, int max_depth) {
+  if (!ctx || !retrieve) return fail("null");
+  return upload_retrieve(ctx, (hipStream_t)stream, retrieve, n_leaf, max_depth, ctx->c.total_token);
 }
 
 __global__ void set_stop2_kernel(DevState* st, int tok) {
@@ -1069,7 +1131,7 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
   ctx->c.total_token = total_token;
-  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar}) g->key = -1;  // captured launch sequences depend on the tree size
+  // (the tree size is part of every graph key: the captured launch sequences depend on it)
   return 0;
 }
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
@@ -1113,7 +1175,7 @@ extern "C" int vispec_set_next_token(vispec_ctx* ctx, void* stream, const int* t
 extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  return run_graphed(ctx, s, ctx->g_ar, (long)ctx->n_hint, [&]() {
+  return run_graphed(ctx, s, ctx->g_ar, graph_key(ctx, -1, false), [&]() {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
     KCHK();
     if (target_forward(ctx, s, 1)) return -1;

@@ -238,14 +238,18 @@ class Engine:
             draft_heads=dcfg.num_heads, draft_intermediate=dcfg.intermediate_size, draft_max_pos=self.draft_max_pos,
             draft_qkv_bias=int(dcfg.qkv_bias), draft_fc_bias=int(dcfg.bias), draft_rms_eps=dcfg.rms_norm_eps,
             total_token=total_token, depth=depth, top_k=top_k, num_q=num_q, eos_token_id=tcfg.eos_token_id,
-            eager_scores=int(eager_scores),
+            eager_scores=int(eager_scores), draft_rope_rows=max(self.kv_max_pos, self.draft_max_pos),
         )
         with torch.cuda.device(self.device):
             h = C.c_void_p()
             L.check(self.lib.vispec_ctx_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.t_cos, self.t_sin = rope_tables(tcfg.head_dim, self.kv_max_pos, tcfg.rope_theta, self.device)
-        self.d_cos, self.d_sin = rope_tables(dcfg.hidden_size // dcfg.num_heads, self.draft_max_pos, dcfg.rope_theta, self.device)
+        # the draft rotates its rows at their UNCOMPRESSED positions (cnets_ours.py:845-868), which run up to the target's context
+        # length: only the draft's KV rows are bounded by draft_max_pos, the tables cover the target cache (the reference regrows its
+        # rotary cache on demand, cnets_ours.py:157-162)
+        self.d_cos, self.d_sin = rope_tables(dcfg.hidden_size // dcfg.num_heads, max(self.kv_max_pos, self.draft_max_pos), dcfg.rope_theta,
+                                             self.device)
         # W32-packed copies of every streamed GEMM weight (the row-major originals stay for the PyTorch prefill)
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
         self.target_weight_dtype = target_weight_dtype
@@ -315,6 +319,12 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- the path ------------------------------------------------------------------------------------
+    def check_prompt_fits(self, n_prompt: int):
+        """Raise BEFORE any kernel writes a KV row when a prompt of n_prompt tokens (+ one tree) cannot fit the target cache — the reference
+        fails cleanly inside KVCache.cat (kv_cache.py:40-58); vispec_begin_request repeats the check on the library side."""
+        if n_prompt < 1 or n_prompt + self.total_token + 8 > self.kv_max_pos:
+            raise L.VispecError(f"prompt does not fit the KV cache ({n_prompt} tokens + a {self.total_token}-node tree > {self.kv_max_pos} rows)")
+
     def begin_request(self, prompt_ids, max_new_tokens: int):
         ids = np.ascontiguousarray(np.asarray(prompt_ids, dtype=np.int32))
         self._keep = ids
@@ -340,12 +350,22 @@ class Engine:
     def accept(self, forced_accept: int = -1):
         L.check(self.lib.vispec_accept(self.h, self._stream(), int(forced_accept)))
 
-    def set_tree(self, tokens: np.ndarray, pos: np.ndarray, mask_bits: np.ndarray, retrieve: np.ndarray):
+    def set_tree(self, tokens: np.ndarray, pos: np.ndarray, mask_bits: np.ndarray, retrieve: Optional[np.ndarray] = None):
+        """Install a caller-built tree; retrieve None = the table follows through set_retrieve (SpecModel.forward's verify form)."""
         tokens, pos = np.ascontiguousarray(tokens, np.int32), np.ascontiguousarray(pos, np.int32)
-        mask_bits, retrieve = np.ascontiguousarray(mask_bits, np.uint64), np.ascontiguousarray(retrieve, np.int32)
+        mask_bits = np.ascontiguousarray(mask_bits, np.uint64)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        if retrieve is None:
+            L.check(self.lib.vispec_set_tree_host(self.h, self._stream(), vp(tokens), vp(pos), vp(mask_bits), None, 0, 0))
+            return
+        retrieve = np.ascontiguousarray(retrieve, np.int32)
         L.check(self.lib.vispec_set_tree_host(self.h, self._stream(), vp(tokens), vp(pos), vp(mask_bits), vp(retrieve),
                                               int(retrieve.shape[0]), int(retrieve.shape[1])))
+
+    def set_retrieve(self, retrieve: np.ndarray):
+        retrieve = np.ascontiguousarray(retrieve, np.int32)
+        L.check(self.lib.vispec_set_retrieve_host(self.h, self._stream(), retrieve.ctypes.data_as(C.c_void_p), int(retrieve.shape[0]),
+                                                  int(retrieve.shape[1])))
 
     def draft_round(self):
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
@@ -380,8 +400,8 @@ class Engine:
     def ar_step(self):
         L.check(self.lib.vispec_ar_step(self.h, self._stream()))
 
-    PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "k5", "k6", "k7", "k8",
-                  "attn_partial", "attn_reduce"]
+    PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "gemm_qkv_rope", "k6", "k7", "k8",
+                  "attn_partial", "attn_reduce", "k11", "attn_partial_sdpa", "attn_reduce_sdpa"]
 
     def set_graphs(self, on: bool):
         L.check(self.lib.vispec_set_graphs(self.h, int(on)))

@@ -19,7 +19,7 @@ class VispecConfig(C.Structure):
         ("draft_heads", c_int), ("draft_intermediate", c_int), ("draft_max_pos", c_int), ("draft_qkv_bias", c_int),
         ("draft_fc_bias", c_int), ("draft_rms_eps", c_float),
         ("total_token", c_int), ("depth", c_int), ("top_k", c_int), ("num_q", c_int),
-        ("eos_token_id", c_int), ("eager_scores", c_int),
+        ("eos_token_id", c_int), ("eager_scores", c_int), ("draft_rope_rows", c_int),
     ]
 
 
@@ -71,6 +71,7 @@ SIGNATURES = {
     "vispec_target_forward": (c_int, [P, P]),
     "vispec_accept": (c_int, [P, P, c_int]),
     "vispec_set_tree_host": (c_int, [P, P, P, P, P, P, c_int, c_int]),
+    "vispec_set_retrieve_host": (c_int, [P, P, P, c_int, c_int]),
     "vispec_draft_round": (c_int, [P, P]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),

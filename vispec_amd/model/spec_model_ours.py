@@ -118,13 +118,28 @@ class SpecModel:
 
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, output_orig=False, position_ids=None,
                 inputs_embeds=None, output_real_hidden=False, **kwargs):
-        """spec_model_ours.py:205-245 — the PREFILL form (empty KV).  Returns (None[, logits fp32 [1,S,V]], hidden [1,S,D]).
-        The tree-verify form is utils.tree_decoding (HIP)."""
+        """spec_model_ours.py:205-245: ONE function serving both callers of the reference —
+          * utils.initialize_tree (utils.py:280-283): empty KV cache -> the PREFILL form (PyTorch-ROCm GEMMs + SDPA, K/V written in place);
+          * utils.tree_decoding (utils.py:404-409): non-empty cache, `input_ids` = the T tree candidates, `position_ids` =
+            tree_position_ids + n (x3, + rope_deltas for Qwen2.5-VL), tree mask installed on `base_model.model.tree_mask`
+            (spec_model_ours.py:486-489) -> the VERIFY form (vispec_target_forward: HIP kernels, K/V rows appended at [n, n+T)).
+        Returns (None[, logits fp32 [1,S,V]], hidden [1,S,D]) (post-final-norm hidden, modeling_llama_kv.py:1062-1066)."""
+        n_past = 0
+        if past_key_values is not None:
+            n_past = int(past_key_values[0][0].current_length.item())  # `past_key_values[0][0].shape[2]` of modeling_llama_kv.py:957
+        if n_past > 0:
+            return self._forward_verify(input_ids, past_key_values, output_orig, position_ids, inputs_embeds)
         if inputs_embeds is None:
             inputs_embeds = self.base_model.get_input_embeddings()(input_ids.to(self.engine.device))
         emb = inputs_embeds.reshape(-1, inputs_embeds.shape[-1]).to(torch.bfloat16).contiguous()
         self._last_embeds = None if input_ids is not None and kwargs.get("_draft_embeds_from_ids") else emb[None]
-        logits, hidden = self.base_model.prefill(emb, all_logits=bool(kwargs.get("all_logits", False)))
+        pos3 = position_ids if (position_ids is not None and position_ids.dim() == 3) else None
+        logits, hidden = self.base_model.prefill(emb, all_logits=bool(kwargs.get("all_logits", False)),
+                                                 position_ids=None if pos3 is None else pos3[:, 0].cpu())
+        # device-side round state: context = the L prefilled rows (utils.initialize_tree re-issues this with the prompt ids)
+        ids0 = (input_ids.reshape(-1).cpu().numpy() if input_ids is not None and input_ids.numel() == emb.shape[0]
+                else np.zeros(emb.shape[0], np.int32))
+        self.engine.begin_request(ids0, 1 << 20)
         if past_key_values is not None:
             for kv in past_key_values:
                 kv[0].current_length.fill_(emb.shape[0])
@@ -132,6 +147,60 @@ class SpecModel:
         if output_orig:
             return None, logits[None], hidden[None]
         return None, hidden[None]
+
+    def _forward_verify(self, input_ids, past_key_values, output_orig, position_ids, inputs_embeds):
+        """The verify form of forward(): S <= 64 new tokens against the committed context of the engine."""
+        eng = self.engine
+        if input_ids is None or inputs_embeds is not None:
+            raise NotImplementedError("forward() with a non-empty KV cache takes token ids (the tree candidates); the reference's "
+                                      "loop never passes inputs_embeds there (utils.py:404-409)")
+        ids = input_ids.reshape(-1).cpu().numpy().astype(np.int32)
+        S = int(ids.shape[0])
+        if S < 1 or S > L.TREE_MAX_T:
+            raise ValueError(f"forward() with a non-empty KV cache handles 1..{L.TREE_MAX_T} tokens per call (one tree), got {S}")
+        st = eng.state()
+        n = int(st["n_ctx"])  # authoritative context length (the host mirror in past_key_values is refreshed below)
+        # relative positions = depth in the tree (utils.py:397: position_ids = tree_position_ids + input_ids.shape[1])
+        if position_ids is None:
+            pos_rel = np.arange(S, dtype=np.int64)
+        else:
+            p = position_ids
+            if p.dim() == 3:  # Qwen2.5-VL: [3, 1, T], the three components are equal in the decode phase (utils.py:398-402)
+                p = p[0]
+            pos_rel = p.reshape(-1).cpu().numpy().astype(np.int64) - n - int(getattr(self, "_rope_delta", 0))
+        if pos_rel.shape[0] != S or pos_rel.min() < 0 or pos_rel.max() >= S:
+            raise ValueError("position_ids of a verify forward must be tree depths offset by the context length "
+                             f"(n = {n}{', + rope_deltas' if getattr(self, '_rope_delta', 0) else ''})")
+        tm = self.base_model.tree_mask
+        bits = np.zeros(L.TREE_MAX_T, np.uint64)
+        if tm is None:  # no tree mask installed: plain causal continuation (modeling_llama_kv.py:890-924 without the tree branch)
+            for i in range(S):
+                bits[i] = np.uint64((1 << (i + 1)) - 1)
+        else:
+            m = (tm.reshape(tm.shape[-2], tm.shape[-1]).cpu().numpy() > 0)
+            if m.shape != (S, S):
+                raise ValueError(f"tree_mask {m.shape} does not match the {S} tree tokens")
+            for i in range(S):
+                bits[i] = np.uint64(sum(1 << j for j in range(S) if m[i, j]))
+        restore = None
+        if S != eng.total_token:
+            restore = eng.total_token
+            eng.set_total_token(S)
+        try:
+            eng.set_tree(ids, pos_rel.astype(np.int32), bits, None)
+            eng.target_forward()
+            V, D = eng.tcfg.vocab_size, eng.tcfg.hidden_size
+            logits = eng.buffer("logits", (64, V))[:S].float()[None]  # `.float()` of modeling_llama_kv.py:1197
+            hidden = eng.buffer("hidden_new", (64, D))[:S].clone()[None]
+        finally:
+            if restore is not None:
+                eng.set_total_token(restore)
+        for kv in past_key_values:  # KVCache.cat appended S rows (kv_cache.py:40-58); update_inference_inputs resets the lengths
+            kv[0].current_length.fill_(n + S)
+            kv[1].current_length.fill_(n + S)
+        if output_orig:
+            return None, logits, hidden
+        return None, hidden
 
     __call__ = forward
 
@@ -176,9 +245,13 @@ class SpecModel:
                     inputs_embeds = inputs_embeds.clone()
                     inputs_embeds[mask] = feats.to(inputs_embeds.dtype)
         elif arch == "Qwen2_5_VLForConditionalGeneration":  # :380-453
-            from ..synth import qwen_rope_index
             pixel_values, grid = kwargs.get("pixel_values"), kwargs.get("image_grid_thw")
             pixel_values_videos, vgrid = kwargs.get("pixel_values_videos"), kwargs.get("video_grid_thw")
+            if pixel_values_videos is not None or vgrid is not None:
+                # HF get_rope_index scales the temporal index of video grids by second_per_grid_ts * tokens_per_second and a prompt may
+                # mix image and video runs; the multimodal rotary positions built here (synth.qwen_rope_index) cover image grids only
+                raise NotImplementedError("Qwen2.5-VL video inputs (pixel_values_videos / video_grid_thw) are out of scope: their M-RoPE "
+                                          "temporal scaling is not implemented")
             tok_id = self.base_model.config.image_token_id
             if inputs_embeds is None:
                 inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
@@ -195,16 +268,58 @@ class SpecModel:
                     special_image_mask = mask  # the reference keeps the LAST mask it built (:420,453)
                     tok_id, grid = tid, g_
             draft_embeds = inputs_embeds
-            # multimodal rotary positions + rope_deltas of the prefill (HF get_rope_index, cached on the model by the reference)
-            grids = [] if grid is None else [tuple(int(v) for v in g3) for g3 in (grid.tolist() if torch.is_tensor(grid) else grid)]
-            pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), tok_id, grids)
-            position_ids = torch.from_numpy(pos3)
-            self.base_model.rope_deltas = torch.tensor([[rope_delta]], device=input_ids.device)
+            position_ids, rope_delta = self._qwen_rope(input_ids, grid, tok_id)
         elif arch in ("LlamaForCausalLM", "Qwen2ForCausalLM"):
             pass  # text targets (Qwen2 = the same decoder with q/k/v bias, modeling_qwen2_kv.py): the draft embeds the ids itself (cnets_ours.py:1099-1107)
         else:
             raise NotImplementedError(f"target architecture {arch}")
         return inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta
+
+    def _qwen_rope(self, input_ids, grid, tok_id=None):
+        """Multimodal rotary positions [3, L] + rope_delta of a Qwen2.5-VL prompt (HF get_rope_index, image grids), cached on the target
+        like the reference's prefill does (modeling_qwen2_5_vl_kv.py `self.rope_deltas`; read back by utils.tree_decoding, utils.py:398-400)."""
+        from ..synth import qwen_rope_index
+        tok_id = self.base_model.config.image_token_id if tok_id is None else tok_id
+        grids = [] if grid is None else [tuple(int(v) for v in g3) for g3 in (grid.tolist() if torch.is_tensor(grid) else grid)]
+        pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), tok_id, grids)
+        self.base_model.rope_deltas = torch.tensor([[rope_delta]], device=input_ids.device)
+        return torch.from_numpy(pos3), int(rope_delta)
+
+    @torch.no_grad()
+    def _start_request(self, input_ids, inputs_embeds, kwargs, temperature=0.0, top_k=0.0, seed=0, max_new_tokens=512, is_llama3=False):
+        """Everything specgenerate does before its loop (spec_model_ours.py:272-475): sampling config, KV reset, vision merge, target
+        prefill, first token, device round state, draft prefill with image-token compression + the first tree.
+        Returns (hidden [L,D], draft_embeds [L,D], image_mask numpy | None, first_token int32 [1]) — what the draft prefill consumed."""
+        eng = self.engine
+        eng.set_sampling(temperature if temperature > 1e-5 else 0.0, seed, top_k=int(top_k) if temperature > 1e-5 else 0)
+        dev = eng.device
+        input_ids = input_ids.clone().to(dev)
+        self.spec_layer.reset_kv()  # :283
+        if not hasattr(self, "past_key_values"):  # :286-307
+            self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
+        self.current_length_data.zero_()
+        inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
+        reset_tree_mode(self)  # :456
+        # initialize_tree (:458-475): prefill + first token + draft prefill with image-token compression
+        emb = (inputs_embeds if inputs_embeds is not None else self.base_model.get_input_embeddings()(input_ids))
+        emb = emb.reshape(-1, emb.shape[-1]).to(torch.bfloat16).contiguous()
+        logits, hidden = self.base_model.prefill(emb, position_ids=position_ids)  # raises before touching the KV when the prompt cannot fit
+        first = eng.sample_row(logits[-1]) if temperature > 1e-5 else self._first_token(logits)
+        eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
+        self._rope_delta = int(rope_delta)
+        if rope_delta:
+            eng.set_rope_delta(rope_delta)
+        if is_llama3:  # :268-269, 540-542
+            eng.set_stop_token(int(self.tokenizer.convert_tokens_to_ids("<|eot_id|>")))
+        if draft_embeds is None:
+            ids1 = torch.cat([input_ids[0], first.long()])
+            demb = torch.nn.functional.embedding(ids1[:-1], self.spec_layer.w.t["embed"]).contiguous()
+        else:
+            demb = emb
+        mask_np = None if special_image_mask is None else special_image_mask.reshape(-1).cpu().numpy()
+        eng.draft_prefill(hidden, demb, mask_np, first)
+        self.spec_layer.stable_kv = ("device", eng)
+        return hidden, demb, mask_np, first
 
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -221,41 +336,16 @@ class SpecModel:
             raise NotImplementedError("TopPLogitsWarper (utils.py:50-51) cannot run on the tree logits (HF scatters along dim 1: "
                                       "RuntimeError in the reference as well); use temperature / top_k")
         eng = self.engine
-        eng.set_sampling(temperature if temperature > 1e-5 else 0.0, seed, top_k=int(top_k) if temperature > 1e-5 else 0)
-        dev = eng.device
         max_length = max_length - self.spec_layer.total_tokens - 10  # :270
-        input_ids = input_ids.clone().to(dev)
-        self.spec_layer.reset_kv()  # :283
-        if not hasattr(self, "past_key_values"):  # :286-307
-            self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model)
-        self.current_length_data.zero_()
-        inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
-        input_len = input_ids.shape[1]
-        reset_tree_mode(self)  # :456
-        # initialize_tree (:458-475): prefill + first token + draft prefill with image-token compression
-        emb = (inputs_embeds if inputs_embeds is not None else self.base_model.get_input_embeddings()(input_ids))
-        emb = emb.reshape(-1, emb.shape[-1]).to(torch.bfloat16).contiguous()
-        logits, hidden = self.base_model.prefill(emb, position_ids=position_ids)
-        first = eng.sample_row(logits[-1]) if temperature > 1e-5 else self._first_token(logits)
-        eng.begin_request(input_ids[0].cpu().numpy(), max_new_tokens)
-        if rope_delta:
-            eng.set_rope_delta(rope_delta)
-        if is_llama3:  # :268-269, 540-542
-            eng.set_stop_token(int(self.tokenizer.convert_tokens_to_ids("<|eot_id|>")))
-        if draft_embeds is None:
-            ids1 = torch.cat([input_ids[0], first.long()])
-            demb = torch.nn.functional.embedding(ids1[:-1], self.spec_layer.w.t["embed"]).contiguous()
-        else:
-            demb = emb
-        mask_np = None if special_image_mask is None else special_image_mask.reshape(-1).cpu().numpy()
-        eng.draft_prefill(hidden, demb, mask_np, first)
-        self.spec_layer.stable_kv = ("device", eng)
+        self._start_request(input_ids, inputs_embeds, kwargs, temperature=temperature, top_k=top_k, seed=seed, max_new_tokens=max_new_tokens,
+                            is_llama3=is_llama3)
+        dev = eng.device
         acceptance_len = []
         if return_decode_time:
             torch.cuda.synchronize()
             start_time = time.time()
         idx = 0
-        st = None
+        st = eng.state()  # max_length <= 0 runs no round: the reference then returns the prompt as it is (:484,555)
         for idx in range(max_length):  # :484
             fa = -1 if forced_accept is None else int(forced_accept(idx))
             eng.verify_accept(fa)   # tree_decoding + evaluate_posterior + accept half of update_inference_inputs
@@ -268,6 +358,9 @@ class SpecModel:
             if st["new_token"] > max_new_tokens:  # :546
                 break
             if st["done"] & 4:  # the next tree would not fit a KV cache: the reference raises in KVCache.cat here (kv_cache.py:40-58)
+                import warnings
+                warnings.warn(f"specgenerate stopped after {st['new_token']} new tokens: the next round would not fit a KV cache "
+                              f"(context {st['n_ctx']} of {eng.kv_max_pos} rows); the returned sequence is truncated", RuntimeWarning)
                 break
         n_ctx, new_token = st["n_ctx"], st["new_token"]
         self.current_length_data.fill_(n_ctx)

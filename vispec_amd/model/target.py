@@ -140,6 +140,7 @@ class TargetLM:
         same rounding points as the decode path): 11 launches per layer instead of ~35, which also keeps the host thread of a lane
         from holding the interpreter while other lanes wait to issue their rounds."""
         c, eng = self.cfg, self.engine
+        eng.check_prompt_fits(int(inputs_embeds.shape[0]))  # before the first KV row is written
         lib, st = eng.lib, eng._stream()
         x = inputs_embeds.to(self.dtype).contiguous()
         Ln = x.shape[0]

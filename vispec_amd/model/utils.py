@@ -48,13 +48,23 @@ def reset_past_key_values(passed_key_values):  # utils.py:341-358
 
 def initialize_tree(input_ids, model, past_key_values, logits_processor, inputs_embeds=None, embed_weights=None,
                     image_mask=None, **kwargs):
-    """utils.py:266-327: target prefill -> first token -> first topK_genrate."""
+    """utils.py:266-327: target prefill -> first token -> first topK_genrate.  For Qwen2.5-VL pass `image_grid_thw` (the processor
+    output the reference hands to its prefill as a kwarg): the multimodal rotary positions and rope_deltas are built from it as in
+    SpecModel.specgenerate."""
     sampling = _enable(model, logits_processor)
-    outputs, orig, hidden_states = model(input_ids, past_key_values=past_key_values, output_orig=True, inputs_embeds=inputs_embeds)
+    position_ids, rope_delta = None, 0
+    if model.base_model.config.architectures[0] == "Qwen2_5_VLForConditionalGeneration":
+        pos3, rope_delta = model._qwen_rope(input_ids, kwargs.get("image_grid_thw"))
+        position_ids = pos3[:, None, :]
+    outputs, orig, hidden_states = model(input_ids, past_key_values=past_key_values, output_orig=True, inputs_embeds=inputs_embeds,
+                                         position_ids=position_ids)
     # argmax(orig[:, -1]) on the device, first max wins (:290) / multinomial(softmax(lp(orig[:, -1]))) (:284-288)
     token = model.engine.sample_row(orig.reshape(-1, orig.shape[-1])[-1]) if sampling else model._first_token(orig)
     # the device-side round state starts here (the reference keeps it in Python locals): prompt ids, n = L, new_token = 0
     model.engine.begin_request(input_ids[0].cpu().numpy(), int(kwargs.get("max_new_tokens", 1 << 20)))
+    model._rope_delta = int(rope_delta)
+    if rope_delta:
+        model.engine.set_rope_delta(rope_delta)
     input_ids = torch.cat((input_ids, token.to(input_ids.device).long()[None]), dim=1)
     embeds = inputs_embeds if inputs_embeds is not None else model._last_embeds
     draft_tokens, retrieve_indices, tree_mask, tree_position_ids = model.spec_layer.topK_genrate(
@@ -63,25 +73,21 @@ def initialize_tree(input_ids, model, past_key_values, logits_processor, inputs_
 
 
 def tree_decoding(model, tree_candidates, past_key_values, tree_position_ids, input_ids, retrieve_indices):
-    """utils.py:389-412: target forward of the T tree tokens with the tree mask installed on the target.
+    """utils.py:389-412, statement for statement: positions = tree depth + context length (x3 + rope_deltas for Qwen2.5-VL), the
+    target forward of the T tree tokens through `model(...)` (SpecModel.forward's verify form -> vispec_target_forward) with the
+    tree mask installed on the target, logits gathered along the candidate paths.
     Returns (logits [n_leaf, m, V] fp32, hidden_state_new [1,T,D], None)."""
-    eng = model.engine
-    T = eng.total_token
-    tm = model.base_model.tree_mask
-    if tm is None:
+    if model.base_model.tree_mask is None:
         raise ValueError("tree_mask must be installed on the target before tree_decoding (spec_model_ours.py:486-489)")
-    bits = np.zeros(64, np.uint64)
-    m = (tm.reshape(T, T).cpu().numpy() > 0)
-    for i in range(T):
-        bits[i] = np.uint64(int("".join("1" if b else "0" for b in m[i][::-1]), 2))
-    ri = retrieve_indices.cpu().numpy().astype(np.int32)
-    eng.set_tree(tree_candidates.reshape(-1).cpu().numpy().astype(np.int32), tree_position_ids.cpu().numpy().astype(np.int32), bits, ri)
-    eng.target_forward()
-    V, D = eng.tcfg.vocab_size, eng.tcfg.hidden_size
-    tree_logits = eng.buffer("logits", (64, V))[:T].float()
-    hidden = eng.buffer("hidden_new", (64, D))[:T]
-    logits = tree_logits[retrieve_indices.to(tree_logits.device)]
-    return logits, hidden[None], None
+    position_ids = tree_position_ids + input_ids.shape[1]
+    if model.base_model.config.architectures[0] == "Qwen2_5_VLForConditionalGeneration":
+        position_ids = position_ids.unsqueeze(0) + model.base_model.rope_deltas.to(position_ids.device)
+        position_ids = position_ids.unsqueeze(0).expand(3, -1, -1)
+    outputs, tree_logits, hidden_state = model(tree_candidates, output_orig=True, past_key_values=past_key_values,
+                                               position_ids=position_ids)
+    model.engine.set_retrieve(retrieve_indices.cpu().numpy())  # what vispec_accept walks (evaluate_posterior / update_inference_inputs)
+    logits = tree_logits[0, retrieve_indices.to(tree_logits.device)]
+    return logits, hidden_state, outputs
 
 
 def evaluate_posterior(logits, candidates, logits_processor, model=None):
@@ -110,6 +116,7 @@ def update_inference_inputs(input_ids, candidates, best_candidate, accept_length
     next topK_genrate — on the device (vispec_accept + vispec_draft_round)."""
     eng = model.engine
     if not getattr(model, "_accept_done", False):
+        eng.set_retrieve(retrieve_indices.cpu().numpy())
         eng.accept()
     model._accept_done = False
     eng.draft_round()
