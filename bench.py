@@ -178,7 +178,7 @@ def algorithmic_bytes_per_ar_step(tcfg, n_ctx, fp8=False):
     return (1 if fp8 else 2) * (NL * (2 * D * D + 2 * D * kvd + 3 * D * I) + V * D) + 2 * NL * kvd * 2 * n_ctx
 
 
-def cpu_baseline_leg():
+def cpu_baseline_leg(sm=None, tcfg=None, req=None):
     """The oracle (numpy port of the reference path, oracle/vispec_oracle.py) timed on this box's host cores on a bounded sample:
     FOUR full draft-and-verify rounds at the real LLaVA-7B dims — all 32 target layers (two distinct random layers' weights, aliased
     16x so that generating them stays cheap; 1.6 GB of fp32 weights per pair, far beyond any cache), lm_head, and the whole draft
@@ -395,7 +395,9 @@ def main():
             n_rounds = idx + 1
             ms_round = 1e3 * t_dec_clean / n_rounds
             n_mid = (ids.shape[1] + st["n_ctx"]) // 2
-            n_c_mid = n_mid - n_img + (eng.num_q - 1) * max(1, MODELS[MODEL]["desc"].count("4 images") * 4)
+            m_img = (ids[0] == tcfg.image_token_index).cpu().numpy()
+            n_runs = int(m_img[0]) + int(((~m_img[:-1]) & m_img[1:]).sum())  # every image run is compressed to num_q - 1 draft rows
+            n_c_mid = n_mid - n_img + n_runs * (eng.num_q - 1)
             b_round = algorithmic_bytes_per_round(tcfg, n_mid, n_c_mid, fp8)
             spc = dict(what="one batch-1 request stream on one GPU, wall clock around the whole specgenerate call (prefill included) — the "
                             "quantity the reference's speed.py divides by its AR counterpart",
