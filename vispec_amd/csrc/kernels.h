@@ -633,6 +633,42 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
   }
 }
 
+// Token embedding rows + the first layer's input RMSNorm in one launch (modeling_llama_kv.py:985 + :104-133): X[i] = table[ids[i]],
+// Y[i] = w * bf16(X[i] * rsqrt(mean(X[i]^2) + eps)).  One workgroup per row.
+__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __restrict__ table, const int* __restrict__ ids, bf16_t* __restrict__ X,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ Y, int D, float eps) {
+  __shared__ float part[4];
+  const bf16_t* x = table + (size_t)ids[blockIdx.x] * D;
+  bf16_t* xo = X + (size_t)blockIdx.x * D;
+  bf16_t* y = Y + (size_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + d);
+    *reinterpret_cast<uint4*>(xo + d) = v;
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f(e[j]);
+      ss += f * f;
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+  const float inv = 1.0f / sqrtf(tot / (float)D + eps);
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + d);
+    const uint4 wv = *reinterpret_cast<const uint4*>(w + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f(we[j]) * rdbf(bf2f(e[j]) * inv);
+    *reinterpret_cast<uint4*>(y + d) = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tree-masked attention, flash-decoding style.  hd = 128.
 //   grid (nsplit, H_kv), 256 threads.  A workgroup stages 128-key chunks of K and V of one KV head in LDS
@@ -950,22 +986,33 @@ __global__ void bcast_row_kernel(const bf16_t* __restrict__ vec, bf16_t* __restr
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restrict__ logits, int ld, int V,
-                                                          int* __restrict__ out) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+                                                           int* __restrict__ out) {
+  // one workgroup per row; a row of 32 064 logits is ONE pass of the block with four 16-byte loads per thread issued back to back
+  // (the 256-thread form walked 16 dependent iterations: 13 us per launch)
+  __shared__ float sv[16];
+  __shared__ int si[16];
   const bf16_t* x = logits + (size_t)blockIdx.x * ld;
   float bv = NEG_INF;
   int bi = 0x7fffffff;
-  for (int d = threadIdx.x * 8; d < V; d += 256 * 8) {
-    uint4 v = *reinterpret_cast<const uint4*>(x + d);
-    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+  for (int base = 0; base < V; base += 1024 * 8 * 4) {
+    uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (d + j < V) {
-        float f = bf2f(e[j]);
-        if (better(f, d + j, bv, bi)) { bv = f; bi = d + j; }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int d = base + (i * 1024 + threadIdx.x) * 8;
+      v[i] = d < V ? *reinterpret_cast<const uint4*>(x + d) : make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = base + (i * 1024 + threadIdx.x) * 8;
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (d + j < V) {
+          const float f = bf2f(e[j]);
+          if (better(f, d + j, bv, bi)) { bv = f; bi = d + j; }
+        }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -976,7 +1023,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restri
   if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
     out[blockIdx.x] = bi;
   }
@@ -992,6 +1039,170 @@ __device__ __forceinline__ void lstk_chunk_range(int V, int chunk, int& lo, int&
   const int per = ((V + LSTK_CHUNKS - 1) / LSTK_CHUNKS + 7) & ~7;
   lo = chunk * per;
   hi = min(V, lo + per);
+}
+
+// ---- one-launch form: ONE workgroup of 1024 threads per row holds the whole row in registers (8*NV logits per thread).
+//   1. block max and sum-exp -> lse (fp32, the oracle's formula: m + log(sum exp(x - m)))
+//   2. keys: 64-bit (order-preserving image of bf16(x - lse), ~index): a larger key is a better candidate (value desc, index asc)
+//   3. threshold: the k-th largest of the 1024 per-LANE maxima (k rounds of shuffle-only wave arg-max per wave, then over the 16*k
+//      survivors).  At most k lanes own an element >= it, so at most k * 8*NV elements of the row pass the threshold.
+//   4. those candidates are appended to an LDS list (capacity 16*8*NV... never exceeded, see 3.) and one wave picks the k best.
+// Exactly the selection of the three-pass form (same key), 4-5 us instead of 36 us per call at V = 32 064, k = 8.
+__device__ __forceinline__ unsigned long long lstk_key(float v, int idx) {
+  const unsigned u = __float_as_uint(v);
+  const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+__device__ __forceinline__ float lstk_key_value(unsigned long long key) {
+  const unsigned ord = (unsigned)(key >> 32);
+  return __uint_as_float((ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord);
+}
+__device__ __forceinline__ int lstk_key_index(unsigned long long key) { return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)); }
+// Wave-wide reductions on the DPP path (row-local quad permutes / mirrors, then row broadcasts; the result is read from lane 63):
+// a __shfl_xor ladder is six dependent ds_bpermute round trips (~700 cycles), this is six VALU steps.  `old` = the identity of the
+// operation, so lanes a row-masked step does not write contribute nothing.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v, unsigned ident) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define VS_STEP(CTRL, RM)                                                                                            \
+  {                                                                                                                  \
+    const unsigned lo_ = dpp_u32<CTRL, RM>((unsigned)v, 0u), hi_ = dpp_u32<CTRL, RM>((unsigned)(v >> 32), 0u);      \
+    const unsigned long long w_ = ((unsigned long long)hi_ << 32) | lo_;                                           \
+    v = w_ > v ? w_ : v;                                                                                             \
+  }
+  VS_STEP(0xB1, 0xf) VS_STEP(0x4E, 0xf) VS_STEP(0x141, 0xf) VS_STEP(0x140, 0xf) VS_STEP(0x142, 0xa) VS_STEP(0x143, 0xc)
+#undef VS_STEP
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define VS_STEP(CTRL, RM) v = fmaxf(v, __uint_as_float(dpp_u32<CTRL, RM>(__float_as_uint(v), 0xFF800000u)));
+  VS_STEP(0xB1, 0xf) VS_STEP(0x4E, 0xf) VS_STEP(0x141, 0xf) VS_STEP(0x140, 0xf) VS_STEP(0x142, 0xa) VS_STEP(0x143, 0xc)
+#undef VS_STEP
+  return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // fixed association: deterministic
+#define VS_STEP(CTRL, RM) v += __uint_as_float(dpp_u32<CTRL, RM>(__float_as_uint(v), 0u));
+  VS_STEP(0xB1, 0xf) VS_STEP(0x4E, 0xf) VS_STEP(0x141, 0xf) VS_STEP(0x140, 0xf) VS_STEP(0x142, 0xa) VS_STEP(0x143, 0xc)
+#undef VS_STEP
+  return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+#define LSTK_ROW_CAND_MAX (TOPK_MAX * 8 * 20)
+template <int NV>
+__global__ __launch_bounds__(1024) void lstk_row_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k, int* __restrict__ out_idx,
+                                                        float* __restrict__ out_logp) {
+  __shared__ float s_red[16];
+  __shared__ unsigned long long s_lmax[1024];
+  __shared__ unsigned long long s_cand[LSTK_ROW_CAND_MAX];
+  __shared__ unsigned long long s_thr;
+  __shared__ int s_n;
+  const bf16_t* x = logits + (size_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint4 raw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e0 = (i * 1024 + tid) * 8;
+    raw[i] = e0 < V ? *reinterpret_cast<const uint4*>(x + e0) : make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);  // -inf
+  }
+  if (tid == 0) s_n = 0;
+  // ---- 1. lse
+  float mx = NEG_INF;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, bf2f(e[j]));
+  }
+  mx = wave_max_dpp(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = s_red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_red[w]);
+  __syncthreads();
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) se += __expf(bf2f(e[j]) - mx);  // exp(-inf) = 0 for the padding
+  }
+  se = wave_sum_dpp(se);
+  if (lane == 0) s_red[wave] = se;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += s_red[w];  // fixed order
+  const float lse = mx + __logf(tot);
+  // ---- 2. per-lane maximum key
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+    const int e0 = (i * 1024 + tid) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned long long key = (e0 + j < V) ? lstk_key(rdbf(bf2f(e[j]) - lse), e0 + j) : 0ull;
+      best = key > best ? key : best;
+    }
+  }
+  s_lmax[tid] = best;
+  __syncthreads();
+  // ---- 3. threshold = k-th largest of the 1024 lane maxima (one wave, 16 values per lane)
+  if (wave == 0) {
+    unsigned long long c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[q] = s_lmax[lane + 64 * q];
+    unsigned long long thr = 0ull;
+    for (int sel = 0; sel < k; ++sel) {
+      unsigned long long m = c[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) m = c[q] > m ? c[q] : m;
+      thr = wave_max_u64(m);
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (c[q] == thr) c[q] = 0ull;  // keys are distinct (they carry the index); 0 = removed / padding
+    }
+    if (lane == 0) s_thr = thr;
+  }
+  __syncthreads();
+  // ---- 4. candidates: every element whose key reaches the threshold (only lanes whose maximum does can own one)
+  const unsigned long long thr = s_thr;
+  if (best >= thr && best != 0ull) {  // (thr == 0: fewer than k lanes hold data, i.e. a row of < 8k elements — everything is a candidate)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+      const int e0 = (i * 1024 + tid) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long key = (e0 + j < V) ? lstk_key(rdbf(bf2f(e[j]) - lse), e0 + j) : 0ull;
+        if (key >= thr && key != 0ull) {
+          const int slot = atomicAdd(&s_n, 1);
+          if (slot < LSTK_ROW_CAND_MAX) s_cand[slot] = key;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = min(s_n, LSTK_ROW_CAND_MAX);
+    for (int sel = 0; sel < k; ++sel) {
+      unsigned long long m = 0ull;
+      for (int c = lane; c < n; c += 64) {
+        const unsigned long long key = s_cand[c];
+        m = key > m ? key : m;
+      }
+      const unsigned long long w = wave_max_u64(m);
+      for (int c = lane; c < n; c += 64)
+        if (s_cand[c] == w) s_cand[c] = 0ull;
+      if (lane == 0) {
+        out_idx[blockIdx.x * k + sel] = lstk_key_index(w);
+        out_logp[blockIdx.x * k + sel] = lstk_key_value(w);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void lstk_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, float* __restrict__ stats) {

@@ -29,9 +29,20 @@ struct TreeBufs {
   int* mask_index;     // [T]  parent row of node i+1 (scratch, kept for the tests)
 };
 
+// The input rows of a level forward are staged where the fused input GEMMs read them: dx1[r, 0:D] = input hidden of frontier node r
+// (row stride 2D; the right half holds the global image feature g, constant during a request) and dx2[r, 0:D] = embed(in_ids[r]).
+__device__ __forceinline__ void tree_stage_row(const bf16_t* __restrict__ hid_src, const bf16_t* __restrict__ emb_src, bf16_t* __restrict__ dx1,
+                                               bf16_t* __restrict__ dx2, int r, int D, int tid, int nthreads) {
+  for (int d = tid * 8; d < D; d += nthreads * 8) {
+    *reinterpret_cast<uint4*>(dx1 + (size_t)r * 2 * D + d) = *reinterpret_cast<const uint4*>(hid_src + d);
+    *reinterpret_cast<uint4*>(dx2 + (size_t)r * 2 * D + d) = *reinterpret_cast<const uint4*>(emb_src + d);
+  }
+}
+
 // Level 1 (cnets_ours.py:1114-1123): the k children of the root come from the last hidden state's top-k.
-__global__ void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
-                                 const bf16_t* __restrict__ last_hidden, bf16_t* __restrict__ in_h, int D) {
+__global__ __launch_bounds__(1024) void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
+                                                         const bf16_t* __restrict__ last_hidden, const bf16_t* __restrict__ embed,
+                                                         bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx2, int D) {
   const int tid = threadIdx.x;
   if (tid < k) {
     tb.scores_all[tid] = top_logp[tid];
@@ -42,17 +53,17 @@ __global__ void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, c
     tb.lvl_mask[tid] = 1ull << tid;  // tree_mask_init = eye(k)
   }
   if (tid == 0) tb.parents_all[0] = 0;
-  for (int e = tid * 8; e < k * D; e += blockDim.x * 8) {  // input_hidden = last_hidden.repeat(k)
-    const int d = e % D, r = e / D;
-    *reinterpret_cast<uint4*>(in_h + (size_t)r * D + d) = *reinterpret_cast<const uint4*>(last_hidden + d);
-  }
+  // input_hidden = last_hidden.repeat(k) ; input_ids = topk_index   (:1120-1121)
+  const int per = 1024 / k;  // threads per row
+  const int r = tid / per;
+  if (r < k) tree_stage_row(last_hidden, embed + (size_t)top_idx[r] * D, dx1, dx2, r, D, tid % per, per);
 }
 
 // One tree level (cnets_ours.py:1139-1165) after the level forward + LM head + per-row top-k.
-__global__ __launch_bounds__(256) void tree_level_kernel(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
-                                                         const float* __restrict__ top_logp,
-                                                         const bf16_t* __restrict__ out_hidden, bf16_t* __restrict__ in_h,
-                                                         int D) {
+__global__ __launch_bounds__(1024) void tree_level_kernel(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
+                                                          const float* __restrict__ top_logp, const bf16_t* __restrict__ out_hidden,
+                                                          const bf16_t* __restrict__ embed, bf16_t* __restrict__ dx1,
+                                                          bf16_t* __restrict__ dx2, int D) {
   __shared__ float cu[TREE_MAX_K * TREE_MAX_K];
   __shared__ int sel[TREE_MAX_K];
   __shared__ unsigned long long newmask[TREE_MAX_K];
@@ -88,11 +99,10 @@ __global__ __launch_bounds__(256) void tree_level_kernel(TreeBufs tb, int level,
     tb.in_ids[tid] = top_idx[s];
     tb.lvl_mask[tid] = newmask[tid];
   }
-  for (int e = tid * 8; e < k * D; e += 256 * 8) {  // input_hidden = out_hidden[:, out_ids]
-    const int d = e % D, r = e / D;
-    *reinterpret_cast<uint4*>(in_h + (size_t)r * D + d) =
-        *reinterpret_cast<const uint4*>(out_hidden + (size_t)(sel[r] / k) * D + d);
-  }
+  // input_hidden = out_hidden[:, out_ids] ; input_ids = topk_index.view(-1)[topk_cs_index]   (:1157-1159)
+  const int per = 1024 / k;
+  const int r = tid / per;
+  if (r < k) tree_stage_row(out_hidden + (size_t)(sel[r] / k) * D, embed + (size_t)top_idx[sel[r]] * D, dx1, dx2, r, D, tid % per, per);
 }
 
 // Global re-rank and tree construction (cnets_ours.py:1167-1213).  total = total_token-1.
@@ -524,28 +534,51 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   }
 }
 
-// KV compaction (utils.py:529-538): rows n+sel[j] -> n+j for j=1..a, for every (layer, k|v, head).
-// One wave per (slab, head): all sources are read into registers before anything is written (rows may overlap).
-__global__ __launch_bounds__(64) void kv_compact_kernel(bf16_t* __restrict__ kv, int s_max, const DevState* __restrict__ st,
-                                                        const int* __restrict__ sel) {
+// After the accept decision (one launch):
+//   blocks [0, n_kv)   KV compaction (utils.py:529-538): rows n+sel[j] -> n+j for j=1..a, for every (layer, k|v, head); one wave per
+//                      (slab, head): all sources are read into registers before anything is written (rows may overlap);
+//   blocks n_kv + j    accept_hidden_state_new[j] = hidden_state_new[sel[j]] (utils.py:543-546), staged where the draft's catch-up forward
+//                      reads it (dx1[j, 0:D]) together with the embedding of the id it is paired with (dx2[j, 0:D] = embed(draft_ids[j]),
+//                      cnets_ours.py:1084,1093).
+__global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ kv, int s_max, int n_kv, const DevState* __restrict__ st,
+                                                          const int* __restrict__ sel, const bf16_t* __restrict__ hidden_new,
+                                                          bf16_t* __restrict__ accept_hidden, const int* __restrict__ draft_ids,
+                                                          const bf16_t* __restrict__ draft_embed, bf16_t* __restrict__ dx1,
+                                                          bf16_t* __restrict__ dx2, int D) {
   constexpr int HD = 128;
-  const int a = st->accept_len, n = st->n_prev;
-  if (a == 0) return;
-  bf16_t* base = kv + ((size_t)blockIdx.x * s_max + n) * HD;  // blockIdx.x = slab*H_kv + head
-  unsigned v[TREE_RET_W];
+  if ((int)blockIdx.x < n_kv) {
+    const int a = st->accept_len, n = st->n_prev;
+    if (a == 0 || threadIdx.x >= 64) return;
+    bf16_t* base = kv + ((size_t)blockIdx.x * s_max + n) * HD;  // blockIdx.x = slab*H_kv + head
+    unsigned v[TREE_RET_W];
 #pragma unroll
-  for (int jj = 1; jj < TREE_RET_W; ++jj)
-    if (jj <= a) v[jj] = *reinterpret_cast<const unsigned*>(base + (size_t)sel[jj] * HD + threadIdx.x * 2);
+    for (int jj = 1; jj < TREE_RET_W; ++jj)
+      if (jj <= a) v[jj] = *reinterpret_cast<const unsigned*>(base + (size_t)sel[jj] * HD + threadIdx.x * 2);
 #pragma unroll
-  for (int jj = 1; jj < TREE_RET_W; ++jj)
-    if (jj <= a) *reinterpret_cast<unsigned*>(base + (size_t)jj * HD + threadIdx.x * 2) = v[jj];
+    for (int jj = 1; jj < TREE_RET_W; ++jj)
+      if (jj <= a) *reinterpret_cast<unsigned*>(base + (size_t)jj * HD + threadIdx.x * 2) = v[jj];
+    return;
+  }
+  const int j = blockIdx.x - n_kv;
+  const bf16_t* hs = hidden_new + (size_t)sel[j] * D;
+  const bf16_t* es = draft_embed ? draft_embed + (size_t)draft_ids[j] * D : nullptr;
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    const uint4 h = *reinterpret_cast<const uint4*>(hs + d);
+    *reinterpret_cast<uint4*>(accept_hidden + (size_t)j * D + d) = h;
+    *reinterpret_cast<uint4*>(dx1 + (size_t)j * 2 * D + d) = h;
+    if (es) *reinterpret_cast<uint4*>(dx2 + (size_t)j * 2 * D + d) = *reinterpret_cast<const uint4*>(es + d);
+  }
 }
 
-// Draft-side bookkeeping after the catch-up forward: the a+1 new rows become part of stable_kv (cnets_ours.py:1108).
-__global__ void draft_advance_kernel(DevState* st) {
+// Draft-side bookkeeping after the catch-up forward: the a+1 new rows become part of stable_kv (cnets_ours.py:1108) and the last
+// of them (out_hidden[:, -1], :1109) is what the tree grows from.
+__global__ __launch_bounds__(256) void draft_advance_kernel(DevState* st, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dlast, int D) {
+  const int a = st->accept_len;
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8)
+    *reinterpret_cast<uint4*>(dlast + d) = *reinterpret_cast<const uint4*>(dout + (size_t)a * D + d);
   if (threadIdx.x == 0) {
-    st->draft_len += st->accept_len + 1;
-    st->draft_real_len += st->accept_len + 1;
+    st->draft_len += a + 1;
+    st->draft_real_len += a + 1;
     // the next round appends a catch-up (<= depth+2 rows) and top_k rows per tree level behind the stable KV
     if (st->draft_len + st->draft_round_rows + KV_GUARD_ROWS > st->draft_cap) st->done |= 4;
     // ... and rotates its rows at the real (uncompressed) positions draft_real_len .. + depth + 1: they must stay inside the tables

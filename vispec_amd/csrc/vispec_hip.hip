@@ -527,6 +527,14 @@ static int launch_bcast(hipStream_t s, const void* vec, void* out, int ld_o, int
 static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int ld, int M, int V, int k, int* out_idx, float* out_logp) {
   if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
   if (M < 1 || M > 64) return fail("logsoftmax_topk: M must be in [1,64]");
+  // one launch: a 1024-thread workgroup per row keeps the row in registers (8 * NV logits per thread)
+  if (V % 8 == 0 && ld % 8 == 0 && V <= 1024 * 8 * 20) {
+    if (V <= 1024 * 8 * 4) hipLaunchKernelGGL(lstk_row_kernel<4>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
+    else if (V <= 1024 * 8 * 8) hipLaunchKernelGGL(lstk_row_kernel<8>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
+    else hipLaunchKernelGGL(lstk_row_kernel<20>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
+    KCHK();
+    return 0;
+  }
   if (!ctx) return fail("logsoftmax_topk: needs a ctx (scratch)");
   hipLaunchKernelGGL(lstk_stats_kernel, dim3(M, LSTK_CHUNKS), dim3(256), 0, s, (const bf16_t*)logits, ld, V, ctx->lstk_stats);
   KCHK();
@@ -657,7 +665,7 @@ extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* 
 }
 extern "C" int vispec_argmax_rows(vispec_ctx*, void* stream, const void* logits, int ld, int M, int V, int* out_idx) {
   if (V % 8 || ld % 8) return fail("argmax_rows: V and ld must be multiples of 8");
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, out_idx);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, out_idx);
   KCHK();
   return 0;
 }
@@ -776,10 +784,12 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
 }
 
 // fc(cat(emb, img_fc(cat(h, g))))  for `rows` rows already gathered:  dx1 = [h | g], dx2[:, :D] = emb   (cnets_ours.py:918-922,982-988)
-static int draft_fuse(vispec_ctx* ctx, hipStream_t s, int rows, void* out, int ld_out) {
+// bcast_g: (re)write the right half of dx1 with the current global image feature g.  g changes only inside the draft prefill (one new
+// g per image run); vispec_draft_prefill leaves dx1[:, D:2D] = final g for all rows, so the decode rounds never touch it.
+static int draft_fuse(vispec_ctx* ctx, hipStream_t s, int rows, void* out, int ld_out, bool bcast_g) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size;
-  if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
+  if (bcast_g && launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
   if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, rows, D, 2 * D, EPI_NONE))
     return -1;
   return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, rows, D, 2 * D, EPI_NONE);
@@ -817,12 +827,12 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
   if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
   if (launch_lstopk(ctx, s, ctx->dlogits, V, 1, V, k, ctx->top_idx, ctx->top_logp)) return -1;
-  hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, ctx->in_h, D);
+  // the tree kernels stage the next level's inputs themselves: dx1[:, :D] = input_hidden, dx2[:, :D] = embed(input_ids)
+  hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast,
+                     (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
   KCHK();
   for (int lvl = 0; lvl < c.depth; ++lvl) {
-    if (launch_gather(s, ctx->in_h, D, nullptr, 0, nullptr, ctx->dx1, 2 * D, k, D)) return -1;  // dx1[:, :D] = input_hidden
-    if (launch_gather(s, ctx->dw.embed, D, ctx->tb.in_ids, 0, nullptr, ctx->dx2, 2 * D, k, D)) return -1;
-    if (draft_fuse(ctx, s, k, ctx->dx, D)) return -1;
+    if (draft_fuse(ctx, s, k, ctx->dx, D, false)) return -1;
     PosSpec ps;  // position_ids = len_posi + i for all k rows (cnets_ours.py:1128,1137); KV rows appended after the stable KV
     ps.base = &ctx->st->n_ctx;
     ps.add = lvl;
@@ -832,8 +842,8 @@ static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
     if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
     if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
     if (launch_lstopk(ctx, s, ctx->dlogits, V, k, V, k, ctx->top_idx, ctx->top_logp)) return -1;
-    hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(256), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
-                       ctx->in_h, D);
+    hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
+                       (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
     KCHK();
   }
   hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1,
@@ -851,16 +861,14 @@ extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
 static int draft_round_body(vispec_ctx* ctx, hipStream_t s) {
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, MC = c.depth + 2;  // a+1 <= depth+2 catch-up rows; rows beyond a are scratch
-  // catch-up forward on the accepted hidden states (cnets_ours.py:1090-1097)
-  if (launch_gather(s, ctx->accept_hidden, D, nullptr, 0, nullptr, ctx->dx1, 2 * D, MC, D)) return -1;
-  if (launch_gather(s, ctx->dw.embed, D, ctx->draft_ids, 0, nullptr, ctx->dx2, 2 * D, MC, D)) return -1;
-  if (draft_fuse(ctx, s, MC, ctx->dx, D)) return -1;
+  // catch-up forward on the accepted hidden states (cnets_ours.py:1090-1097); its inputs (dx1[:, :D] = accepted hidden rows,
+  // dx2[:, :D] = embeddings of the ids they pair with) were staged by the accept step (post_accept_kernel)
+  if (draft_fuse(ctx, s, MC, ctx->dx, D, false)) return -1;
   PosSpec ps;  // positions continue from the REAL length, KV rows from the compressed length (cnets_ours.py:845-868)
   ps.base = &ctx->st->draft_real_len;
   ps.kv_base = &ctx->st->draft_len;
   if (draft_layer(ctx, s, MC, ps, &ctx->st->draft_len, MC, ctx->causal_mask)) return -1;
-  if (launch_gather(s, ctx->dout, D, nullptr, 0, &ctx->st->accept_len, ctx->dlast, D, 1, D)) return -1;  // out_hidden[:, -1]
-  hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(64), 0, s, ctx->st);
+  hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(256), 0, s, ctx->st, ctx->dout, ctx->dlast, D);  // + dlast = out_hidden[:, -1]
   KCHK();
   return draft_grow_tree(ctx, s);
 }
@@ -931,7 +939,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
         const int rows = std::min(CHUNK, op.n - o), r0 = op.c_row + o;
         if (launch_gather(s, hidden, D, ctx->idx_tmp, r0, nullptr, ctx->dx1, 2 * D, rows, D)) return -1;
         if (launch_gather(s, ctx->emb_shift, D, ctx->idx_tmp, r0, nullptr, ctx->dx2, 2 * D, rows, D)) return -1;
-        if (draft_fuse(ctx, s, rows, ctx->xc + (size_t)r0 * D, D)) return -1;
+        if (draft_fuse(ctx, s, rows, ctx->xc + (size_t)r0 * D, D, true)) return -1;
       }
       continue;
     }
@@ -992,6 +1000,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     return -1;
   hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, s, ctx->st, first_token_dev, Lc, L);
   KCHK();
+  if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, ROWS, D)) return -1;  // the request's final g, for every later draft_fuse
   return draft_grow_tree(ctx, s);
 }
 
@@ -1001,14 +1010,15 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
   const int QKV = (H + 2 * Hk) * 128;
   if (!ctx->target_kv) return fail("target KV not set");
   // embed the tree tokens (modeling_llama_kv.py:985)
-  if (launch_gather(s, ctx->tm.embed, D, ctx->tb.tree_tokens, 0, nullptr, ctx->xa, D, T, D)) return -1;
+  hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(T), dim3(256), 0, s, (const bf16_t*)ctx->tm.embed, ctx->tb.tree_tokens, ctx->xa,
+                     (const bf16_t*)ctx->layers[0].ln1, ctx->xn, D, c.rms_eps);
+  KCHK();
   PosSpec ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
   ps.base = &ctx->st->n_ctx;
   ps.base2 = &ctx->st->rope_delta;
   ps.off = ctx->tb.tree_pos;
   ps.kv_base = &ctx->st->n_ctx;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
-  if (launch_rmsnorm(s, ctx->xa, ctx->layers[0].ln1, ctx->xn, T, D, c.rms_eps)) return -1;
   for (int l = 0; l < c.num_layers; ++l) {
     const vispec_layer_weights& w = ctx->layers[l];
     bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
@@ -1038,7 +1048,7 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
   }
   if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE, ctx->tm.lm_head_scale))
     return -1;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(256), 0, s, ctx->logits, V, V, ctx->am);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(1024), 0, s, ctx->logits, V, V, ctx->am);
   KCHK();
   return 0;
 }
@@ -1053,12 +1063,13 @@ static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accep
     hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
                        ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
   KCHK();
-  if (T > 1) {
-    hipLaunchKernelGGL(kv_compact_kernel, dim3(2 * c.num_layers * Hk), dim3(64), 0, s, ctx->target_kv, c.max_pos, ctx->st, ctx->sel);
-    KCHK();
-  }
-  // accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1]   (utils.py:543-546)
-  return launch_gather(s, ctx->hidden_new, D, ctx->sel, 0, nullptr, ctx->accept_hidden, D, TREE_RET_W, D);
+  // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
+  // for the draft's catch-up forward
+  const int n_kv = T > 1 ? 2 * c.num_layers * Hk : 0;
+  hipLaunchKernelGGL(post_accept_kernel, dim3(n_kv + TREE_RET_W), dim3(256), 0, s, ctx->target_kv, c.max_pos, n_kv, ctx->st, ctx->sel,
+                     ctx->hidden_new, ctx->accept_hidden, ctx->draft_ids, (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
+  KCHK();
+  return 0;
 }
 
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
