@@ -56,8 +56,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_models(device, seed, rank, world, lanes):
-    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU."""
+def build_models(device, seed, rank, world, lanes, cohort=1):
+    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2 every lane
+    also gets a cohort member (second request context on the same weight pass): returns [leader, member] lists then."""
     from vispec_amd import parallel, synth_gpu
     from vispec_amd.engine import LLAVA_16_7B, DraftConfig, TargetConfig
     from vispec_amd.model import SpecModel
@@ -101,7 +102,8 @@ def build_models(device, seed, rank, world, lanes):
     for _ in range(lanes):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
-        sms.append(SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE))
+        lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
+        sms.append([lead, lead.make_cohort_member()] if cohort == 2 else lead)
     return sms, tcfg, t_rep
 
 
@@ -269,6 +271,9 @@ def main():
     ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
     ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
+    ap.add_argument("--cohort", type=int, default=1, choices=(1, 2),
+                    help="requests per lane that run their rounds in lockstep on ONE weight pass (2 = every GEMM of a round serves two "
+                         "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
                          "replicas (request i -> GPU i mod N, then over that GPU's lanes); 0 = one request per lane per step (weak scaling)")
@@ -308,19 +313,23 @@ def main():
 
     R = max(1, args.lanes)
     fp8 = MODEL.endswith("fp8")
-    sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R)
+    CO = args.cohort
+    sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R, CO)
+    pairs = sms if CO == 2 else None
+    sms = [p[0] for p in sms] if CO == 2 else sms  # the leaders double as the single-request models of the annotation legs
     sm = sms[0]
     eng = sm.engine
     K, W = args.steps, args.warmup
     streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
     # plan[lane][step] = request ids that lane runs in that step
     if args.requests > 0:  # strong scaling: the batch is fixed, request i -> replica i mod N (parallel.shard_requests), then lane
         mine = parallel.shard_requests(args.requests, rank, world)
         plan = [[[i + s * args.requests for i in mine[lane::R]] for s in range(W + K)] for lane in range(R)]
         scaling = "strong"
-    else:  # weak scaling: every (rank, lane) runs one request of its own per step
-        plan = [[[(rank * R + lane) + s * world * R] for s in range(W + K)] for lane in range(R)]
+    else:  # weak scaling: every (rank, lane) runs one request (cohort: two) of its own per step
+        plan = [[[((rank * R + lane) + s * world * R) * CO + j for j in range(CO)] for s in range(W + K)] for lane in range(R)]
         scaling = "weak"
     req_cache = {}
 
@@ -342,7 +351,16 @@ def main():
             torch.cuda.set_device(device)  # HIP's current device is per host thread; a new thread starts on device 0
             with torch.cuda.stream(streams[lane]):
                 for s_ in range(lo, hi):
-                    for i in plan[lane][s_]:
+                    todo = list(plan[lane][s_])
+                    while CO == 2 and not ar and len(todo) >= 2:  # two requests per weight pass
+                        ia, ib = todo.pop(0), todo.pop(0)
+                        outs = specgenerate_cohort(pairs[lane], [get_req(ia), get_req(ib)], max_new_tokens=MAX_NEW,
+                                                   temperature=args.temperature, seeds=[ia, ib])
+                        for o, new_token, idx, acc in outs:
+                            tok += int(new_token)
+                            rnd += idx + 1
+                            accs += acc
+                    for i in todo:
                         ids, pix = get_req(i)
                         if ar:
                             o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
@@ -451,9 +469,13 @@ def main():
                                   note="kernel_ms_per_round comes from the instrumented (un-graphed) request and only splits the round by kernel; "
                                        "the round's own time and roofline fraction are speedpy_comparable.ms_per_round / round_roofline_frac_of_8TBps")
             # aggregate over all lanes: the lanes share ONE copy of the weights but each streams it on its own
-            extra["aggregate"] = dict(lanes=R, rounds_per_s_per_gpu=round(rounds / world / dt, 2),
-                                      streamed_GBps_per_gpu=round(b_round * rounds / world / dt / 1e9, 1),
-                                      frac_of_8TBps=round(b_round * rounds / world / dt / 8e12, 4))
+            # (with a cohort the weight bytes of a round are SHARED by its two requests: bytes per request-round = weights / 2 + its own KV)
+            b_kv = b_round - algorithmic_bytes_per_round(tcfg, 0, 0, fp8)
+            b_req_round = (b_round - b_kv) / CO + b_kv
+            extra["aggregate"] = dict(lanes=R, cohort=CO, request_rounds_per_s_per_gpu=round(rounds / world / dt, 2),
+                                      algorithmic_GB_per_request_round=round(b_req_round / 1e9, 2),
+                                      streamed_GBps_per_gpu=round(b_req_round * rounds / world / dt / 1e9, 1),
+                                      frac_of_8TBps=round(b_req_round * rounds / world / dt / 8e12, 4))
             # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
             #      once on a single lane (latency) and once with the same lane concurrency as the timed region (throughput)
             if not args.no_ar:
@@ -492,7 +514,9 @@ def main():
             except Exception as e:  # never lose the GPU line to the CPU leg
                 extra["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(e).__name__}: {e}"[:300])
         per_step = (f"{args.requests} independent requests sharded round-robin over the {world} replica(s) and their lanes" if args.requests
-                    else f"1 request on each of {R} concurrent batch-1 lanes per GPU")
+                    else f"{CO} request{'s' if CO > 1 else ''} on each of {R} concurrent lanes per GPU")
+        if CO == 2:
+            per_step += " (every lane runs its two batch-1 requests in lockstep on one weight pass: each GEMM of a round is launched once for both)"
         line = {
             "metric": f"accepted output tokens/sec (ViSpec speculative decoding, {MODELS[MODEL]['name']} + ViSpec draft, T={args.temperature:g})",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -503,7 +527,7 @@ def main():
                                    f"a step = {per_step} (replicas share one weight copy per GPU)",
                        "weights": f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
                                   f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)",
-                       "parallelism": f"dp{world} x {R} lanes/GPU (independent replicas, one-time RCCL weight replication {t_rep:.2f}s)"},
+                       "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)"},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }
         line.update(extra)

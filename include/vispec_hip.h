@@ -74,6 +74,10 @@ const char* vispec_last_error(void);
 int  vispec_version(void);
 
 int  vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out);
+/* Cohort member: a second request context whose 64-row activation workspaces are the second 32-row tiles of `leader`'s, so that the
+   cohort round functions below can launch every GEMM once for both requests (same config as the leader; destroy it before the leader).
+   A member is otherwise an ordinary ctx: own round state, tree, KV caches (vispec_set_kv), prefill calls. */
+int  vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out);
 void vispec_ctx_destroy(vispec_ctx* ctx);
 int  vispec_set_target_layer(vispec_ctx*, int layer, const vispec_layer_weights*);
 int  vispec_set_target_misc(vispec_ctx*, const vispec_target_misc*);
@@ -176,6 +180,14 @@ int vispec_set_retrieve_host(vispec_ctx*, void* stream, const int* retrieve, int
 /* One decode call of topK_genrate (cnets_ours.py:1043-1238, stable_kv branch) on the hidden states accepted by the
    last vispec_verify_accept. */
 int vispec_draft_round(vispec_ctx*, void* stream);
+
+/* The same two round functions for a COHORT of two independent requests (leader + member ctx) running their rounds in lockstep:
+   a round is bound by the HBM stream of the weights, so every GEMM is launched once on 64 activation rows (tile t = request t) and the
+   weights are read once for both; trees, accept decisions, KV caches, attention and round state stay per request.  Each request keeps
+   the reference's batch-1 semantics (spec_model_ours.py:247-582 per request) and produces the tokens it would produce alone, bit for
+   bit.  A request that has finished (done != 0) is frozen on the device while its partner completes.  total_token <= 32. */
+int vispec_cohort_verify_accept(vispec_ctx* leader, vispec_ctx* member, void* stream, int forced_accept);
+int vispec_cohort_draft_round(vispec_ctx* leader, vispec_ctx* member, void* stream);
 
 /* second stop token of the current request (`is_llama3`: "<|eot_id|>", spec_model_ours.py:268-269,540-542); call after
    vispec_begin_request, which clears it; -1 = none */

@@ -64,6 +64,8 @@ struct DevState {
   int stop2;        // second stop token (llama-3 "<|eot_id|>", spec_model_ours.py:268-269,540-542); -1 = none
   int draft_rope_rows;  // rows of the draft's rotary tables: draft rows rotate at their UNCOMPRESSED position (cnets_ours.py:845-868)
   int draft_round_rows; // draft KV rows one round appends behind the stable KV: catch-up (<= depth+2) + top_k per tree level
+  int frozen;       // the request had already finished (done != 0) when the last accept step ran: that step and everything after it
+                    // in the round left the request's state alone (a cohort keeps launching rounds until its last request is done)
 };
 #define KV_GUARD_ROWS 64  // rows kept free beyond the next tree (the AR baseline polls `done` only every 16 steps)
 
@@ -103,12 +105,14 @@ struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m 
 // meet in one lane, so the q and k rows of the weight are packed in "rope order": 32-row tile t of a head holds
 // d = 16t..16t+15 followed by d+64 (qkv_rope_perm(); v rows keep their order).  q goes to Y at its natural column, k / v
 // go straight to cache row *kv_base + kv_add + m.
+// Cohort mode (m_tile > 0, two requests sharing one weight pass): activation tile mt belongs to request mt, which has its own
+// positions and its own KV cache -> index [mt]; otherwise index 0 serves every row.
 struct RopeEpi {
   const bf16_t* cosT = nullptr;
   const bf16_t* sinT = nullptr;
-  PosSpec ps;
-  bf16_t* kc = nullptr;
-  bf16_t* vc = nullptr;
+  PosSpec ps[2];
+  bf16_t* kc[2] = {nullptr, nullptr};
+  bf16_t* vc[2] = {nullptr, nullptr};
   int s_max = 0, H = 0, H_kv = 0;
 };
 
@@ -170,7 +174,10 @@ template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int
 __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
-                                                           int S, const float* __restrict__ wscale, RopeEpi re) {
+                                                           int S, const float* __restrict__ wscale, RopeEpi re, int m_tile) {
+  // m_tile > 0 ("cohort"): the MT activation tiles belong to different requests, rows 32 mt .. 32 mt + m_tile - 1 of each are valid
+  // (instead of the contiguous rows 0 .. M-1); the weights are still streamed once for all of them
+  auto row_ok = [&](int m) { return m_tile > 0 ? ((m & 31) < m_tile) : (m < M); };
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     const int row = srow0 + i * RPI;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)  // rows >= M read row 0, never stored
-      sx[mt][i] = X + (size_t)(32 * mt + row < M ? 32 * mt + row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;
+      sx[mt][i] = X + (size_t)(row_ok(32 * mt + row) ? 32 * mt + row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;
     woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
   const int roff = hi * XS_HALF + j * 16;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     const bf16_t* px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      px[mt] = X + (size_t)(32 * mt + j < M ? 32 * mt + j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
+      px[mt] = X + (size_t)(row_ok(32 * mt + j) ? 32 * mt + j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
     for (int rstep = n_groups * LOADS; rstep < n_steps; ++rstep) {
       const uint4 av = pa0[0];
       const uint4 av1 = pa1[0];
@@ -351,7 +358,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
     // waves 0/1 own column groups q and q+2 of the tile: packed columns c = 8q + 4hi + r (< 16) and c + 16 = its rotate_half partner
     for (int mt = 0; mt < MT; ++mt) {
       const int m = 32 * mt + j;
-      if (wave < 2 && m < M) {
+      const int rq = m_tile > 0 ? mt : 0;        // request owning this tile
+      const int mr = m_tile > 0 ? j : m;         // row index inside the request
+      if (wave < 2 && row_ok(m)) {
         const int qq = wave;
         float a[4], b[4];
 #pragma unroll
@@ -367,11 +376,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
         }
         const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
         const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
-        const int kvrow = (re.ps.kv_base ? *re.ps.kv_base : 0) + re.ps.kv_add + m;
+        const PosSpec& ps_ = re.ps[rq];
+        const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + mr;
         if (h < re.H + re.H_kv) {
           const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of a[] / b[]
-          const int pos = (re.ps.base ? *re.ps.base : 0) + (re.ps.base2 ? *re.ps.base2 : 0) + re.ps.add +
-                          (re.ps.off ? re.ps.off[m] : (re.ps.row ? m : 0));
+          const int pos = (ps_.base ? *ps_.base : 0) + (ps_.base2 ? *ps_.base2 : 0) + ps_.add +
+                          (ps_.off ? ps_.off[mr] : (ps_.row ? mr : 0));
           float o1[4], o2[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
             o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
           }
           bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
-                                   : re.kc + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+                                   : re.kc[rq] + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
           *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
         } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
             o1[r] = rdbf(x1);
             o2[r] = rdbf(x2);
           }
-          bf16_t* dst = re.vc + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+          bf16_t* dst = re.vc[rq] + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
           *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
         }
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
         b[r] = sb;
       }
       const int n = tile * 16 + 8 * qq + 4 * hi;  // output column of a[0]; gate row n, up row N + n of the natural weight
-      if (m < M && n < N) {
+      if (row_ok(m) && n < N) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
         if (EPI == EPI_SWIGLU) u2[r] *= wscale[tile2_off * 32 + n + r];
       }
     }
-    if (m < M && n < N) {
+    if (row_ok(m) && n < N) {
       if (EPI == EPI_PARTIAL) {
         float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * (32 * MT) + m) * N + n;
         *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int Mpad, int N,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                             bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
-                                                            bf16_t* __restrict__ normed, int ldn, float eps) {
+                                                            bf16_t* __restrict__ normed, int ldn, float eps, int m_tile) {
   // Latency-bound (a few MB out of L2 per launch, 80 launches per round): every load of a row chunk — up to 8 partial slabs with
   // clamped (always valid) slab indices, residual, bias, norm weight — is issued before the first use, and a row that fits one
   // pass of the block (N <= 4 x threads: every model here) keeps its values in registers across the block-wide sum of squares.
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable): only for rows longer than one pass
   __shared__ float partsum[16];
   const int m = blockIdx.x;
+  if (m_tile > 0 && (m & 31) >= m_tile) return;  // cohort mode: padding rows between the requests' tiles
   const int nthreads = blockDim.x;
   const bool one_pass = N <= nthreads * 4;
   float ss = 0.f;

@@ -229,6 +229,11 @@ __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __res
                                      int forced_accept, int* __restrict__ draft_ids) {
   __shared__ int acc[TREE_MAX_T];
   const int tid = threadIdx.x;
+  if (st->done) {  // finished request (its cohort partner is still running): freeze
+    __syncthreads();
+    if (tid == 0) st->frozen = 1;
+    return;
+  }
   const int n_leaf = st->n_leaf, md = st->max_depth;
   if (tid < n_leaf) {
     const int* row = tb.retrieve + tid * TREE_RET_W;
@@ -427,6 +432,11 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   __shared__ int s_i[2];
   __shared__ int s_hist[258];
   const int tid = threadIdx.x;
+  if (st->done) {  // finished request (its cohort partner is still running): freeze
+    __syncthreads();
+    if (tid == 0) st->frozen = 1;
+    return;
+  }
   const int nl = st->n_leaf, md = st->max_depth, round = st->rounds;
   if (tid < nl)
     for (int c = 0; c < TREE_RET_W; ++c) {
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ k
                                                           const bf16_t* __restrict__ draft_embed, bf16_t* __restrict__ dx1,
                                                           bf16_t* __restrict__ dx2, int D) {
   constexpr int HD = 128;
+  if (st->frozen) return;
   if ((int)blockIdx.x < n_kv) {
     const int a = st->accept_len, n = st->n_prev;
     if (a == 0 || threadIdx.x >= 64) return;
@@ -573,6 +584,7 @@ __global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ k
 // Draft-side bookkeeping after the catch-up forward: the a+1 new rows become part of stable_kv (cnets_ours.py:1108) and the last
 // of them (out_hidden[:, -1], :1109) is what the tree grows from.
 __global__ __launch_bounds__(256) void draft_advance_kernel(DevState* st, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dlast, int D) {
+  if (st->frozen) return;
   const int a = st->accept_len;
   for (int d = threadIdx.x * 8; d < D; d += 256 * 8)
     *reinterpret_cast<uint4*>(dlast + d) = *reinterpret_cast<const uint4*>(dout + (size_t)a * D + d);

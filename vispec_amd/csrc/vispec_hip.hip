@@ -46,7 +46,7 @@ struct vispec_ctx {
   int *am, *sel, *draft_ids;
   bf16_t* accept_hidden;  // [16, D]
   // draft buffers
-  bf16_t *dx1, *dx2, *dx, *dqkv, *dattn, *dh, *dn, *dact, *dout, *dlast, *in_h, *dlogits, *dg;
+  bf16_t *dx1, *dx2, *dx, *dqkv, *dattn, *dh, *dn, *dact, *dout, *dlast, *dlogits, *dg;
   bf16_t *xc, *emb_shift, *ad_kv, *ad_out, *ad_tmp;  // prefill-only scratch
   int *top_idx, *pos_c, *idx_tmp, *idx_img, *scratch_int;
   int* h_pin = nullptr;  // pinned host staging for the prefill's index lists [3 * draft_max_pos]
@@ -71,13 +71,18 @@ struct vispec_ctx {
     int n_hint = -1, forced_accept = 0, total_token = 0, sample_top_k = 0;
     float temperature = 0.f;
     unsigned long long seed = 0;
+    int n_hint2 = -1, sample_top_k2 = 0;  // the second request of a cohort round
+    float temperature2 = 0.f;
+    unsigned long long seed2 = 0;
     bool operator==(const GraphKey& o) const {
       return n_hint == o.n_hint && forced_accept == o.forced_accept && total_token == o.total_token && sample_top_k == o.sample_top_k &&
-             memcmp(&temperature, &o.temperature, sizeof(float)) == 0 && seed == o.seed;
+             memcmp(&temperature, &o.temperature, sizeof(float)) == 0 && seed == o.seed && n_hint2 == o.n_hint2 &&
+             sample_top_k2 == o.sample_top_k2 && memcmp(&temperature2, &o.temperature2, sizeof(float)) == 0 && seed2 == o.seed2;
     }
   };
   struct GraphSlot { hipGraphExec_t exec = nullptr; GraphKey key; };
-  GraphSlot g_verify, g_draft, g_ar;
+  GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft;
+  vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are the second 32-row tiles of the leader's
   float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
   int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
   unsigned long long seed = 0;
@@ -101,8 +106,10 @@ extern "C" int vispec_version(void) { return 1; }
 
 #define ROWS 64   /* rows of the activation workspaces */
 #define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
-extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
+static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
+  if (leader && (leader->leader || memcmp(&leader->c, cfg, sizeof(vispec_config)) != 0))
+    return fail("ctx_create_member: the leader must be an ordinary ctx created with the same config");
   const vispec_config& c = *cfg;
   if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
   if (c.hidden_size % 64 || c.intermediate_size % 64 || c.draft_intermediate % 64 || c.vocab_size % 16)
@@ -116,6 +123,7 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   if (c.draft_rope_rows < 0) return fail("draft_rope_rows must be >= 0");
   vispec_ctx* ctx = new vispec_ctx();
   ctx->c = c;
+  ctx->leader = leader;
   ctx->layers.resize(c.num_layers);
   const size_t D = c.hidden_size, I = c.intermediate_size, Id = c.draft_intermediate, V = c.vocab_size;
   const size_t QKV = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
@@ -124,17 +132,22 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
     vispec_ctx_destroy(ctx);                      \
     return -1;                                    \
   }
+  // row-wise activation workspaces (ROWS = 64 rows of `ld` elements): a cohort member's are the second 32-row tiles of its leader's,
+  // so that a GEMM launched once on the leader's 64 rows serves both requests
+#define AL(p, ld)                                           \
+  if (leader) ctx->p = leader->p + (size_t)32 * (ld);      \
+  else A(p, (size_t)ROWS * (ld))
   A(st, 1);
   ctx->tokens_cap = c.max_pos + 64;
   A(tokens, ctx->tokens_cap);
   ctx->log_cap = c.max_pos;
   A(accept_log, ctx->log_cap);
-  A(xa, ROWS * D); A(xn, ROWS * D); A(qkv, ROWS * QKV); A(attn_o, ROWS * (size_t)c.num_heads * c.head_dim);
-  A(act, ROWS * I); A(hidden_new, ROWS * D); A(logits, ROWS * V);
-  A(am, ROWS); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D);
-  A(dx1, ROWS * 2 * D); A(dx2, ROWS * 2 * D); A(dx, ROWS * D); A(dqkv, ROWS * 3 * D); A(dattn, ROWS * D);
-  A(dh, ROWS * D); A(dn, ROWS * D); A(dact, ROWS * Id); A(dout, ROWS * D); A(dlast, 16 * D); A(in_h, 16 * D);
-  A(dlogits, 16 * V); A(dg, D);
+  AL(xa, D); AL(xn, D); AL(qkv, QKV); AL(attn_o, (size_t)c.num_heads * c.head_dim);
+  AL(act, I); AL(hidden_new, D); AL(logits, V);
+  AL(am, 1); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D);
+  AL(dx1, 2 * D); AL(dx2, 2 * D); AL(dx, D); AL(dqkv, 3 * D); AL(dattn, D);
+  AL(dh, D); AL(dn, D); AL(dact, Id); AL(dout, D); AL(dlast, D);
+  AL(dlogits, V); A(dg, D);
   const int scr = c.max_pos > c.draft_max_pos ? c.max_pos : c.draft_max_pos;
   ctx->scr_rows = scr;
   ctx->rope_rows = c.draft_rope_rows > 0 ? c.draft_rope_rows : c.draft_max_pos;
@@ -174,10 +187,12 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
     if (nmax < (size_t)3 * c.hidden_size) nmax = (size_t)3 * c.hidden_size;
     if (nmax < 16384) nmax = 16384;
     ctx->gemm_part_elems = (size_t)8 * 64 * nmax;
-    A(gemm_part, ctx->gemm_part_elems);
+    if (leader) ctx->gemm_part = leader->gemm_part;  // launches of a cohort are stream-ordered: one partial workspace serves both
+    else A(gemm_part, ctx->gemm_part_elems);
     A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
   }
 #undef A
+#undef AL
   ctx->n_hint = c.max_pos;
   const int lds = ATT_LDS_BYTES;
   if (hipFuncSetAttribute((const void*)tree_attn_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -190,9 +205,15 @@ extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) {
   return 0;
 }
 
+extern "C" int vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out) { return ctx_create_impl(cfg, nullptr, out); }
+extern "C" int vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
+  if (!leader) return fail("ctx_create_member: null leader");
+  return ctx_create_impl(cfg, leader, out);
+}
+
 extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
   if (!ctx) return;
-  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar})
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft})
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -324,6 +345,7 @@ struct GemmOut {
   void* Y = nullptr; int ldy = 0;
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
+  int m_tile = 0;  // > 0: cohort mode — two requests share the weight pass: tile t holds request t's rows 32t .. 32t + m_tile - 1 (M = 32 + m_tile)
 };
 // MT = number of 32-row activation tiles (M <= 32*MT): each weight tile held in registers feeds MT MFMAs, so trees of 33..64
 // nodes (and two requests sharing a launch) still stream every weight once.
@@ -337,7 +359,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
   PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
-                     T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{})
+                     T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile)
   if (epi == EPI_SWIGLU) {  // weight in "SwiGLU order" (vispec_pack_weight docs): N/16 workgroups of one 32-row tile each
     if (N % 16) return fail("gemm_skinny: SwiGLU needs N %% 16 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
@@ -376,7 +398,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   prof_begin(s, 4, 0.0);
   PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
                      N, b, epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed,
-                     o.ldn, o.eps);
+                     o.ldn, o.eps, o.m_tile);
   KCHK();
   prof_end(s);
   return 0;
@@ -384,6 +406,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1) {
+  if (o.m_tile > 0 && (M != 32 + o.m_tile || o.m_tile > 32)) return fail("gemm_skinny: cohort mode wants M = 32 + m_tile");
   if (M <= 32) return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   if (M <= 64) return launch_gemm_mt<2>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   return fail("gemm_skinny: M must be in [1,64]");
@@ -391,9 +414,10 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 
 // legacy-shaped helper used by most call sites
 static int launch_gemm(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, void* Y, int ldy,
-                       const void* R, int ldr, int M, int N, int K, int epi, const void* wscale = nullptr) {
+                       const void* R, int ldr, int M, int N, int K, int epi, const void* wscale = nullptr, int m_tile = 0) {
   GemmOut o;
   o.wscale = (const float*)wscale;
+  o.m_tile = m_tile;
   o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr;
   return launch_gemm_ex(ctx, s, X, ldx, P, bias, M, N, K, epi, o);
 }
@@ -451,29 +475,47 @@ static int launch_rope(hipStream_t s, void* qkv, int M, int H, int H_kv, const v
 // split-K GEMM is followed by rope_append2_kernel on a naturally ordered weight.
 // (un-split: with >= 128 row blocks one launch beats split-K + reduce + rotary launches even on a half-filled chip — choose_split)
 static bool qkv_rope_fused(int n_rows) { return n_rows % 128 == 0 && n_rows / 32 >= 128; }
+struct QkvReq {  // per-request part of a q|k|v projection: positions and the cache it appends to
+  PosSpec ps;
+  void* kc = nullptr;
+  void* vc = nullptr;
+};
+// n_req = 1: rows 0 .. M-1 of X belong to rq[0].  n_req = 2 (cohort): request t owns rows 32t .. 32t + M - 1, the weights are
+// streamed once for both.
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
-                           void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, PosSpec ps, void* kc, void* vc,
+                           void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, const QkvReq* rq, int n_req,
                            int s_max) {
   const int N = (H + 2 * H_kv) * 128;
+  const int m_tile = n_req == 2 ? M : 0, Mk = n_req == 2 ? 32 + M : M;
   if (!qkv_rope_fused(N)) {
-    if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, M, N, K, EPI_NONE, wscale)) return -1;
-    return launch_rope(s, qkv, M, H, H_kv, cosT, sinT, ps, kc, vc, s_max, 1);
+    if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, Mk, N, K, EPI_NONE, wscale, m_tile)) return -1;
+    for (int t = 0; t < n_req; ++t)
+      if (launch_rope(s, (bf16_t*)qkv + (size_t)32 * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
+    return 0;
   }
-  if (M < 1 || M > 64) return fail("gemm_qkv_rope: M must be in [1,64]");
+  if (M < 1 || Mk > 64) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
   RopeEpi re;
-  re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT; re.ps = ps; re.kc = (bf16_t*)kc; re.vc = (bf16_t*)vc;
+  re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
+  for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
   prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
 #define VISPEC_QKV(W8_, MT_)                                                                                                              \
   PLAUNCH((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, MT_>()), s, \
-                     (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, M, N, K, 1, (const float*)wscale, re)
-  if (M <= 32) { if (wscale) VISPEC_QKV(true, 1); else VISPEC_QKV(false, 1); }
+                     (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1, (const float*)wscale, re, m_tile)
+  if (Mk <= 32) { if (wscale) VISPEC_QKV(true, 1); else VISPEC_QKV(false, 1); }
   else { if (wscale) VISPEC_QKV(true, 2); else VISPEC_QKV(false, 2); }
 #undef VISPEC_QKV
   KCHK();
   prof_end(s);
   return 0;
+}
+static int launch_qkv_rope1(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
+                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, PosSpec ps, void* kc, void* vc,
+                            int s_max) {
+  QkvReq rq;
+  rq.ps = ps; rq.kc = kc; rq.vc = vc;
+  return launch_qkv_rope(ctx, s, X, ldx, P, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, &rq, 1, s_max);
 }
 
 // prefix = (prefix_dev ? *prefix_dev : 0) + prefix_add is folded by a tiny helper kernel into a scratch int when needed
@@ -591,16 +633,16 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
-                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{})
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (dbg == 1) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 1>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
     KCHK();
     return 0;
   }
   if (dbg == 2) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{});
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
     KCHK();
     return 0;
   }
@@ -617,7 +659,7 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   KCHK();
   if (no_reduce) return 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(256), 0, s, ctx->gemm_part, S, 32, N, nullptr, nullptr, 0, (bf16_t*)Y, ldy, nullptr,
-                     nullptr, 0, 0.f);
+                     nullptr, 0, 0.f, 0);
   KCHK();
   return 0;
 }
@@ -653,7 +695,7 @@ extern "C" int vispec_gemm_qkv_rope(vispec_ctx* ctx, void* stream, const void* X
   ps.base = pos_base_dev;
   ps.off = pos_off_dev;
   ps.kv_base = kv_base_dev;
-  return launch_qkv_rope(ctx, (hipStream_t)stream, X, ldx, W, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, ps, k_cache, v_cache, s_max);
+  return launch_qkv_rope1(ctx, (hipStream_t)stream, X, ldx, W, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, ps, k_cache, v_cache, s_max);
 }
 extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* q, int ldq, const void* k_cache,
                                      const void* v_cache, int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev,
@@ -784,93 +826,147 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
 }
 
 // fc(cat(emb, img_fc(cat(h, g))))  for `rows` rows already gathered:  dx1 = [h | g], dx2[:, :D] = emb   (cnets_ours.py:918-922,982-988)
+// ---- cohorts ----------------------------------------------------------------------------------------------------------------------
+// A round is HBM-bound on the weights, so two requests that run their rounds in lockstep can share ONE weight pass: every GEMM of the
+// round is launched once on 64 activation rows — tile t (rows 32t ..) belongs to request t (gemm_w32_kernel's m_tile mode) — while
+// everything that is per request (tree, accept, KV caches, attention, round state) stays per request: each request keeps its own
+// vispec_ctx, and the "member" ctx's activation buffers are simply the second 32-row tiles of the "leader's" (vispec_ctx_create_member).
+// Every request keeps the reference's batch-1 semantics; its tokens are bit-identical to a run on its own (the 64-row GEMM computes
+// each row with the same tiles, in the same order).  n == 1 is the ordinary single-request round.
+struct Cohort {
+  int n;
+  vispec_ctx* c[2];
+  vispec_ctx* lead() const { return c[0]; }
+  int mt(int rows) const { return n == 2 ? rows : 0; }       // m_tile argument
+  int M(int rows) const { return n == 2 ? 32 + rows : rows; }  // M argument of a shared GEMM
+};
+
 // bcast_g: (re)write the right half of dx1 with the current global image feature g.  g changes only inside the draft prefill (one new
 // g per image run); vispec_draft_prefill leaves dx1[:, D:2D] = final g for all rows, so the decode rounds never touch it.
-static int draft_fuse(vispec_ctx* ctx, hipStream_t s, int rows, void* out, int ld_out, bool bcast_g) {
+static int draft_fuse(const Cohort& co, hipStream_t s, int rows, void* out, int ld_out, bool bcast_g) {
+  vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size;
-  if (bcast_g && launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
-  if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, rows, D, 2 * D, EPI_NONE))
+  if (bcast_g)
+    for (int t = 0; t < co.n; ++t)
+      if (launch_bcast(s, co.c[t]->dg, co.c[t]->dx1 + D, 2 * D, rows, D)) return -1;
+  if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, co.M(rows), D, 2 * D, EPI_NONE, nullptr,
+                  co.mt(rows)))
     return -1;
-  return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, rows, D, 2 * D, EPI_NONE);
+  return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, co.M(rows), D, 2 * D, EPI_NONE, nullptr, co.mt(rows));
 }
 
-// the draft's single decoder layer on `rows` rows of ctx->dx (cnets_ours.py:545-600); result in ctx->dout
-static int draft_layer(vispec_ctx* ctx, hipStream_t s, int rows, PosSpec ps, const int* prefix_dev, int tail,
-                       const unsigned long long* mask) {
+// o_proj + residual -> post_attention_layernorm -> SwiGLU MLP -> + residual for `rows` rows per request (cnets_ours.py:575-600):
+// attention output in dattn, residual rows `resid` (ld D), result rows in `out` (ld D) — pointers of the leader's 64-row buffers.
+static int draft_layer_tail(const Cohort& co, hipStream_t s, int rows, const bf16_t* resid, bf16_t* out) {
+  vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
-  const int D = c.hidden_size, Hd = c.draft_heads;
-  bf16_t* kc = ctx->draft_kv;
-  bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
-  if (launch_qkv_rope(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D, ctx->dw.rope_cos,
-                      ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos))
-    return -1;
-  if (launch_attention(ctx, s, ctx->dqkv, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, rows, prefix_dev, tail, mask, ctx->dattn, D, 0,
-                       ctx->n_hint < c.draft_max_pos ? ctx->n_hint : c.draft_max_pos))
-    return -1;
+  const int D = c.hidden_size, Id = c.draft_intermediate;
   {
     GemmOut o;  // o_proj + residual, post_attention_layernorm fused into the split-K reduce
-    o.Y = ctx->dh; o.ldy = D; o.R = ctx->dx; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
-    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, rows, D, D, EPI_RESIDUAL, o)) return -1;
+    o.Y = ctx->dh; o.ldy = D; o.R = resid; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
+    o.m_tile = co.mt(rows);
+    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, co.M(rows), D, D, EPI_RESIDUAL, o)) return -1;
   }
-  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, rows, c.draft_intermediate, D,
-                  EPI_SWIGLU))
+  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, Id, nullptr, 0, co.M(rows), Id, D, EPI_SWIGLU, nullptr, co.mt(rows))) return -1;
+  return launch_gemm(ctx, s, ctx->dact, Id, ctx->dw.wdown, nullptr, out, D, ctx->dh, D, co.M(rows), D, Id, EPI_RESIDUAL, nullptr, co.mt(rows));
+}
+
+// the draft's single decoder layer on `rows` rows per request of dx (cnets_ours.py:545-600); result in dout.
+// level < 0: the catch-up forward (positions continue from the real length, causal mask); level >= 0: tree level (same position for
+// all rows, level mask).
+static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
+  vispec_ctx* ctx = co.lead();
+  const vispec_config& c = ctx->c;
+  const int D = c.hidden_size, Hd = c.draft_heads, k = c.top_k;
+  QkvReq rq[2];
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    PosSpec& ps = rq[t].ps;
+    if (level < 0) {  // positions continue from the REAL length, KV rows from the compressed length (cnets_ours.py:845-868)
+      ps.base = &x->st->draft_real_len;
+      ps.kv_base = &x->st->draft_len;
+    } else {  // position_ids = len_posi + i for all k rows (cnets_ours.py:1128,1137); KV rows appended after the stable KV
+      ps.base = &x->st->n_ctx;
+      ps.add = level;
+      ps.row = 0;
+      ps.kv_base = &x->st->draft_len;
+      ps.kv_add = level * k;
+    }
+    rq[t].kc = x->draft_kv;
+    rq[t].vc = x->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
+  }
+  if (launch_qkv_rope(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D, ctx->dw.rope_cos, ctx->dw.rope_sin, rq,
+                      co.n, c.draft_max_pos))
     return -1;
-  return launch_gemm(ctx, s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dout, D, ctx->dh, D, rows, D,
-                     c.draft_intermediate, EPI_RESIDUAL);
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    const int tail = level < 0 ? rows : k * (level + 1);
+    if (launch_attention(x, s, x->dqkv, 3 * D, rq[t].kc, rq[t].vc, c.draft_max_pos, Hd, Hd, rows, &x->st->draft_len, tail,
+                         level < 0 ? x->causal_mask : x->tb.lvl_mask, x->dattn, D, 0, x->n_hint < c.draft_max_pos ? x->n_hint : c.draft_max_pos))
+      return -1;
+  }
+  return draft_layer_tail(co, s, rows, ctx->dx, ctx->dout);
 }
 
 // head(last) -> log-softmax -> top-k, then `depth` tree levels and the final re-rank (cnets_ours.py:1109-1238).
-// Expects ctx->dlast = last hidden row, draft_len/real_len already advanced.
-static int draft_grow_tree(vispec_ctx* ctx, hipStream_t s) {
+// Expects dlast = last hidden row, draft_len/real_len already advanced.
+static int draft_grow_tree(const Cohort& co, hipStream_t s) {
+  vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
-  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, 1, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
-  if (launch_lstopk(ctx, s, ctx->dlogits, V, 1, V, k, ctx->top_idx, ctx->top_logp)) return -1;
-  // the tree kernels stage the next level's inputs themselves: dx1[:, :D] = input_hidden, dx2[:, :D] = embed(input_ids)
-  hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast,
-                     (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
-  KCHK();
-  for (int lvl = 0; lvl < c.depth; ++lvl) {
-    if (draft_fuse(ctx, s, k, ctx->dx, D, false)) return -1;
-    PosSpec ps;  // position_ids = len_posi + i for all k rows (cnets_ours.py:1128,1137); KV rows appended after the stable KV
-    ps.base = &ctx->st->n_ctx;
-    ps.add = lvl;
-    ps.row = 0;
-    ps.kv_base = &ctx->st->draft_len;
-    ps.kv_add = lvl * k;
-    if (draft_layer(ctx, s, k, ps, &ctx->st->draft_len, k * (lvl + 1), ctx->tb.lvl_mask)) return -1;
-    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, k, V, D, EPI_NONE, ctx->tm.lm_head_scale)) return -1;
-    if (launch_lstopk(ctx, s, ctx->dlogits, V, k, V, k, ctx->top_idx, ctx->top_logp)) return -1;
-    hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout,
-                       (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
+  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(1), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(1)))
+    return -1;
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    if (launch_lstopk(x, s, x->dlogits, V, 1, V, k, x->top_idx, x->top_logp)) return -1;
+    // the tree kernels stage the next level's inputs themselves: dx1[:, :D] = input_hidden, dx2[:, :D] = embed(input_ids)
+    hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(1024), 0, s, x->tb, x->top_idx, x->top_logp, k, x->dlast, (const bf16_t*)ctx->dw.embed,
+                       x->dx1, x->dx2, D);
     KCHK();
   }
-  hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1,
-                     ctx->temperature > 1e-5f ? 1 : 0);  // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
-  KCHK();
+  for (int lvl = 0; lvl < c.depth; ++lvl) {
+    if (draft_fuse(co, s, k, ctx->dx, D, false)) return -1;
+    if (draft_layer(co, s, k, lvl)) return -1;
+    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(k), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(k)))
+      return -1;
+    for (int t = 0; t < co.n; ++t) {
+      vispec_ctx* x = co.c[t];
+      if (launch_lstopk(x, s, x->dlogits, V, k, V, k, x->top_idx, x->top_logp)) return -1;
+      hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(1024), 0, s, x->tb, lvl, k, x->top_idx, x->top_logp, x->dout, (const bf16_t*)ctx->dw.embed,
+                         x->dx1, x->dx2, D);
+      KCHK();
+    }
+  }
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, x->tb, x->st, k, c.depth, c.total_token - 1,
+                       x->temperature > 1e-5f ? 1 : 0);  // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
+    KCHK();
+  }
   return 0;
 }
 
-static int draft_round_body(vispec_ctx* ctx, hipStream_t s);
-extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
-  if (!ctx) return fail("null ctx");
-  hipStream_t s = (hipStream_t)stream;
-  return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(ctx, s); });
-}
-static int draft_round_body(vispec_ctx* ctx, hipStream_t s) {
+static int draft_round_body(const Cohort& co, hipStream_t s) {
+  vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, MC = c.depth + 2;  // a+1 <= depth+2 catch-up rows; rows beyond a are scratch
   // catch-up forward on the accepted hidden states (cnets_ours.py:1090-1097); its inputs (dx1[:, :D] = accepted hidden rows,
   // dx2[:, :D] = embeddings of the ids they pair with) were staged by the accept step (post_accept_kernel)
-  if (draft_fuse(ctx, s, MC, ctx->dx, D, false)) return -1;
-  PosSpec ps;  // positions continue from the REAL length, KV rows from the compressed length (cnets_ours.py:845-868)
-  ps.base = &ctx->st->draft_real_len;
-  ps.kv_base = &ctx->st->draft_len;
-  if (draft_layer(ctx, s, MC, ps, &ctx->st->draft_len, MC, ctx->causal_mask)) return -1;
-  hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(256), 0, s, ctx->st, ctx->dout, ctx->dlast, D);  // + dlast = out_hidden[:, -1]
-  KCHK();
-  return draft_grow_tree(ctx, s);
+  if (draft_fuse(co, s, MC, ctx->dx, D, false)) return -1;
+  if (draft_layer(co, s, MC, -1)) return -1;
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(256), 0, s, x->st, x->dout, x->dlast, D);  // + dlast = out_hidden[:, -1]
+    KCHK();
+  }
+  return draft_grow_tree(co, s);
+}
+extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
+  if (!ctx) return fail("null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  const Cohort co{1, {ctx, nullptr}};
+  return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(co, s); });
 }
 
 extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* hidden, const void* embeds,
@@ -879,6 +975,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
+  const Cohort solo{1, {ctx, nullptr}};  // the prefill of a request always runs on its own (cohorts form in the decode rounds)
   // the prompt may be as long as the target cache allows (the reference's draft handles it, cnets_ours.py:879-975); what must fit the
   // draft's own cache is the COMPRESSED sequence (checked below), and every row is rotated at its real position < rope_rows
   if (L < 1 || L > ctx->scr_rows) return fail("draft_prefill: prompt does not fit the prefill scratch (max(max_pos, draft_max_pos) rows)");
@@ -939,7 +1036,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
         const int rows = std::min(CHUNK, op.n - o), r0 = op.c_row + o;
         if (launch_gather(s, hidden, D, ctx->idx_tmp, r0, nullptr, ctx->dx1, 2 * D, rows, D)) return -1;
         if (launch_gather(s, ctx->emb_shift, D, ctx->idx_tmp, r0, nullptr, ctx->dx2, 2 * D, rows, D)) return -1;
-        if (draft_fuse(ctx, s, rows, ctx->xc + (size_t)r0 * D, D, true)) return -1;
+        if (draft_fuse(solo, s, rows, ctx->xc + (size_t)r0 * D, D, true)) return -1;
       }
       continue;
     }
@@ -976,8 +1073,8 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     PosSpec ps;
     ps.off = ctx->pos_c + o;
     ps.kv_add = o;
-    if (launch_qkv_rope(ctx, s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D,
-                        ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos))
+    if (launch_qkv_rope1(ctx, s, ctx->xc + (size_t)o * D, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D,
+                         ctx->dw.rope_cos, ctx->dw.rope_sin, ps, kc, vc, c.draft_max_pos))
       return -1;
     last_chunk_rows = rows;
   }
@@ -987,55 +1084,55 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   KCHK();
   if (launch_attention(ctx, s, qlast, 3 * D, kc, vc, c.draft_max_pos, Hd, Hd, 1, ctx->scratch_int, 0, nullptr, ctx->dattn, D, 0, Lc))
     return -1;
-  {
-    GemmOut o;
-    o.Y = ctx->dh; o.ldy = D; o.R = xlast; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
-    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, 1, D, D, EPI_RESIDUAL, o)) return -1;
-  }
-  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, c.draft_intermediate, nullptr, 0, 1, c.draft_intermediate, D,
-                  EPI_SWIGLU))
-    return -1;
-  if (launch_gemm(ctx, s, ctx->dact, c.draft_intermediate, ctx->dw.wdown, nullptr, ctx->dlast, D, ctx->dh, D, 1, D, c.draft_intermediate,
-                  EPI_RESIDUAL))
-    return -1;
+  if (draft_layer_tail(solo, s, 1, xlast, ctx->dlast)) return -1;
   hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, s, ctx->st, first_token_dev, Lc, L);
   KCHK();
   if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, ROWS, D)) return -1;  // the request's final g, for every later draft_fuse
-  return draft_grow_tree(ctx, s);
+  return draft_grow_tree(solo, s);
 }
 
-static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
+static int target_forward(const Cohort& co, hipStream_t s, int T) {
+  vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, H = c.num_heads, Hk = c.num_kv_heads, V = c.vocab_size, I = c.intermediate_size;
   const int QKV = (H + 2 * Hk) * 128;
-  if (!ctx->target_kv) return fail("target KV not set");
-  // embed the tree tokens (modeling_llama_kv.py:985)
-  hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(T), dim3(256), 0, s, (const bf16_t*)ctx->tm.embed, ctx->tb.tree_tokens, ctx->xa,
-                     (const bf16_t*)ctx->layers[0].ln1, ctx->xn, D, c.rms_eps);
-  KCHK();
-  PosSpec ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
-  ps.base = &ctx->st->n_ctx;
-  ps.base2 = &ctx->st->rope_delta;
-  ps.off = ctx->tb.tree_pos;
-  ps.kv_base = &ctx->st->n_ctx;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
+  QkvReq rq[2];
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* x = co.c[t];
+    if (!x->target_kv) return fail("target KV not set");
+    // embed the tree tokens (modeling_llama_kv.py:985) + the first layer's input_layernorm
+    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(T), dim3(256), 0, s, (const bf16_t*)ctx->tm.embed, x->tb.tree_tokens, x->xa,
+                       (const bf16_t*)ctx->layers[0].ln1, x->xn, D, c.rms_eps);
+    KCHK();
+    PosSpec& ps = rq[t].ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
+    ps.base = &x->st->n_ctx;
+    ps.base2 = &x->st->rope_delta;
+    ps.off = x->tb.tree_pos;
+    ps.kv_base = &x->st->n_ctx;
+  }
   for (int l = 0; l < c.num_layers; ++l) {
     const vispec_layer_weights& w = ctx->layers[l];
-    bf16_t* kc = ctx->target_kv + (size_t)(2 * l) * slab;
-    bf16_t* vc = ctx->target_kv + (size_t)(2 * l + 1) * slab;
-    if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, ps, kc,
-                        vc, c.max_pos))
+    for (int t = 0; t < co.n; ++t) {
+      rq[t].kc = co.c[t]->target_kv + (size_t)(2 * l) * slab;
+      rq[t].vc = co.c[t]->target_kv + (size_t)(2 * l + 1) * slab;
+    }
+    if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
       return -1;
-    if (launch_attention(ctx, s, ctx->qkv, QKV, kc, vc, c.max_pos, H, Hk, T, &ctx->st->n_ctx, T, ctx->tb.tree_mask, ctx->attn_o,
-                         H * 128, c.eager_scores, ctx->n_hint))
-      return -1;
+    for (int t = 0; t < co.n; ++t) {
+      vispec_ctx* x = co.c[t];
+      if (launch_attention(x, s, x->qkv, QKV, rq[t].kc, rq[t].vc, c.max_pos, H, Hk, T, &x->st->n_ctx, T, x->tb.tree_mask, x->attn_o, H * 128,
+                           c.eager_scores, x->n_hint))
+        return -1;
+    }
     {
       GemmOut o;  // x += o_proj(attn) ; xn = post_attention_layernorm(x)   — one split-K GEMM + one reduce
       o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.norm_w = w.ln2; o.normed = ctx->xn; o.ldn = D; o.eps = c.rms_eps;
       o.wscale = (const float*)w.so;
-      if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, T, D, H * 128, EPI_RESIDUAL, o)) return -1;
+      o.m_tile = co.mt(T);
+      if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
     }
-    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, T, I, D, EPI_SWIGLU, w.sgu)) return -1;
+    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, co.M(T), I, D, EPI_SWIGLU, w.sgu, co.mt(T))) return -1;
     {
       GemmOut o;  // x += down(act) ; then the NEXT layer's input_layernorm, or the final model.norm (hidden_states[-1] is post-norm)
       const bool last = l + 1 == c.num_layers;
@@ -1043,50 +1140,87 @@ static int target_forward(vispec_ctx* ctx, hipStream_t s, int T) {
       o.norm_w = last ? ctx->tm.norm : ctx->layers[l + 1].ln1;
       o.normed = last ? ctx->hidden_new : ctx->xn;
       o.wscale = (const float*)w.sdown;
-      if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, T, D, I, EPI_RESIDUAL, o)) return -1;
+      o.m_tile = co.mt(T);
+      if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
     }
   }
-  if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, T, V, D, EPI_NONE, ctx->tm.lm_head_scale))
+  if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, co.M(T), V, D, EPI_NONE, ctx->tm.lm_head_scale,
+                  co.mt(T)))
     return -1;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(1024), 0, s, ctx->logits, V, V, ctx->am);
-  KCHK();
+  for (int t = 0; t < co.n; ++t) {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(1024), 0, s, co.c[t]->logits, V, V, co.c[t]->am);
+    KCHK();
+  }
   return 0;
 }
 
-static int target_accept(vispec_ctx* ctx, hipStream_t s, int T, int forced_accept) {
-  const vispec_config& c = ctx->c;
+static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_accept) {
+  const vispec_config& c = co.lead()->c;
   const int D = c.hidden_size, Hk = c.num_kv_heads;
-  if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
-    hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
-                       ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
-  else
-    hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
-                       ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
-  KCHK();
-  // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
-  // for the draft's catch-up forward
-  const int n_kv = T > 1 ? 2 * c.num_layers * Hk : 0;
-  hipLaunchKernelGGL(post_accept_kernel, dim3(n_kv + TREE_RET_W), dim3(256), 0, s, ctx->target_kv, c.max_pos, n_kv, ctx->st, ctx->sel,
-                     ctx->hidden_new, ctx->accept_hidden, ctx->draft_ids, (const bf16_t*)ctx->dw.embed, ctx->dx1, ctx->dx2, D);
-  KCHK();
+  for (int t = 0; t < co.n; ++t) {
+    vispec_ctx* ctx = co.c[t];
+    if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
+      hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
+                         ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
+    else
+      hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
+                         ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
+    KCHK();
+    // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
+    // for the draft's catch-up forward
+    const int n_kv = T > 1 ? 2 * c.num_layers * Hk : 0;
+    hipLaunchKernelGGL(post_accept_kernel, dim3(n_kv + TREE_RET_W), dim3(256), 0, s, ctx->target_kv, c.max_pos, n_kv, ctx->st, ctx->sel,
+                       ctx->hidden_new, ctx->accept_hidden, ctx->draft_ids, (const bf16_t*)co.lead()->dw.embed, ctx->dx1, ctx->dx2, D);
+    KCHK();
+  }
   return 0;
 }
 
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
+  const Cohort co{1, {ctx, nullptr}};
   return run_graphed(ctx, s, ctx->g_verify, graph_key(ctx, forced_accept, true), [&]() {
-    if (target_forward(ctx, s, ctx->c.total_token)) return -1;
-    return target_accept(ctx, s, ctx->c.total_token, forced_accept);
+    if (target_forward(co, s, ctx->c.total_token)) return -1;
+    return target_accept(co, s, ctx->c.total_token, forced_accept);
   });
 }
 extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
-  return target_forward(ctx, (hipStream_t)stream, ctx->c.total_token);
+  return target_forward(Cohort{1, {ctx, nullptr}}, (hipStream_t)stream, ctx->c.total_token);
 }
 extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
-  return target_accept(ctx, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+  return target_accept(Cohort{1, {ctx, nullptr}}, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+}
+
+// ---- cohort rounds: two requests (leader + member ctx), one weight pass -----------------------------------------------------------
+static int cohort_check(vispec_ctx* a, vispec_ctx* b) {
+  if (!a || !b) return fail("null ctx");
+  if (b->leader != a) return fail("cohort: the second ctx must have been created as a member of the first (vispec_ctx_create_member)");
+  if (a->c.total_token != b->c.total_token || a->c.total_token > 32) return fail("cohort: both requests need the same tree size <= 32");
+  return 0;
+}
+static vispec_ctx::GraphKey cohort_key(const vispec_ctx* a, const vispec_ctx* b, int forced_accept, bool sampling_args) {
+  vispec_ctx::GraphKey k = graph_key(a, forced_accept, sampling_args);
+  const vispec_ctx::GraphKey kb = graph_key(b, forced_accept, sampling_args);
+  k.n_hint2 = kb.n_hint; k.temperature2 = kb.temperature; k.seed2 = kb.seed; k.sample_top_k2 = kb.sample_top_k;
+  return k;
+}
+extern "C" int vispec_cohort_verify_accept(vispec_ctx* a, vispec_ctx* b, void* stream, int forced_accept) {
+  if (cohort_check(a, b)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const Cohort co{2, {a, b}};
+  return run_graphed(a, s, a->g_cverify, cohort_key(a, b, forced_accept, true), [&]() {
+    if (target_forward(co, s, a->c.total_token)) return -1;
+    return target_accept(co, s, a->c.total_token, forced_accept);
+  });
+}
+extern "C" int vispec_cohort_draft_round(vispec_ctx* a, vispec_ctx* b, void* stream) {
+  if (cohort_check(a, b)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const Cohort co{2, {a, b}};
+  return run_graphed(a, s, a->g_cdraft, cohort_key(a, b, 0, false), [&]() { return draft_round_body(co, s); });
 }
 __global__ void set_tree_meta_kernel(DevState* st, int n_leaf, int max_depth, int T) {
   if (threadIdx.x == 0) { st->n_leaf = n_leaf; st->max_depth = max_depth; st->tree_T = T; }
@@ -1189,8 +1323,9 @@ extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
   return run_graphed(ctx, s, ctx->g_ar, graph_key(ctx, -1, false), [&]() {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
     KCHK();
-    if (target_forward(ctx, s, 1)) return -1;
-    return target_accept(ctx, s, 1, -1);
+    const Cohort co{1, {ctx, nullptr}};
+    if (target_forward(co, s, 1)) return -1;
+    return target_accept(co, s, 1, -1);
   });
 }
 
@@ -1250,7 +1385,7 @@ extern "C" void* vispec_buffer(vispec_ctx* ctx, const char* name) {
                    {"draft_xc", ctx->xc}, {"tree_tokens", ctx->tb.tree_tokens}, {"tree_pos", ctx->tb.tree_pos},
                    {"tree_mask", ctx->tb.tree_mask}, {"retrieve", ctx->tb.retrieve}, {"scores_all", ctx->tb.scores_all},
                    {"tokens_all", ctx->tb.tokens_all}, {"parents_all", ctx->tb.parents_all}, {"accept_log", ctx->accept_log},
-                   {"lvl_mask", ctx->tb.lvl_mask}, {"in_ids", ctx->tb.in_ids}, {"in_h", ctx->in_h}};
+                   {"lvl_mask", ctx->tb.lvl_mask}, {"in_ids", ctx->tb.in_ids}};
   for (const E& e : tab)
     if (!strcmp(e.n, name)) return e.p;
   return nullptr;

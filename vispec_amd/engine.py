@@ -220,7 +220,9 @@ class Engine:
 
     def __init__(self, tcfg: TargetConfig, dcfg: DraftConfig, tw: TargetWeights, dw: DraftWeightsDev, total_token=30, depth=3,
                  top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None,
-                 target_weight_dtype: str = "bf16"):
+                 target_weight_dtype: str = "bf16", leader: Optional["Engine"] = None):
+        """leader: build this engine as a COHORT MEMBER of `leader` (same configs and weights): its activation workspaces alias the
+        leader's second 32-row tiles, so `leader.cohort_round(self)` runs both requests' rounds on one weight pass."""
         if eager_scores is None:
             eager_scores = tcfg.attn_impl == "eager"
         if not torch.cuda.is_available():
@@ -240,9 +242,13 @@ class Engine:
             total_token=total_token, depth=depth, top_k=top_k, num_q=num_q, eos_token_id=tcfg.eos_token_id,
             eager_scores=int(eager_scores), draft_rope_rows=max(self.kv_max_pos, self.draft_max_pos),
         )
+        self.leader = leader
         with torch.cuda.device(self.device):
             h = C.c_void_p()
-            L.check(self.lib.vispec_ctx_create(C.byref(cfg), C.byref(h)))
+            if leader is None:
+                L.check(self.lib.vispec_ctx_create(C.byref(cfg), C.byref(h)))
+            else:
+                L.check(self.lib.vispec_ctx_create_member(C.byref(cfg), leader.h, C.byref(h)))
         self.h = h
         self.t_cos, self.t_sin = rope_tables(tcfg.head_dim, self.kv_max_pos, tcfg.rope_theta, self.device)
         # the draft rotates its rows at their UNCOMPRESSED positions (cnets_ours.py:845-868), which run up to the target's context
@@ -369,6 +375,12 @@ class Engine:
 
     def draft_round(self):
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
+
+    def cohort_round(self, member: "Engine", forced_accept: int = -1):
+        """One draft-and-verify round of TWO requests (this engine's and `member`'s, created with leader=self) on one weight pass."""
+        st = self._stream()
+        L.check(self.lib.vispec_cohort_verify_accept(self.h, member.h, st, int(forced_accept)))
+        L.check(self.lib.vispec_cohort_draft_round(self.h, member.h, st))
 
     def set_total_token(self, total_token: int):
         L.check(self.lib.vispec_set_total_token(self.h, int(total_token)))

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vispec_last_error": (C.c_char_p, []),
     "vispec_version": (c_int, []),
     "vispec_ctx_create": (c_int, [C.POINTER(VispecConfig), C.POINTER(P)]),
+    "vispec_ctx_create_member": (c_int, [C.POINTER(VispecConfig), P, C.POINTER(P)]),
     "vispec_ctx_destroy": (None, [P]),
     "vispec_set_target_layer": (c_int, [P, c_int, C.POINTER(LayerWeights)]),
     "vispec_set_target_misc": (c_int, [P, C.POINTER(TargetMisc)]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "vispec_set_tree_host": (c_int, [P, P, P, P, P, P, c_int, c_int]),
     "vispec_set_retrieve_host": (c_int, [P, P, P, c_int, c_int]),
     "vispec_draft_round": (c_int, [P, P]),
+    "vispec_cohort_verify_accept": (c_int, [P, P, P, c_int]),
+    "vispec_cohort_draft_round": (c_int, [P, P, P]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),
     "vispec_sample_row": (c_int, [P, P, P, c_int, P]),

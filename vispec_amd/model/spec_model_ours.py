@@ -26,7 +26,10 @@ from .utils import initialize_tree, reset_tree_mode
 
 class SpecModel:
     def __init__(self, base_model: TargetLM, spec_layer: Model, tokenizer=None, total_token=30, depth=3, top_k=8, num_q=2,
-                 kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, target_weight_dtype: str = "bf16"):
+                 kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, target_weight_dtype: str = "bf16",
+                 cohort_leader: Optional["SpecModel"] = None):
+        """cohort_leader: build this model as the second member of a two-request cohort (same weights objects as the leader): see
+        specgenerate_cohort()."""
         self.base_model = base_model
         self.config = base_model.config
         self.hidden_size = base_model.cfg.hidden_size
@@ -35,7 +38,7 @@ class SpecModel:
         self.spec_layer = spec_layer
         self.engine = Engine(base_model.cfg, spec_layer.config, base_model.w, spec_layer.w, total_token=total_token, depth=depth,
                              top_k=top_k, num_q=num_q, kv_max_pos=kv_max_pos, draft_max_pos=draft_max_pos,
-                             target_weight_dtype=target_weight_dtype)
+                             target_weight_dtype=target_weight_dtype, leader=None if cohort_leader is None else cohort_leader.engine)
         base_model.engine = self.engine
         spec_layer.engine = self.engine
         spec_layer.init_tree()
@@ -44,6 +47,15 @@ class SpecModel:
 
     def eval(self):
         return self
+
+    def make_cohort_member(self) -> "SpecModel":
+        """A second model over the SAME weight tensors (nothing is copied or re-packed) whose engine is a cohort member of this one's:
+        own KV caches, tree and round state; specgenerate_cohort([self, member], [req_a, req_b]) then runs two requests per weight pass."""
+        e = self.engine
+        base = TargetLM(self.base_model.cfg, self.base_model.w, vision=self.base_model.vision)
+        draft = Model(self.spec_layer.config, self.spec_layer.w, total_tokens=e.total_token, depth=e.depth, top_k=e.top_k, num_q=e.num_q)
+        return SpecModel(base, draft, tokenizer=self.tokenizer, total_token=e.total_token, depth=e.depth, top_k=e.top_k, num_q=e.num_q,
+                         kv_max_pos=e.kv_max_pos, draft_max_pos=e.draft_max_pos, target_weight_dtype=e.target_weight_dtype, cohort_leader=self)
 
     def get_tokenizer(self):
         return self.tokenizer
@@ -411,3 +423,52 @@ class SpecModel:
         elif len(gen) > max_new_tokens + 1:
             toks = toks[: input_ids.shape[1] + max_new_tokens + 1]
         return torch.from_numpy(toks).to(dev)[None]
+
+
+@torch.no_grad()
+def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
+                        forced_accept=None):
+    """Two independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
+
+    models   = [leader, member]  (member built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
+    requests = [(input_ids [1,L], specgenerate kwargs), (input_ids, kwargs)]
+    Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — exactly what
+    `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` returns for that request alone, token for token: the prefills run
+    per request, every decode round launches each GEMM once on both requests' rows (Engine.cohort_round), and a request that finishes
+    first is frozen on the device while the other completes."""
+    if len(models) != 2 or len(requests) != 2:
+        raise ValueError("a cohort is two models (leader, member) and two requests")
+    lead, memb = models
+    if memb.engine.leader is not lead.engine:
+        raise ValueError("models[1] must have been built with cohort_leader=models[0]")
+    seeds = seeds or [0, 0]
+    for m, (ids, kw), sd in zip(models, requests, seeds):
+        m._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=sd, max_new_tokens=max_new_tokens, is_llama3=is_llama3)
+    rounds_cap = max_length - lead.spec_layer.total_tokens - 10  # :270
+    alive = [True, True]
+    final = [m.engine.state() for m in models]
+    idxs, accs = [0, 0], [[], []]
+    for idx in range(rounds_cap):
+        fa = -1 if forced_accept is None else int(forced_accept(idx))
+        lead.engine.cohort_round(memb.engine, fa)
+        for t, m in enumerate(models):
+            if not alive[t]:
+                continue
+            st = m.engine.state()
+            final[t], idxs[t] = st, idx
+            accs[t].append(int(st["accept_len"]))
+            if (st["done"] & 1) or st["new_token"] > max_new_tokens or (st["done"] & 4):  # :544 / :546 / KV full
+                if st["done"] & 4 and not (st["done"] & 3):
+                    import warnings
+                    warnings.warn(f"cohort request {t} stopped after {st['new_token']} new tokens: the next round would not fit a KV cache",
+                                  RuntimeWarning)
+                alive[t] = False
+        if not any(alive):
+            break
+    outs = []
+    for t, m in enumerate(models):
+        n_ctx = final[t]["n_ctx"]
+        m.current_length_data.fill_(n_ctx)
+        toks = torch.from_numpy(m.engine.tokens(n_ctx).astype(np.int64)).to(m.engine.device)[None]
+        outs.append((toks, final[t]["new_token"], idxs[t], accs[t]))
+    return outs
