@@ -897,12 +897,237 @@ __global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
   }
 }
 
+// ---- round-2 form of the partial kernel -----------------------------------------------------------------------------------------
+// Same contract (one partial (m, l, O^T) per (q-tile, key split)), different work distribution:
+//   * a workgroup stages 128-key chunks; each of the 4 waves owns ONE 32-key tile of the chunk completely — QK^T, softmax and P·V
+//     over all 128 head_dim columns — so nothing is computed twice (the first form ran QK^T + softmax in both head_dim-half waves);
+//   * the V^T operand of P·V comes from the hardware transposing read (ds_read_b64_tr_b16: 16 per 32-key tile instead of 64
+//     ds_read_u16 + packing); V rows keep their natural order in LDS, 64-byte blocks XOR-ed with (row & 3) -> conflict-free;
+//   * up to two requests per launch (blockIdx.z / NQT): a cohort's two attention calls run side by side.
+// LDS: K 32 KB + V 32 KB, single-buffered (the next chunk waits in registers while the current one is on the matrix cores); two
+// workgroups per CU.  The four waves' (m, l, O) are merged through the same 64 KB at the end.
+#define ATT2_CHUNK 128
+#define ATT2_LDS_BYTES (2 * ATT2_CHUNK * 256 + 1024)
+struct AttnReq {
+  const bf16_t* Q;
+  const bf16_t* Kc;
+  const bf16_t* Vc;
+  const int* prefix_dev;
+  const unsigned long long* mask;
+  float* part_o;
+  float* part_ml;
+  bf16_t* out;  // (reduce kernel)
+};
+struct AttnArgs { AttnReq r[2]; };
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int att_vswz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 3) << 6)); }
+
+template <bool EAGER>
+__global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs args, int ldq, int s_max, int H, int H_kv, int M, int tail,
+                                                                    int keys_per_wg, int nsplit, int NQT) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + ATT2_CHUNK * 256;
+  const int split = blockIdx.x, kvh = blockIdx.y;
+  const int rq = blockIdx.z / NQT, qt = blockIdx.z - rq * NQT;
+  const AttnReq R = rq ? args.r[1] : args.r[0];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, hi = lane >> 5;
+  const int n_prefix = R.prefix_dev ? *R.prefix_dev : 0;
+  const int n_total = n_prefix + tail;
+  const int key0 = split * keys_per_wg;
+  if (key0 >= n_total) return;
+  const int key_end = min(key0 + keys_per_wg, n_total);
+  const int G = H / H_kv, MT = (M + 31) >> 5;
+  const bf16_t* Kh = R.Kc + (size_t)kvh * s_max * 128;
+  const bf16_t* Vh = R.Vc + (size_t)kvh * s_max * 128;
+  const int nchunk = (key_end - key0 + ATT2_CHUNK - 1) / ATT2_CHUNK;
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float sqrt_hd = 11.313708498984761f;
+  const float rsqrt_hd = 1.0f / sqrt_hd;
+  const int last_key = n_total - 1;  // rows past the end are clamped to the last valid key (never visible): unconditional loads
+  const int head = kvh * G + qt / MT, m0 = (qt % MT) * 32;
+  const int mrow = m0 + j;
+  const bool qvalid = mrow < M;
+  uint4 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    qf[ks] = *reinterpret_cast<const uint4*>(R.Q + (size_t)(qvalid ? mrow : 0) * ldq + head * 128 + ks * 16 + hi * 8);
+  const unsigned long long mbits = (qvalid && R.mask) ? R.mask[mrow] : 0ull;
+  float m_run = NEG_INF, l_run = 0.f;
+  f32x16 O[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  // staging map: thread -> 8 x 16 B of K and of V per chunk (row = (tid >> 4) + 16 p, 16-B column = tid & 15)
+  const int srow = threadIdx.x >> 4, sc16 = threadIdx.x & 15;
+  // staging registers as named scalars + macros: arrays that are written under a condition in the loop end up in scratch memory
+  uint4 k0r, k1r, k2r, k3r, k4r, k5r, k6r, k7r, v0r, v1r, v2r, v3r, v4r, v5r, v6r, v7r;
+#define ATT2_G1(kk, vv, p, ch)                                                              \
+  {                                                                                         \
+    const int key_ = min(key0 + (ch) * ATT2_CHUNK + srow + 16 * (p), last_key);             \
+    kk = *reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8);               \
+    vv = *reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8);               \
+  }
+#define ATT2_GLOAD(ch)                                                                      \
+  ATT2_G1(k0r, v0r, 0, ch) ATT2_G1(k1r, v1r, 1, ch) ATT2_G1(k2r, v2r, 2, ch) ATT2_G1(k3r, v3r, 3, ch) \
+  ATT2_G1(k4r, v4r, 4, ch) ATT2_G1(k5r, v5r, 5, ch) ATT2_G1(k6r, v6r, 6, ch) ATT2_G1(k7r, v7r, 7, ch)
+#define ATT2_W1(kk, vv, p)                                                                  \
+  *reinterpret_cast<uint4*>(sK + att_swz(srow + 16 * (p), sc16 * 16)) = kk;                 \
+  *reinterpret_cast<uint4*>(sV + att_vswz(srow + 16 * (p), sc16 * 16)) = vv;
+#define ATT2_LWRITE()                                                                       \
+  ATT2_W1(k0r, v0r, 0) ATT2_W1(k1r, v1r, 1) ATT2_W1(k2r, v2r, 2) ATT2_W1(k3r, v3r, 3)       \
+  ATT2_W1(k4r, v4r, 4) ATT2_W1(k5r, v5r, 5) ATT2_W1(k6r, v6r, 6) ATT2_W1(k7r, v7r, 7)
+  ATT2_GLOAD(0)
+  ATT2_LWRITE()
+  __syncthreads();
+  // per-lane constants of the transposing V reads: 16-lane group g reads the [4 keys][16 cols] block of keys +0..3, columns
+  // 32 dt + 16 (g & 1) ..+15 ; lane i of the group supplies row (i >> 2), columns 4 (i & 3) .. +3
+  const int li = lane & 15, lg = lane >> 4;
+  const int vrow_l = wave * 32 + 4 * hi + (li >> 2);
+  const int vcol_l = (16 * (lg & 1) + 4 * (li & 3)) * 2;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch + 1 < nchunk) { ATT2_GLOAD(ch + 1) }  // in flight during the MFMA work below
+    const int kbase = key0 + ch * ATT2_CHUNK + wave * 32;
+    if (kbase < key_end) {
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      const int krow = wave * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
+      }
+      float mx = NEG_INF;
+      // eager scores: bf16(bf16(S) / sqrt(hd)) through one FMA-corrected reciprocal multiply (bit-identical to the division for
+      // every bf16 input, tools/div_check.hip)
+      if (kbase + 32 <= n_prefix) {  // wave-uniform: the whole tile lies in the committed context, every key visible
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sc;
+          if (EAGER) {
+            const float xb = rdbf(S[r]);
+            float q = xb * rsqrt_hd;
+            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+            sc = rdbf(q);
+          } else {
+            sc = S[r] * scale;
+          }
+          S[r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          float sc;
+          if (EAGER) {
+            const float xb = rdbf(S[r]);
+            float q = xb * rsqrt_hd;
+            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+            sc = rdbf(q);
+          } else {
+            sc = S[r] * scale;
+          }
+          bool vis = key < n_prefix;
+          if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
+          sc = vis ? sc : NEG_INF;
+          S[r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
+      float psum = 0.f;
+      unsigned pb[8];
+      const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;  // a row with nothing visible yet: exp(-inf - 0) = 0, never inf - inf
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(S[r] - m_sub);
+        const float p1 = __expf(S[r + 1] - m_sub);
+        psum += p0 + p1;
+        pb[r >> 1] = pack2(p0, p1);
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (__any(alpha != 1.0f)) {  // the running maximum settles after the first tiles: most tiles rescale nothing
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+      }
+      // O^T[d][q] += V^T[d][key] P^T[key][q]: k-slot (hi, t) of 16-key step kk is key 16 kk + 8 (t >> 2) + 4 hi + (t & 3) for BOTH
+      // operands — P already sits that way in the accumulator layout, V^T is fetched to match by two transposing reads
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4 pB = make_uint4(pb[kk * 4 + 0], pb[kk * 4 + 1], pb[kk * 4 + 2], pb[kk * 4 + 3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int r0 = vrow_l + 16 * kk;
+          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(sV + att_vswz(r0, 64 * dt + vcol_l)));
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(sV + att_vswz(r0 + 8, 64 * dt + vcol_l)));
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          const s16x8_t va = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+          O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&va), as_bf16x8(pB), O[dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with this chunk's LDS image
+    if (ch + 1 < nchunk) {
+      ATT2_LWRITE()
+      __syncthreads();
+    }
+  }
+#undef ATT2_GLOAD
+#undef ATT2_LWRITE
+#undef ATT2_G1
+#undef ATT2_W1
+  // ---- merge the four key-tile waves through LDS (the K/V image is dead: the loop ended with a barrier) ----
+  float* sM = reinterpret_cast<float*>(smem + 2 * ATT2_CHUNK * 256);  // [4][32] m, then [4][32] l
+  float* sO = reinterpret_cast<float*>(smem);                          // [4 waves][128 hd][32 q] fp32
+  if (hi == 0) sM[wave * 32 + j] = m_run;
+  __syncthreads();
+  const float m_all = fmaxf(fmaxf(sM[j], sM[32 + j]), fmaxf(sM[64 + j], sM[96 + j]));
+  const float f = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_all);
+  if (hi == 0) sM[128 + wave * 32 + j] = l_run * f;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int drow = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      sO[wave * 4096 + drow * 32 + j] = O[dt][r] * f;
+    }
+  __syncthreads();
+  const size_t pidx = ((size_t)(kvh * NQT + qt) * nsplit + split);
+  float4* po = reinterpret_cast<float4*>(R.part_o + pidx * (128 * 32));
+  const float4* s4 = reinterpret_cast<const float4*>(sO);
+#pragma unroll
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const float4 a = s4[e], b = s4[1024 + e], c = s4[2048 + e], d = s4[3072 + e];
+    po[e] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  }
+  if (threadIdx.x < 32) {
+    const int q = threadIdx.x;
+    R.part_ml[pidx * 64 + q] = fmaxf(fmaxf(sM[q], sM[32 + q]), fmaxf(sM[64 + q], sM[96 + q]));
+    R.part_ml[pidx * 64 + 32 + q] = (sM[128 + q] + sM[160 + q]) + (sM[192 + q] + sM[224 + q]);
+  }
+}
+
 // merge partials over splits: grid (H*MT), 256 threads
-__global__ __launch_bounds__(256) void tree_attn_reduce_kernel(const float* __restrict__ part_o,
-                                                               const float* __restrict__ part_ml, int H, int H_kv, int M,
-                                                               const int* __restrict__ prefix_dev, int tail,
-                                                               int keys_per_wg, int nsplit, bf16_t* __restrict__ out,
-                                                               int ldo) {
+__global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, int H, int H_kv, int M, int tail,
+                                                               int keys_per_wg, int nsplit, int ldo) {
+  // blockIdx.z = request of a cohort (0 otherwise)
+  const AttnReq R = blockIdx.z ? args.r[1] : args.r[0];
+  const float* __restrict__ part_o = R.part_o;
+  const float* __restrict__ part_ml = R.part_ml;
+  const int* __restrict__ prefix_dev = R.prefix_dev;
+  bf16_t* __restrict__ out = R.out;
   // Latency-bound (a few hundred KB per launch): every load of a phase is issued before the first use, with clamped
   // (always valid) addresses instead of guards, so the dependent chain is prefix -> {m,l and the first 16 partial tiles} -> out.
   __shared__ float wgt[64][32];

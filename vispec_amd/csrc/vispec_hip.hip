@@ -194,10 +194,10 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
 #undef A
 #undef AL
   ctx->n_hint = c.max_pos;
-  const int lds = ATT_LDS_BYTES;
-  if (hipFuncSetAttribute((const void*)tree_attn_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+  const int lds = ATT2_LDS_BYTES;
+  if (hipFuncSetAttribute((const void*)tree_attn2_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
           hipSuccess ||
-      hipFuncSetAttribute((const void*)tree_attn_partial_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+      hipFuncSetAttribute((const void*)tree_attn2_partial_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
           hipSuccess) {
     (void)hipGetLastError();  // a device-less build/load check must still be able to create nothing; report lazily
   }
@@ -521,35 +521,51 @@ static int launch_qkv_rope1(vispec_ctx* ctx, hipStream_t s, const void* X, int l
 // prefix = (prefix_dev ? *prefix_dev : 0) + prefix_add is folded by a tiny helper kernel into a scratch int when needed
 __global__ void add_scalar_kernel(const int* src, int add, int* dst) { *dst = (src ? *src : 0) + add; }
 
-static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int ldq, const void* kc, const void* vc, int s_max,
-                            int H, int H_kv, int M, const int* prefix_dev, int tail, const unsigned long long* mask, void* out,
-                            int ldo, int eager, int max_keys) {
+struct AttnCall {  // per-request part of an attention call
+  vispec_ctx* ctx;  // owner of the partial workspace
+  const void* q;
+  const void* kc;
+  const void* vc;
+  const int* prefix_dev;
+  const unsigned long long* mask;
+  void* out;
+};
+// n = 1, or 2 for a cohort: both requests' attention runs in ONE partial launch and ONE reduce launch (blockIdx.z)
+static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int ldq, int s_max, int H, int H_kv, int M, int tail, int ldo,
+                              int eager, int max_keys) {
   if (M < 1 || M > 64) return fail("tree_attention: M must be in [1,64]");
   if (tail < 0 || tail > 64) return fail("tree_attention: tail must be in [0,64]");
   const int MT = (M + 31) / 32, NQT = (H / H_kv) * MT;
   static const int kpw_env = getenv("VISPEC_ATT_KPW") ? atoi(getenv("VISPEC_ATT_KPW")) : 0;  // tuning experiments only
-  int kpw = (kpw_env >= 64 && kpw_env % 64 == 0) ? kpw_env : 256;
+  int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : 256;
   if (max_keys < 1) max_keys = 1;
   while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
-  if ((size_t)H_kv * NQT * nsplit > ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
-  const int lds = ATT_LDS_BYTES;
-  dim3 grid(nsplit, H_kv, NQT), block(256);
+  AttnArgs args{};
+  for (int t = 0; t < n; ++t) {
+    if ((size_t)H_kv * NQT * nsplit > calls[t].ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
+    AttnReq& r = args.r[t];
+    r.Q = (const bf16_t*)calls[t].q; r.Kc = (const bf16_t*)calls[t].kc; r.Vc = (const bf16_t*)calls[t].vc;
+    r.prefix_dev = calls[t].prefix_dev; r.mask = calls[t].mask; r.part_o = calls[t].ctx->part_o; r.part_ml = calls[t].ctx->part_ml;
+    r.out = (bf16_t*)calls[t].out;
+  }
+  dim3 grid(nsplit, H_kv, NQT * n), block(256);
   prof_begin(s, eager ? PROF_ATT_PARTIAL : PROF_ATT_PARTIAL_DRAFT, 0.0);
-  if (eager)
-    PLAUNCH(tree_attn_partial_kernel<true>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
-                       (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
-  else
-    PLAUNCH(tree_attn_partial_kernel<false>, grid, block, lds, s, (const bf16_t*)q, ldq, (const bf16_t*)kc,
-                       (const bf16_t*)vc, s_max, H, H_kv, M, prefix_dev, tail, mask, ctx->part_o, ctx->part_ml, kpw, nsplit);
+  if (eager) PLAUNCH(tree_attn2_partial_kernel<true>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT);
+  else PLAUNCH(tree_attn2_partial_kernel<false>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT);
   KCHK();
   prof_end(s);
   prof_begin(s, eager ? PROF_ATT_REDUCE : PROF_ATT_REDUCE_DRAFT, 0.0);
-  PLAUNCH(tree_attn_reduce_kernel, dim3(H * MT, 4), dim3(256), 0, s, ctx->part_o, ctx->part_ml, H, H_kv, M, prefix_dev,
-                     tail, kpw, nsplit, (bf16_t*)out, ldo);
+  PLAUNCH(tree_attn_reduce_kernel, dim3(H * MT, 4, n), dim3(256), 0, s, args, H, H_kv, M, tail, kpw, nsplit, ldo);
   KCHK();
   prof_end(s);
   return 0;
+}
+static int launch_attention(vispec_ctx* ctx, hipStream_t s, const void* q, int ldq, const void* kc, const void* vc, int s_max,
+                            int H, int H_kv, int M, const int* prefix_dev, int tail, const unsigned long long* mask, void* out,
+                            int ldo, int eager, int max_keys) {
+  const AttnCall call{ctx, q, kc, vc, prefix_dev, mask, out};
+  return launch_attention_n(s, &call, 1, ldq, s_max, H, H_kv, M, tail, ldo, eager, max_keys);
 }
 
 static int launch_gather(hipStream_t s, const void* table, int ld_t, const int* idx, int idx_off, const int* idx_base_dev,
@@ -899,12 +915,16 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
   if (launch_qkv_rope(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D, ctx->dw.rope_cos, ctx->dw.rope_sin, rq,
                       co.n, c.draft_max_pos))
     return -1;
-  for (int t = 0; t < co.n; ++t) {
-    vispec_ctx* x = co.c[t];
+  {
+    AttnCall calls[2];
+    int max_keys = 1;
+    for (int t = 0; t < co.n; ++t) {
+      vispec_ctx* x = co.c[t];
+      calls[t] = AttnCall{x, x->dqkv, rq[t].kc, rq[t].vc, &x->st->draft_len, level < 0 ? x->causal_mask : x->tb.lvl_mask, x->dattn};
+      max_keys = std::max(max_keys, x->n_hint < c.draft_max_pos ? x->n_hint : c.draft_max_pos);
+    }
     const int tail = level < 0 ? rows : k * (level + 1);
-    if (launch_attention(x, s, x->dqkv, 3 * D, rq[t].kc, rq[t].vc, c.draft_max_pos, Hd, Hd, rows, &x->st->draft_len, tail,
-                         level < 0 ? x->causal_mask : x->tb.lvl_mask, x->dattn, D, 0, x->n_hint < c.draft_max_pos ? x->n_hint : c.draft_max_pos))
-      return -1;
+    if (launch_attention_n(s, calls, co.n, 3 * D, c.draft_max_pos, Hd, Hd, rows, tail, D, 0, max_keys)) return -1;
   }
   return draft_layer_tail(co, s, rows, ctx->dx, ctx->dout);
 }
@@ -1119,11 +1139,15 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
     }
     if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
       return -1;
-    for (int t = 0; t < co.n; ++t) {
-      vispec_ctx* x = co.c[t];
-      if (launch_attention(x, s, x->qkv, QKV, rq[t].kc, rq[t].vc, c.max_pos, H, Hk, T, &x->st->n_ctx, T, x->tb.tree_mask, x->attn_o, H * 128,
-                           c.eager_scores, x->n_hint))
-        return -1;
+    {
+      AttnCall calls[2];
+      int max_keys = 1;
+      for (int t = 0; t < co.n; ++t) {
+        vispec_ctx* x = co.c[t];
+        calls[t] = AttnCall{x, x->qkv, rq[t].kc, rq[t].vc, &x->st->n_ctx, x->tb.tree_mask, x->attn_o};
+        max_keys = std::max(max_keys, x->n_hint);
+      }
+      if (launch_attention_n(s, calls, co.n, QKV, c.max_pos, H, Hk, T, T, H * 128, c.eager_scores, max_keys)) return -1;
     }
     {
       GemmOut o;  // x += o_proj(attn) ; xn = post_attention_layernorm(x)   — one split-K GEMM + one reduce
