@@ -129,6 +129,46 @@ def test_draft_prefill_stage(num_q, n_pre, n_img, n_post):
     assert tok[0] == ids[L]
 
 
+def test_draft_prefill_stage_on_the_prefill_gemm():
+    """Stages of >= 64 rows run on the prefill GEMM (csrc/gemm_prefill.h: 128 x 128 tiles, operand rows gathered / concatenated while
+    staged, K|V scatter and rotary+append epilogues) instead of 32-row passes of the skinny kernel.  A draft wide enough for the
+    one-launch q|k|v form (3D = 4608 rows) with a prompt whose text segments, image run and compressed length all exceed 64 rows,
+    against the oracle: compressed K/V (rotary at the ORIGINAL positions), g, last hidden row, first tree."""
+    D, H, I, V, NL, P = 1536, 12, 1024, 1008, 1, 512
+    tw = synth.make_target_weights(D, H, I, V, NL, seed=120)
+    dw = synth.make_draft_weights(D, H, I, V, num_q=3, seed=121)
+    tcfg = TargetConfig(hidden_size=D, num_heads=H, num_kv_heads=H, intermediate_size=I, vocab_size=V, num_layers=NL,
+                        max_position_embeddings=P, architectures=("LlavaNextForConditionalGeneration",), image_token_index=IMG_TOK)
+    dcfg = DraftConfig(hidden_size=D, num_heads=H, intermediate_size=I, vocab_size=V, max_position_embeddings=P)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, num_q=3)
+    ot = vo.TargetLlama(vo.TargetConfig(D, H, H, I, V, NL, P), tw, bf16=True)
+    od = vo.DraftModel(vo.DraftConfig(D, H, I, V, P, num_q=3), dw, bf16=True)
+    eng = sm.engine
+    assert eng.lib.vispec_qkv_rope_fused(3 * D)
+    rng = np.random.default_rng(122)
+    n_pre, n_img, n_post = 70, 150, 81
+    L = n_pre + n_img + n_post
+    hidden = synth.bf16_grid(rng.standard_normal((L, D), dtype=np.float32))
+    embeds = synth.bf16_grid(rng.standard_normal((L, D), dtype=np.float32) * 0.05)
+    mask = np.zeros(L, bool)
+    mask[n_pre: n_pre + n_img] = True
+    ids = rng.integers(3, IMG_TOK, size=L + 1)
+    eng.begin_request(ids[:L], 64)
+    first = torch.tensor([ids[L]], dtype=torch.int32, device="cuda")
+    eng.draft_prefill(torch.from_numpy(hidden).to(torch.bfloat16).cuda(), torch.from_numpy(embeds).to(torch.bfloat16).cuda(), mask, first)
+    tok, pos, tmask, ret = check_tree_exact(eng)
+    od.reset_kv()
+    od.topK_genrate(hidden, ids, ot.lm_head, inputs_embeds=embeds, image_mask=mask)
+    Lc = od.stable_kv[0].shape[1]
+    assert Lc == L - n_img + 2 and eng.state()["draft_len"] == Lc
+    kv = eng.draft_kv.float().cpu().numpy()
+    tol = lambda a, b: np.testing.assert_allclose(a, b, rtol=2.0 ** -6, atol=2.0 ** -6 * np.abs(b).max())
+    tol(kv[0][:, :Lc], od.stable_kv[0])
+    tol(kv[1][:, :Lc], od.stable_kv[1])
+    tol(eng.buffer("draft_g", (1, D)).float().cpu().numpy(), od.last_img_hidden)
+    assert tok[0] == ids[L]
+
+
 def test_round_stages_against_oracle():
     """One verify + accept + draft round on the random (unstructured) pair, stage by stage."""
     sm, ot, od = build(21, 13, False)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "gemm_prefill.h"
 #include "tree_kernels.h"
 
 static thread_local std::string g_err;
@@ -47,7 +48,7 @@ struct vispec_ctx {
   bf16_t* accept_hidden;  // [16, D]
   // draft buffers
   bf16_t *dx1, *dx2, *dx, *dqkv, *dattn, *dh, *dn, *dact, *dout, *dlast, *dlogits, *dg;
-  bf16_t *xc, *emb_shift, *ad_kv, *ad_out, *ad_tmp;  // prefill-only scratch
+  bf16_t *xc, *emb_shift, *ad_kv, *ad_out, *ad_tmp, *pf_t1;  // prefill-only scratch
   int *top_idx, *pos_c, *idx_tmp, *idx_img, *scratch_int;
   int* h_pin = nullptr;  // pinned host staging for the prefill's index lists [3 * draft_max_pos]
   float* top_logp;
@@ -151,7 +152,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   const int scr = c.max_pos > c.draft_max_pos ? c.max_pos : c.draft_max_pos;
   ctx->scr_rows = scr;
   ctx->rope_rows = c.draft_rope_rows > 0 ? c.draft_rope_rows : c.draft_max_pos;
-  A(xc, (size_t)scr * D); A(emb_shift, (size_t)scr * D);
+  A(xc, (size_t)scr * D); A(emb_shift, (size_t)scr * D); A(pf_t1, (size_t)scr * D);
   A(ad_kv, (size_t)2 * scr * D); A(ad_out, 16 * D); A(ad_tmp, ROWS * 2 * D);
   A(top_idx, TREE_MAX_K * TREE_MAX_K); A(top_logp, TREE_MAX_K * TREE_MAX_K); A(pos_c, scr);
   A(idx_tmp, scr); A(idx_img, scr); A(scratch_int, 4);
@@ -604,6 +605,21 @@ static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int
   return 0;
 }
 
+// Prefill-side GEMM (csrc/gemm_prefill.h): M rows against `n_tiles` 32-row blocks of a W32-packed weight starting at block n_tile0.
+enum { PROF_GEMM_PREFILL = 7 };
+static int launch_gemm_big(hipStream_t s, int epi, const BigA& a, int M, const void* P, int K, int n_tile0, int n_tiles, const BigEpi& e) {
+  if (M < 1 || K % 64 || a.k_split % 64 || n_tiles < 1) return fail("gemm_prefill: K, k_split %% 64 == 0 and M, n_tiles >= 1 required");
+  dim3 grid((n_tiles + 3) / 4, (M + 127) / 128), block(256);
+  prof_begin(s, PROF_GEMM_PREFILL, 2.0 * M * (double)n_tiles * 32 * K);  // (flops, not bytes: this kernel is MFMA-bound)
+  if (epi == BIG_PLAIN) PLAUNCH(gemm_w32_big_kernel<BIG_PLAIN>, grid, block, BIG_LDS_BYTES, s, a, M, (const bf16_t*)P, K, n_tile0, n_tiles, e);
+  else if (epi == BIG_KV) PLAUNCH(gemm_w32_big_kernel<BIG_KV>, grid, block, BIG_LDS_BYTES, s, a, M, (const bf16_t*)P, K, n_tile0, n_tiles, e);
+  else PLAUNCH(gemm_w32_big_kernel<BIG_ROPE_KV>, grid, block, BIG_LDS_BYTES, s, a, M, (const bf16_t*)P, K, n_tile0, n_tiles, e);
+  KCHK();
+  prof_end(s);
+  return 0;
+}
+#define PREFILL_BIG_MIN_ROWS 64  // below this many rows a stage stays on the skinny kernel (one or two 32-row passes)
+
 // ------------------------------------------------------------------------------------------------ unit-level C-ABI
 extern "C" int vispec_pack_weight(vispec_ctx*, void* stream, const void* W, int N, int K, void* P) {
   return launch_pack((hipStream_t)stream, W, N, K, P);
@@ -1051,6 +1067,23 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   const int ad_cap = ctx->scr_rows;  // row capacity of the adaptor's scratch K/V (one image run can be as long as the prompt)
   bf16_t* avc = ctx->ad_kv + (size_t)Hd * ad_cap * 128;
   for (const Op& op : plan) {
+    if (!op.is_adapt && op.n >= PREFILL_BIG_MIN_ROWS) {
+      // fc(cat(emb, img_fc(cat(h, g)))) over the segment's rows in two prefill GEMMs: the row gathers (hidden / shifted embeddings by
+      // source row) and both concatenations happen while the operands are staged
+      BigA a1;
+      a1.src0 = (const bf16_t*)hidden; a1.idx0 = ctx->idx_tmp + op.c_row; a1.ld0 = D;
+      a1.src1 = ctx->dg; a1.bcast1 = 1; a1.ld1 = D; a1.k_split = D;
+      BigEpi e1;
+      e1.bias = (const bf16_t*)ctx->dw.imgfc_b; e1.Y = ctx->pf_t1; e1.ldy = D;
+      if (launch_gemm_big(s, BIG_PLAIN, a1, op.n, ctx->dw.imgfc_w, 2 * D, 0, D / 32, e1)) return -1;
+      BigA a2;
+      a2.src0 = ctx->emb_shift; a2.idx0 = ctx->idx_tmp + op.c_row; a2.ld0 = D;
+      a2.src1 = ctx->pf_t1; a2.ld1 = D; a2.k_split = D;
+      BigEpi e2;
+      e2.bias = (const bf16_t*)ctx->dw.fc_b; e2.Y = ctx->xc + (size_t)op.c_row * D; e2.ldy = D;
+      if (launch_gemm_big(s, BIG_PLAIN, a2, op.n, ctx->dw.fc_w, 2 * D, 0, D / 32, e2)) return -1;
+      continue;
+    }
     if (!op.is_adapt) {
       for (int o = 0; o < op.n; o += CHUNK) {
         const int rows = std::min(CHUNK, op.n - o), r0 = op.c_row + o;
@@ -1062,7 +1095,14 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
     }
     // ImgAdaptor (cnets_ours.py:630-661): K/V projection of the image rows into a [2][H][cap][hd] scratch cache ...
     const int N = op.n;
-    for (int o = 0; o < N; o += CHUNK) {
+    if (N >= PREFILL_BIG_MIN_ROWS) {  // K|V projection of all N image rows in one prefill GEMM, image-row gather fused into its operand load
+      BigA a;
+      a.src0 = ctx->emb_shift; a.idx0 = ctx->idx_img + op.off; a.ld0 = D; a.k_split = D;
+      BigEpi e;
+      e.bias = (const bf16_t*)ctx->dw.ad_bkv; e.kc = akc; e.vc = avc; e.cap = ad_cap; e.H = Hd; e.D = D;
+      if (launch_gemm_big(s, BIG_KV, a, N, ctx->dw.ad_wkv, D, 0, 2 * D / 32, e)) return -1;
+    }
+    for (int o = 0; o < (N >= PREFILL_BIG_MIN_ROWS ? 0 : N); o += CHUNK) {
       const int rows = std::min(CHUNK, N - o);
       if (launch_gather(s, ctx->emb_shift, D, ctx->idx_img, op.off + o, nullptr, ctx->dx, D, rows, D)) return -1;
       if (launch_gemm(ctx, s, ctx->dx, D, ctx->dw.ad_wkv, ctx->dw.ad_bkv, ctx->ad_tmp, 2 * D, nullptr, 0, rows, 2 * D, D, EPI_NONE))
@@ -1088,7 +1128,19 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   bf16_t* kc = ctx->draft_kv;
   bf16_t* vc = ctx->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
   int last_chunk_rows = 0;
-  for (int o = 0; o < Lc; o += CHUNK) {
+  int o_first = 0;
+  if (Lc >= PREFILL_BIG_MIN_ROWS && qkv_rope_fused(3 * D)) {
+    // k|v (+ rotary at each row's ORIGINAL position, + append) of every compressed row in one prefill GEMM over the k and v row blocks of
+    // the rope-ordered q|k|v weight; q is only needed for the last row (:1109) — the last 32-row pass below provides it
+    BigA a;
+    a.src0 = ctx->xc; a.ld0 = D; a.k_split = D;
+    BigEpi e;
+    e.bias = (const bf16_t*)ctx->dw.bqkv; e.kc = kc; e.vc = vc; e.cap = c.draft_max_pos; e.H = Hd; e.D = D;
+    e.cosT = (const bf16_t*)ctx->dw.rope_cos; e.sinT = (const bf16_t*)ctx->dw.rope_sin; e.pos = ctx->pos_c;
+    if (launch_gemm_big(s, BIG_ROPE_KV, a, Lc, ctx->dw.wqkv, D, D / 32, 2 * D / 32, e)) return -1;
+    o_first = ((Lc - 1) / CHUNK) * CHUNK;  // only the last chunk goes through the skinny q|k|v (it rewrites the same k, v rows)
+  }
+  for (int o = o_first; o < Lc; o += CHUNK) {
     const int rows = std::min(CHUNK, Lc - o);
     PosSpec ps;
     ps.off = ctx->pos_c + o;
