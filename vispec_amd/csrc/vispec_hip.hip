@@ -111,6 +111,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   if (!cfg || !out) return fail("null argument");
   if (leader && (leader->leader || memcmp(&leader->c, cfg, sizeof(vispec_config)) != 0))
     return fail("ctx_create_member: the leader must be an ordinary ctx created with the same config");
+  if (leader && cfg->total_token > 32) return fail("ctx_create_member: a cohort member owns one 32-row activation tile: total_token <= 32");
   const vispec_config& c = *cfg;
   if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
   if (c.hidden_size % 64 || c.intermediate_size % 64 || c.draft_intermediate % 64 || c.vocab_size % 16)
@@ -1159,7 +1160,9 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   if (draft_layer_tail(solo, s, 1, xlast, ctx->dlast)) return -1;
   hipLaunchKernelGGL(set_first_token_kernel, dim3(1), dim3(64), 0, s, ctx->st, first_token_dev, Lc, L);
   KCHK();
-  if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, ROWS, D)) return -1;  // the request's final g, for every later draft_fuse
+  // the request's final g, for every later draft_fuse (they use <= max(depth + 2, top_k) <= 16 rows; a cohort member's dx1 is the
+  // second 32-row tile of its leader's: never write past 32 rows of a ctx's own view)
+  if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, 32, D)) return -1;
   return draft_grow_tree(solo, s);
 }
 
@@ -1351,6 +1354,7 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   const vispec_config& c = ctx->c;
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
+  if (ctx->leader && total_token > 32) return fail("a cohort member owns one 32-row activation tile: total_token <= 32");
   ctx->c.total_token = total_token;
   // (the tree size is part of every graph key: the captured launch sequences depend on it)
   return 0;
