@@ -164,6 +164,37 @@ def test_g8_whole_loop_image(golden_dir):
     assert max(acc) == 4 and d.stable_kv[0].shape[1] < len(out) - 20  # compressed draft KV is shorter than the context
 
 
+@pytest.mark.parametrize("case", ["succ0", "succ1", "rand1", "img"])
+def test_torch_cpu_backend_reproduces_the_reference_streams(golden_dir, case):
+    """oracle/torch_cpu.py (the PyTorch-CPU back end bench.py's cpu_baseline leg times) is pinned like the numpy oracle: the
+    reference-captured token streams and accept lengths of g8, through TorchOps, and through timed_request's call sequence."""
+    pytest.importorskip("torch")
+    from oracle import torch_cpu as tc
+    g = load(golden_dir, "g8_loop.npz")
+    if case == "img":
+        t, tw = oracle_target(seed=70, structured=True)
+        d, _ = oracle_draft(seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+        kw, mnt = dict(inputs_embeds=g["img_emb"], image_mask=g["img_mask"]), 30
+    elif case.startswith("rand"):
+        t, _ = oracle_target(seed=30 + int(case[4:]))
+        d, _ = oracle_draft(seed=40 + int(case[4:]))
+        kw, mnt = {}, 24
+    else:
+        t, tw = oracle_target(seed=50 + int(case[4:]), structured=True)
+        d, _ = oracle_draft(seed=60 + int(case[4:]), structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+        kw, mnt = {}, 40
+    t.ops, d.ops = tc.TorchOps(), tc.TorchOps()
+    out, new_token, idx, acc = vo.specgenerate(t, d, g[f"{case}_ids"], max_new_tokens=mnt, max_pos=T["max_pos"], **kw)
+    np.testing.assert_array_equal(out, g[f"{case}_out"])
+    np.testing.assert_array_equal(acc, g[f"{case}_acc"])
+    # the timed leg's own call sequence: same rounds, same accept lengths, AR continuation == the speculative stream
+    rounds = 5
+    r = tc.timed_request(t, d, g[f"{case}_ids"], kw.get("inputs_embeds"), kw.get("image_mask"), rounds=rounds, ar_steps=3, max_pos=T["max_pos"])
+    assert r["accept_lengths"] == list(g[f"{case}_acc"][:rounds])
+    np.testing.assert_array_equal(r["tokens"], g[f"{case}_out"][: len(r["tokens"])])
+    assert len(r["verify_s"]) == rounds and len(r["ar_s"]) == 3 and r["context"] == len(r["tokens"])
+
+
 def test_g9_bf16_rounding_points(golden_dir):
     """Oracle in bf16-emulation mode vs the reference run in torch-bf16 on CPU.  Reduction orders differ, so the
     bound is a few bf16 ulps (2^-8 relative), not bitwise."""
