@@ -180,13 +180,19 @@ def algorithmic_bytes_per_ar_step(tcfg, n_ctx, fp8=False):
     return (1 if fp8 else 2) * (NL * (2 * D * D + 2 * D * kvd + 3 * D * I) + V * D) + 2 * NL * kvd * 2 * n_ctx
 
 
-def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4):
+CPU_THREADS = 16  # torch's CPU GEMMs at M <= 30 are memory-bound and get SLOWER with more threads on the 256-core GPU box
+                  # (tools/cpu_probe.py, [30,4096]x[11008,4096]: 6.0 ms at 16 threads, 26 ms at 64, 261 ms at 256)
+
+
+def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
     """The reference's CPU path in spirit: the oracle's restatement on its PyTorch-CPU back end
-    (oracle/torch_cpu.py: torch ops, fp32, torch.set_num_threads(all host cores)) runs ONE request of the bench workload on the host —
-    the very weights the GPU streams (copied to the host, de-fused to the reference's state-dict names), the same prompt at its real
-    length: target prefill, draft prefill with image-token compression, then a bounded number of draft-and-verify rounds with MEASURED
-    accept lengths and of plain AR steps on the same cores.  tokens/s = (tau + 1) / seconds per round, steady state (the prefill is
-    reported separately).  Checker-side code only: nothing here is on the product path."""
+    (oracle/torch_cpu.py: torch ops, fp32, torch.set_num_threads) runs the decode part of ONE request of the bench workload on the
+    host — the very weights the GPU streams (copied to the host, de-fused to the reference's state-dict names), the same prompt at its
+    real length: the draft prefill with image-token compression, then a bounded number (and a bounded time) of draft-and-verify rounds
+    with MEASURED accept lengths and of plain AR steps on the same cores.  The 2704-token TARGET prefill (36 TFLOP: minutes on host
+    cores) is not repeated on the CPU: its outputs — KV rows, hidden states, last logits — are copied from the GPU's prefill, which is
+    how the CPU rounds start from the real context.  tokens/s = (tau + 1) / seconds per round, steady state.  Checker-side code only:
+    nothing here is on the product path."""
     from oracle import torch_cpu as tc
     from oracle import vispec_oracle as vo
     avail_gb = 0.0
@@ -200,7 +206,7 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4):
     need_gb = n_par * 4 * 1.6 / 1e9  # fp32 copies + transients
     if avail_gb and avail_gb < need_gb + 16:
         return dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"skipped: {avail_gb:.0f} GB of host memory available, {need_gb:.0f} GB needed")
-    cores = os.cpu_count()
+    cores = min(CPU_THREADS, os.cpu_count())
     torch.set_num_threads(cores)
     eng = sm.engine
     t0 = time.time()
@@ -218,17 +224,24 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4):
     emb = emb_in.reshape(-1, emb_in.shape[-1]).float().cpu().numpy()
     mask_np = None if mask is None else mask.reshape(-1).cpu().numpy().astype(bool)
     L = emb.shape[0]
+    # the GPU's target prefill of this prompt: KV rows [0, L) of every layer, post-norm hidden states, last logits row
+    logits_g, hidden_g = sm.base_model.prefill(emb_in.reshape(-1, emb_in.shape[-1]).to(torch.bfloat16).contiguous(), position_ids=pos3)
+    torch.cuda.synchronize()
+    kv_g = eng.target_kv[:, 0, :, :L].float().cpu().numpy()
     r = tc.timed_request(ot, od, ids[0].cpu().numpy(), emb, mask_np, rounds=rounds, ar_steps=ar_steps, max_pos=L + 64 * (rounds + 2),
-                         position_ids=None if pos3 is None else pos3.numpy(), rope_delta=int(rope_delta))
+                         position_ids=None if pos3 is None else pos3.numpy(), rope_delta=int(rope_delta),
+                         prefilled=(kv_g, hidden_g.float().cpu().numpy(), logits_g[-1].float().cpu().numpy()), budget_s=budget_s)
+    rounds = len(r["verify_s"])
     t_round = (sum(r["verify_s"]) + sum(r["draft_s"])) / rounds
     tau = float(np.mean(r["accept_lengths"]))
     t_ar = float(np.mean(r["ar_s"]))
     return dict(value=round((tau + 1) / t_round, 3), unit="tokens/s", cores=cores, kind="port",
                 ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar=round((tau + 1) / t_round * t_ar, 3), tau_measured=round(tau, 3),
                 seconds_per_round=round(t_round, 3), verify_s=round(float(np.mean(r["verify_s"])), 3), draft_s=round(float(np.mean(r["draft_s"])), 3),
-                prefill_s=round(r["prefill_s"], 2), draft_prefill_s=round(r["draft_prefill_s"], 2),
-                sample=(f"the oracle on its PyTorch-CPU back end (torch {torch.__version__}, fp32, {cores} threads): one bench request on the host — "
-                        f"target prefill of L={L} ({r['prefill_s']:.1f}s) and draft prefill with compression ({r['draft_prefill_s']:.1f}s, both outside the "
+                draft_prefill_s=round(r["draft_prefill_s"], 2), host_cores=os.cpu_count(),
+                sample=(f"the oracle on its PyTorch-CPU back end (torch {torch.__version__}, fp32, {cores} threads of {os.cpu_count()} host cores: more "
+                        f"threads slow torch's M<=30 GEMMs down here): the decode part of one bench request on the host — target prefill of L={L} taken "
+                        f"from the GPU (KV rows, hidden states), draft prefill with compression on the CPU ({r['draft_prefill_s']:.1f}s, outside the "
                         f"quoted rate), then {rounds} full draft-and-verify rounds at context {L}..{r['context']} (all {tcfg.num_layers} target layers + "
                         f"lm_head on T={eng.total_token} tree nodes {np.mean(r['verify_s']):.2f}s + draft round {np.mean(r['draft_s']):.2f}s per round) with the "
                         f"GPU's own weight pair (measured tau {tau:.2f}) and {ar_steps} AR steps ({t_ar:.2f}s each) on the same cores; host copy and "

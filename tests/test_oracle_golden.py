@@ -193,6 +193,15 @@ def test_torch_cpu_backend_reproduces_the_reference_streams(golden_dir, case):
     assert r["accept_lengths"] == list(g[f"{case}_acc"][:rounds])
     np.testing.assert_array_equal(r["tokens"], g[f"{case}_out"][: len(r["tokens"])])
     assert len(r["verify_s"]) == rounds and len(r["ar_s"]) == 3 and r["context"] == len(r["tokens"])
+    # ... and with the target prefill handed over (bench.py passes the GPU's KV rows, hidden states and last logits)
+    ids = g[f"{case}_ids"]
+    pkv, data, cur = vo.initialize_past_key_values(T["NL"], T["H"], T["max_pos"], T["D"] // T["H"])
+    t.tree_mask = None
+    lg, hid = t.forward(pkv, input_ids=ids) if kw.get("inputs_embeds") is None else t.forward(pkv, inputs_embeds=kw["inputs_embeds"])
+    r2 = tc.timed_request(t, d, ids, kw.get("inputs_embeds"), kw.get("image_mask"), rounds=rounds, ar_steps=0, max_pos=T["max_pos"],
+                          prefilled=(data[0][:, 0, :, : len(ids)].copy(), hid, lg[-1]))
+    assert r2["accept_lengths"] == r["accept_lengths"]
+    np.testing.assert_array_equal(r2["tokens"], r["tokens"])
 
 
 def test_g9_bf16_rounding_points(golden_dir):
