@@ -3,7 +3,7 @@
 # (copy into profiles/ to keep it).  Usage on the GPU box:  ./tools/profile_bench.sh r02 [extra bench args, default: --lanes 1]
 tag=${1:-r02}
 shift
-args=${@:---lanes 1}
+args=${@:---lanes 1 --cohort 1}
 export TMPDIR=/tmp
 out=/tmp/prof_$tag
 rm -rf $out
