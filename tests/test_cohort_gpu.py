@@ -102,3 +102,42 @@ def test_member_requires_its_leader():
     mb = sm.make_cohort_member()
     with pytest.raises(RuntimeError, match="member of the first"):
         other.engine.cohort_round(mb.engine)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_cohort_qwen_tiny_gqa_bias_mrope_and_fp8(fp8):
+    """Qwen2.5-VL-shaped pair (GQA 4/2, q/k/v bias, two-kernel q|k|v + rotary path below the fused threshold, rope_delta per request,
+    multimodal rotary prefill) and its fp8 variant: the cohort reproduces the two single runs."""
+    from test_loop_gpu import build_qwen, build_qwen_fp8
+    sm, ot, od, IMG = build_qwen_fp8() if fp8 else build_qwen()
+    mb = sm.make_cohort_member()
+    Q = synth.QWEN_TINY
+    rng = np.random.default_rng(81)
+    reqs = []
+    for grids, segs in (([(1, 6, 8), (1, 4, 4)], (4, 3, 6)), ([(1, 4, 8)], (7, 5))):
+        parts = []
+        for gi, g3 in enumerate(grids):
+            parts += [rng.integers(3, IMG, segs[gi]), np.full(g3[1] * g3[2] // 4, IMG)]
+        parts.append(rng.integers(3, IMG, segs[-1]))
+        ids = np.concatenate(parts)
+        n_img = int((ids == IMG).sum())
+        feats = synth.bf16_grid(rng.standard_normal((n_img, Q["D"]), dtype=np.float32) * 0.05)
+        reqs.append((torch.from_numpy(ids)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(), image_grid_thw=torch.tensor(grids))))
+    want = [single(sm, *r, max_new_tokens=24) for r in reqs]
+    got = specgenerate_cohort([sm, mb], reqs, max_new_tokens=24)
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    assert max(max(g[3]) for g in got) >= 3
+
+
+def test_cohort_with_sampling_uses_each_requests_seed():
+    sm, ot, od = build(50, 60, True)
+    mb = sm.make_cohort_member()
+    rng = np.random.default_rng(82)
+    reqs = [(torch.from_numpy(rng.integers(3, T["V"], size=14))[None], {}), (torch.from_numpy(rng.integers(3, T["V"], size=19))[None], {})]
+    want = [sm.specgenerate(r[0], temperature=6.0, top_k=8, seed=sd, max_new_tokens=20, log=True, return_acceptance_len=True) for r, sd in zip(reqs, (3, 5))]
+    got = specgenerate_cohort([sm, mb], reqs, temperature=6.0, top_k=8, seeds=[3, 5], max_new_tokens=20)
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())
+        assert acc == w[3]

@@ -77,3 +77,20 @@ def test_idempotent_and_request_independent(model_full):
     b1 = sm.specgenerate(b_ids, max_new_tokens=48, **b_pix)
     a2 = sm.specgenerate(a_ids, max_new_tokens=48, **a_pix)
     assert torch.equal(a1, a2) and not torch.equal(a1[:, -40:], b1[:, -40:])
+
+
+def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
+    """Two requests on one weight pass (64-row GEMMs, m_tile mode, fused two-request attention) at the real model sizes: token for token
+    the single-request results."""
+    import bench
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    sm, tcfg, name = model_full
+    bench.MODEL = name
+    dev = torch.device("cuda:0")
+    reqs = [bench.make_request(tcfg, 7, dev), bench.make_request(tcfg, 8, dev)]
+    want = [sm.specgenerate(ids, max_new_tokens=64, log=True, return_acceptance_len=True, **pix) for ids, pix in reqs]
+    mb = sm.make_cohort_member()
+    got = specgenerate_cohort([sm, mb], reqs, max_new_tokens=64)
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3])
+    del mb
