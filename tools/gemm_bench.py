@@ -20,7 +20,7 @@ SHAPES = [("o_proj", 4096, 4096), ("qkv", 12288, 4096), ("down", 4096, 11008), (
 variants = [int(v) for v in sys.argv[1:]] or [100, 101, 110, 111, 201, 401, 411, 402, 801]
 p = lambda t: C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for M in (30, 8):
+for M in [int(m) for m in os.environ.get("MS", "30,8").split(",")]:
     for name, N, K in SHAPES:
         nbuf = max(2, int(1.5e9 // (N * K * 2)))
         Ws = [pack_weight((torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)) for _ in range(nbuf)]
@@ -30,7 +30,7 @@ for M in (30, 8):
         Y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         res = []
         for v in variants:
-            if ((v % 10000) // 100) * 32 * N > 8 * 32 * 16384:
+            if ((v % 10000) // 100) * (64 if M > 32 else 32) * N > 8 * 64 * 16384:
                 continue
             for w in Ws[:2]:
                 L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K + PAD, p(w), p(Y), N, M, N, K))

@@ -165,13 +165,28 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #define XS_STEP 1056
 #define XS_HALF 528
 // MT = 32-row activation tiles per launch (M <= 32*MT): every weight tile in registers feeds MT MFMAs
+// Two-tile (MT = 2: cohorts, trees of 33..64 nodes) instantiation: ONE activation LDS buffer per wave (same-wave LDS traffic is
+// processed in issue order, so the second buffer is not needed for correctness) and a register budget for 3 waves per SIMD:
+// 33.8 KB of LDS and 152 VGPRs instead of 67.6 KB / 181 -> three workgroups per CU instead of two (1030 -> 1048 tok/s for one cohort
+// lane).  What the second tile really costs is the activation traffic itself: tools/gemm_bench.py (MS=30,60, variants 10100 / 20100)
+// — gate|up 37.4 us at M = 30, 49.3 us at M = 60, 38.4 us at M = 60 WITHOUT the activation loads: every one of the 688 workgroups
+// re-reads the whole 64 x 4096 block from L2 (360 MB per launch, ~33 TB/s: the L2's own limit).
+#ifndef VISPEC_MT2_LDSBUF
+#define VISPEC_MT2_LDSBUF 1
+#endif
+#ifndef VISPEC_MT2_MINWAVES
+#define VISPEC_MT2_MINWAVES 3
+#endif
+template <int MT>
+constexpr int gemm_w32_xbufs() { return MT == 2 ? VISPEC_MT2_LDSBUF : 2; }
 template <int NT, int UNROLL, int NW, int MT = 1>
 constexpr int gemm_w32_lds_bytes() {
-  return (NW * MT * 2 * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * 2 * UNROLL * XS_STEP) : (NW * NT * MT * 4096);
+  return (NW * MT * gemm_w32_xbufs<MT>() * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * gemm_w32_xbufs<MT>() * UNROLL * XS_STEP)
+                                                                                       : (NW * NT * MT * 4096);
 }
 
 template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
-__global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+__global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
                                                            int S, const float* __restrict__ wscale, RopeEpi re, int m_tile) {
@@ -206,7 +221,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
   constexpr int SEGS = 2 * UNROLL, RPI = 64 / SEGS, NINST = 32 / RPI;
   const int seg = lane % SEGS, srow0 = lane / SEGS;
   constexpr int XTILE = UNROLL * XS_STEP;  // one staged group of one activation tile; per wave: [2 buffers][MT tiles]
-  unsigned char* xs = smem_g + wave * (MT * 2 * XTILE);
+  constexpr int XBUFS = gemm_w32_xbufs<MT>();  // same-wave LDS traffic is processed in issue order: one buffer is enough for correctness
+  unsigned char* xs = smem_g + wave * (MT * XBUFS * XTILE);
   const bf16_t* sx[MT][NINST];
   int woff[NINST];
 #pragma unroll
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w32_kernel(const bf16_t* __restr
       for (int i = 0; i < NINST; ++i) sx[mt][i] += 16 * UNROLL;
   };
   auto compute = [&](const Regs& g, int buf) {
-    unsigned char* xb = xs + buf * (MT * XTILE);
+    unsigned char* xb = xs + (XBUFS == 2 ? buf : 0) * (MT * XTILE);
     if (DBG != 1) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
