@@ -412,7 +412,7 @@ class Engine:
     def ar_step(self):
         L.check(self.lib.vispec_ar_step(self.h, self._stream()))
 
-    PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "gemm_qkv_rope", "k6", "k7", "k8",
+    PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "gemm_qkv_rope", "k6", "gemm_prefill_mfma", "k8",
                   "attn_partial", "attn_reduce", "k11", "attn_partial_sdpa", "attn_reduce_sdpa"]
 
     def set_graphs(self, on: bool):
