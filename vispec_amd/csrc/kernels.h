@@ -81,11 +81,12 @@ struct DevState {
 //           loads per operand in flight behind the MFMAs; waves are reduced through LDS in a fixed order (deterministic).
 //   X (activations, L2-resident) is fetched in whole 128-B lines and re-shaped into the B operand through a per-wave LDS image
 //   (MT images when M > 32: the weight tile in registers then feeds MT MFMAs).
+//   NT = 2: the workgroup owns TWO row blocks (tile, tile + tile2_off) and every staged activation fragment feeds both — half the
+//   L2 -> CU activation traffic per weight byte.  Used with MT = 2, where that traffic is what the second tile costs (see below).
 //   D[i = n][j = m]: a lane ends with 4 groups of 4 consecutive n for its m -> 8-byte bf16 / 16-byte fp32 stores.
 // Epilogues (bf16 results carry the reference's rounding points):
 //   NONE / RESIDUAL   plain
-//   SWIGLU            NT = 1: weight in "SwiGLU order" (16 gate rows + the 16 up rows of the same outputs per tile), act closes in-lane;
-//                     NT = 2 (unused by the library now): second stream = the matching `up` block
+//   SWIGLU            weight in "SwiGLU order" (16 gate rows + the 16 up rows of the same outputs per tile), act closes in-lane
 //   PARTIAL           fp32 partial sums [S][32·MT][N] that splitk_reduce_kernel finishes (bias, residual, RMSNorm fused)
 //   ROPE              q|k|v projection: rotary + KV append (weight in "rope order", see RopeEpi)
 // ------------------------------------------------------------------------------------------------
@@ -186,7 +187,7 @@ constexpr int gemm_w32_lds_bytes() {
 }
 
 template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
-__global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+__global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES : 2) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
                                                            int S, const float* __restrict__ wscale, RopeEpi re, int m_tile) {
@@ -372,25 +373,29 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void 
   __syncthreads();
   if (EPI == EPI_ROPE) {
     // waves 0/1 own column groups q and q+2 of the tile: packed columns c = 8q + 4hi + r (< 16) and c + 16 = its rotate_half partner
+    // (NT = 2: waves 2/3 do the same for the workgroup's second row block)
+    static_assert(NW >= 2 * NT, "rope epilogue: two waves per row block");
+    const int tb = (NT == 2) ? (wave >> 1) : 0;
+    const int tile_b = tile + tb * tile2_off;
     for (int mt = 0; mt < MT; ++mt) {
       const int m = 32 * mt + j;
       const int rq = m_tile > 0 ? mt : 0;        // request owning this tile
       const int mr = m_tile > 0 ? j : m;         // row index inside the request
-      if (wave < 2 && row_ok(m)) {
-        const int qq = wave;
+      if (wave < 2 * NT && row_ok(m)) {
+        const int qq = wave & 1;
         float a[4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sa = red[0][0][mt][lane][4 * qq + r], sb = red[0][0][mt][lane][4 * (qq + 2) + r];
+          float sa = red[0][tb][mt][lane][4 * qq + r], sb = red[0][tb][mt][lane][4 * (qq + 2) + r];
 #pragma unroll
           for (int w = 1; w < NW; ++w) {
-            sa += red[w][0][mt][lane][4 * qq + r];
-            sb += red[w][0][mt][lane][4 * (qq + 2) + r];
+            sa += red[w][tb][mt][lane][4 * qq + r];
+            sb += red[w][tb][mt][lane][4 * (qq + 2) + r];
           }
           a[r] = sa;
           b[r] = sb;
         }
-        const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
+        const int ncol = tile_b * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
         const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
         const PosSpec& ps_ = re.ps[rq];
         const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + mr;
@@ -432,26 +437,26 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void 
     }
     return;
   }
-  if (EPI == EPI_SWIGLU && NT == 1) {
+  if (EPI == EPI_SWIGLU) {
     // "SwiGLU order" (one 32-row tile = the 16 gate rows and the 16 up rows of the same 16 outputs, packed by the loader): column
     // group qq (< 2) holds gate values, group qq + 2 the matching up values, so act = silu(gate) * up closes inside one lane and a
     // gate|up GEMM is N/16 equal workgroups of ONE tile stream (688 for I = 11 008: 2.7 rounds of 256 KB instead of 1.34 of 512 KB).
-    for (int idx = wave; idx < 2 * MT; idx += NW) {
-      const int qq = idx & 1, mt = idx >> 1;
+    for (int idx = wave; idx < 2 * MT * NT; idx += NW) {
+      const int qq = idx & 1, mt = (idx >> 1) % MT, tb = (idx >> 1) / MT;
       const int m = 32 * mt + j;
       float a[4], b[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float sa = red[0][0][mt][lane][4 * qq + r], sb = red[0][0][mt][lane][4 * (qq + 2) + r];
+        float sa = red[0][tb][mt][lane][4 * qq + r], sb = red[0][tb][mt][lane][4 * (qq + 2) + r];
 #pragma unroll
         for (int w = 1; w < NW; ++w) {
-          sa += red[w][0][mt][lane][4 * qq + r];
-          sb += red[w][0][mt][lane][4 * (qq + 2) + r];
+          sa += red[w][tb][mt][lane][4 * qq + r];
+          sb += red[w][tb][mt][lane][4 * (qq + 2) + r];
         }
         a[r] = sa;
         b[r] = sb;
       }
-      const int n = tile * 16 + 8 * qq + 4 * hi;  // output column of a[0]; gate row n, up row N + n of the natural weight
+      const int n = (tile + tb * tile2_off) * 16 + 8 * qq + 4 * hi;  // output column of a[0]; gate row n, up row N + n of the natural weight
       if (row_ok(m) && n < N) {
         float o[4];
 #pragma unroll
@@ -469,32 +474,23 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void 
     }
     return;
   }
-  constexpr int NGROUPS = ((EPI == EPI_SWIGLU) ? 4 : 4 * NT) * MT;
+  constexpr int NGROUPS = 4 * NT * MT;
   for (int idx = wave; idx < NGROUPS; idx += NW) {
     const int q = idx & 3, tm = idx >> 2;
-    const int mt = tm % MT, tt = (EPI == EPI_SWIGLU) ? 0 : tm / MT;
+    const int mt = tm % MT, tt = tm / MT;
     const int m = 32 * mt + j;
-    float v[4], u2[4];
+    float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float sum = red[0][tt][mt][lane][4 * q + r];
 #pragma unroll
       for (int w = 1; w < NW; ++w) sum += red[w][tt][mt][lane][4 * q + r];
       v[r] = sum;
-      if (EPI == EPI_SWIGLU) {
-        float su = red[0][NT - 1][mt][lane][4 * q + r];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) su += red[w][NT - 1][mt][lane][4 * q + r];
-        u2[r] = su;
-      }
     }
     const int n = (tile + (tt ? tile2_off : 0)) * 32 + 8 * q + 4 * hi;
     if (W8 && n < N) {  // per-output-channel dequantisation scale on the fp32 accumulator
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] *= wscale[n + r];
-        if (EPI == EPI_SWIGLU) u2[r] *= wscale[tile2_off * 32 + n + r];
-      }
+      for (int r = 0; r < 4; ++r) v[r] *= wscale[n + r];
     }
     if (row_ok(m) && n < N) {
       if (EPI == EPI_PARTIAL) {
@@ -508,13 +504,6 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? VISPEC_MT2_MINWAVES : 1)) void 
           float y = v[r];
           if (bias) y += bf2f(bias[n + r]);
           y = rdbf(y);
-          if (EPI == EPI_SWIGLU) {
-            float u = u2[r];
-            if (bias) u += bf2f(bias[tile2_off * 32 + n + r]);
-            u = rdbf(u);
-            float act = rdbf(y / (1.0f + __expf(-y)));
-            y = rdbf(act * u);
-          }
           if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
           o[r] = y;
         }

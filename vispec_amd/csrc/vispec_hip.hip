@@ -310,6 +310,9 @@ extern "C" int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, i
 // packed size in bf16 elements of an [N, K] weight in the W32 layout (rows padded to a multiple of 32)
 static size_t packed_elems(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
 
+// tuning / A-B switch (VISPEC_MT2_SINGLE_BLOCK=1): two-tile GEMMs with one row block per workgroup, the round-2a form
+static const bool g_mt2_single_block = getenv("VISPEC_MT2_SINGLE_BLOCK") && atoi(getenv("VISPEC_MT2_SINGLE_BLOCK")) != 0;
+
 static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
   if (K % 16) return fail("pack: K %% 16");
   hipLaunchKernelGGL(pack_w32_kernel, dim3(K / 16, (N + 31) / 32), dim3(64), 0, s, (const bf16_t*)W, N, K, (bf16_t*)P);
@@ -362,17 +365,33 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
   PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
                      T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile)
-  if (epi == EPI_SWIGLU) {  // weight in "SwiGLU order" (vispec_pack_weight docs): N/16 workgroups of one 32-row tile each
+  // Two activation tiles: a workgroup takes TWO row blocks (tile, tile + tiles/2) and feeds both from each staged activation
+  // fragment (NT = 2) — the activation re-read from L2 is what the second tile costs (kernels.h), and with several lanes in flight
+  // the halved workgroup count costs nothing (tools/gemm_mt2_concurrency.py: 4.03 -> 5.14 TB/s aggregate on 3 streams).
+#define VISPEC_GEMM_NT(EPI_, W8_, TILES, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                     \
+  do {                                                                                                                  \
+    bool done_ = false;                                                                                                 \
+    if constexpr (MT == 2 && !(W8_)) { /* fp8 tiles: the up-conversion temporaries push the paired form into scratch */ \
+      if ((TILES) % 2 == 0 && !g_mt2_single_block) {                                                                    \
+        VISPEC_GEMM(2, EPI_, W8_, dim3((TILES) / 2, SPLITS), (TILES) / 2, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE);   \
+        done_ = true;                                                                                                   \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    if (!done_) VISPEC_GEMM(1, EPI_, W8_, dim3(TILES, SPLITS), 0, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE);           \
+  } while (0)
+  if (epi == EPI_SWIGLU) {  // weight in "SwiGLU order" (vispec_pack_weight docs): N/16 32-row tiles
     if (N % 16) return fail("gemm_skinny: SwiGLU needs N %% 16 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
     prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
-    if (o.wscale) VISPEC_GEMM(1, EPI_SWIGLU, true, dim3(N / 16, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else VISPEC_GEMM(1, EPI_SWIGLU, false, dim3(N / 16, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    if (o.wscale) VISPEC_GEMM_NT(EPI_SWIGLU, true, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM_NT(EPI_SWIGLU, false, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
   }
   // split-K when the row blocks alone cannot fill the chip, or when a fused norm is requested (the reduce kernel owns it)
+  // (the split factor is the single-tile one whatever the workgroup shape: a row's partial sums then group the same k ranges in
+  //  every instantiation, which is what keeps a cohort request bit-identical to the same request run alone)
   int S = 1;
   if (tiles < 256 || o.norm_w) {
     S = choose_split(tiles, KS, (double)32 * K * (o.wscale ? 1.0 : 2.0), o.norm_w != nullptr);
@@ -381,10 +400,10 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (force_split > 0) S = force_split;
   if (S == 1 && !o.norm_w) {
     prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
-    if (epi == EPI_RESIDUAL && o.wscale) VISPEC_GEMM(1, EPI_RESIDUAL, true, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else if (epi == EPI_RESIDUAL) VISPEC_GEMM(1, EPI_RESIDUAL, false, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
-    else if (o.wscale) VISPEC_GEMM(1, EPI_NONE, true, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else VISPEC_GEMM(1, EPI_NONE, false, dim3(tiles, 1), 0, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    if (epi == EPI_RESIDUAL && o.wscale) VISPEC_GEMM_NT(EPI_RESIDUAL, true, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (epi == EPI_RESIDUAL) VISPEC_GEMM_NT(EPI_RESIDUAL, false, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    else if (o.wscale) VISPEC_GEMM_NT(EPI_NONE, true, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM_NT(EPI_NONE, false, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
@@ -392,8 +411,9 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (!ctx) return fail("gemm_skinny: split-K needs a ctx (partial workspace)");
   if ((size_t)S * 32 * MT * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
   prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
-  if (o.wscale) VISPEC_GEMM(1, EPI_PARTIAL, true, dim3(tiles, S), 0, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
-  else VISPEC_GEMM(1, EPI_PARTIAL, false, dim3(tiles, S), 0, nullptr, ctx->gemm_part, 0, nullptr, 0, S, nullptr);
+  if (o.wscale) VISPEC_GEMM_NT(EPI_PARTIAL, true, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
+  else VISPEC_GEMM_NT(EPI_PARTIAL, false, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, nullptr);
+#undef VISPEC_GEMM_NT
 #undef VISPEC_GEMM
   KCHK();
   prof_end(s);
@@ -502,11 +522,14 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
   prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
-#define VISPEC_QKV(W8_, MT_)                                                                                                              \
-  PLAUNCH((gemm_w32_kernel<1, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32, 1), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, MT_>()), s, \
-                     (const bf16_t*)X, ldx, (const bf16_t*)P, 0, (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1, (const float*)wscale, re, m_tile)
-  if (Mk <= 32) { if (wscale) VISPEC_QKV(true, 1); else VISPEC_QKV(false, 1); }
-  else { if (wscale) VISPEC_QKV(true, 2); else VISPEC_QKV(false, 2); }
+#define VISPEC_QKV(W8_, MT_, NT_)                                                                                                         \
+  PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT_>()), s, \
+                     (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
+                     (const float*)wscale, re, m_tile)
+  if (Mk <= 32) { if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
+  else if (wscale) VISPEC_QKV(true, 2, 1);
+  else if (g_mt2_single_block) VISPEC_QKV(false, 2, 1);
+  else VISPEC_QKV(false, 2, 2);  // N %% 128 == 0: the tile count is even
 #undef VISPEC_QKV
   KCHK();
   prof_end(s);
@@ -672,7 +695,11 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #define V2(DBG_)                                                                                                                   \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, DBG_, false, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 2>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
-    if (dbg == 1) V2(1); else if (dbg == 2) V2(2); else V2(0);
+    if (dbg == 4) {  // 5xxxx: two row blocks per workgroup (NT = 2) sharing every staged activation group: half the L2 -> CU activation traffic
+      if (tiles & 1) return fail("tune: NT=2 needs an even tile count");
+      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 0, false, 2>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s, x,
+                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+    } else if (dbg == 1) V2(1); else if (dbg == 2) V2(2); else V2(0);
 #undef V2
     KCHK();
     return 0;
