@@ -178,12 +178,15 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #ifndef VISPEC_MT2_MINWAVES
 #define VISPEC_MT2_MINWAVES 3
 #endif
-template <int MT>
-constexpr int gemm_w32_xbufs() { return MT == 2 ? VISPEC_MT2_LDSBUF : 2; }
+#ifndef VISPEC_MT2NT2_LDSBUF
+#define VISPEC_MT2NT2_LDSBUF 1
+#endif
+template <int MT, int NT = 1>
+constexpr int gemm_w32_xbufs() { return MT == 2 ? (NT == 2 ? VISPEC_MT2NT2_LDSBUF : VISPEC_MT2_LDSBUF) : 2; }
 template <int NT, int UNROLL, int NW, int MT = 1>
 constexpr int gemm_w32_lds_bytes() {
-  return (NW * MT * gemm_w32_xbufs<MT>() * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * gemm_w32_xbufs<MT>() * UNROLL * XS_STEP)
-                                                                                       : (NW * NT * MT * 4096);
+  return (NW * MT * gemm_w32_xbufs<MT, NT>() * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * gemm_w32_xbufs<MT, NT>() * UNROLL * XS_STEP)
+                                                                                           : (NW * NT * MT * 4096);
 }
 
 template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   constexpr int SEGS = 2 * UNROLL, RPI = 64 / SEGS, NINST = 32 / RPI;
   const int seg = lane % SEGS, srow0 = lane / SEGS;
   constexpr int XTILE = UNROLL * XS_STEP;  // one staged group of one activation tile; per wave: [2 buffers][MT tiles]
-  constexpr int XBUFS = gemm_w32_xbufs<MT>();  // same-wave LDS traffic is processed in issue order: one buffer is enough for correctness
+  constexpr int XBUFS = gemm_w32_xbufs<MT, NT>();  // same-wave LDS traffic is processed in issue order: one buffer is enough for correctness
   unsigned char* xs = smem_g + wave * (MT * XBUFS * XTILE);
   const bf16_t* sx[MT][NINST];
   int woff[NINST];

@@ -418,7 +418,10 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
-  PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? 1024 : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
+  // 512 threads per row: a 1024-thread workgroup needs 4 free waves on every SIMD of ONE CU, which it waits for when other lanes'
+  // GEMMs hold the slots (rocprofv3, 4 lanes: 24 us average against 5 us alone); 256 threads make the row pass itself slower
+  static const int red_threads = getenv("VISPEC_REDUCE_THREADS") ? atoi(getenv("VISPEC_REDUCE_THREADS")) : 512;
+  PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? red_threads : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
                      N, b, epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed,
                      o.ldn, o.eps, o.m_tile);
   KCHK();
@@ -701,6 +704,13 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                          ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
     } else if (dbg == 1) V2(1); else if (dbg == 2) V2(2); else V2(0);
 #undef V2
+    KCHK();
+    return 0;
+  }
+  if (dbg == 4) {  // 5xxxx at M <= 32: two row blocks per workgroup, one activation tile
+    if (tiles & 1) return fail("tune: NT=2 needs an even tile count");
+    hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 0, false, 1>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 1>()), s, x,
+                       ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
     KCHK();
     return 0;
   }
