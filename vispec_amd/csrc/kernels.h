@@ -288,17 +288,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
       // half 0 / half 1 of the activation image
 #pragma unroll
       for (int c = 0; c < LOADS; ++c) {
+        uint4 a_lo[NT], a_hi[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          uint4 a_lo, a_hi;
-          fp8x16_to_bf16(g.a[t][c], a_lo, a_hi);
+        for (int t = 0; t < NT; ++t) fp8x16_to_bf16(g.a[t][c], a_lo[t], a_hi[t]);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const unsigned char* xstep = xb + mt * XTILE + (2 * c + hi) * XS_STEP + j * 16;
-            const uint4 b0 = *reinterpret_cast<const uint4*>(xstep);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(xstep + XS_HALF);
-            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), acc[t][mt], 0, 0, 0);
-            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[t][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {  // each activation fragment is read once and feeds every row block
+          const unsigned char* xstep = xb + mt * XTILE + (2 * c + hi) * XS_STEP + j * 16;
+          const uint4 b0 = *reinterpret_cast<const uint4*>(xstep);
+          const uint4 b1 = *reinterpret_cast<const uint4*>(xstep + XS_HALF);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo[t]), as_bf16x8(b0), acc[t][mt], 0, 0, 0);
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi[t]), as_bf16x8(b1), acc[t][mt], 0, 0, 0);
           }
         }
       }
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __rest
 
 // ------------------------------------------------------------------------------------------------
 // Tree-masked attention, flash-decoding style.  hd = 128.
-//   grid (nsplit, H_kv), 256 threads.  A workgroup stages 128-key chunks of K and V of one KV head in LDS
+//   grid (nsplit, H_kv, q-tiles x requests), 256 threads.  A workgroup stages 128-key chunks of K and V of one KV head in LDS
 //   (coalesced 16-byte loads, XOR-swizzled rows), each wave owns one 32-key tile per chunk:
 //     S^T[key][q]  = K_tile · Q^T           8x mfma_32x32x16 (A = K from LDS, B = Q held in registers)
 //     online softmax per query column (the 16 scores a lane holds all belong to ONE query; the other 16 are in lane^32)
@@ -698,215 +699,10 @@ __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __rest
 //   The 4 waves' partial (m, l, O) are merged through LDS and written as one partial per (q-tile, split).
 //   Visibility: key < prefix -> visible to all rows; prefix <= key < prefix+tail -> bit (key-prefix) of mask[row].
 // ------------------------------------------------------------------------------------------------
-#define ATT_CHUNK 64
 __device__ __forceinline__ int att_swz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 15) << 4)); }
-// LDS: two 64-key buffers of K (16 KB) + V (16 KB) each; the merge area aliases buffer 0 after the last chunk
-#define ATT_LDS_BYTES (2 * 2 * ATT_CHUNK * 256 + 1024)
 
-template <bool EAGER>
-__global__ __launch_bounds__(256, 2) void tree_attn_partial_kernel(
-    const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vc, int s_max, int H,
-    int H_kv, int M, const int* __restrict__ prefix_dev, int tail, const unsigned long long* __restrict__ mask,
-    float* __restrict__ part_o, float* __restrict__ part_ml, int keys_per_wg, int nsplit) {
-  // grid (nsplit, H_kv), 256 threads = 4 waves arranged 2 (key tiles of a 64-key chunk) x 2 (halves of head_dim for P·V).
-  // Chunks stream HBM -> registers -> LDS with the NEXT chunk's loads in flight while the current one is on the matrix
-  // cores (one barrier per chunk); two workgroups per CU overlap each other's barriers.
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int split = blockIdx.x, kvh = blockIdx.y;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int kt = wave & 1, dh = wave >> 1;  // key tile / head_dim half owned by this wave
-  const int j = lane & 31, hi = lane >> 5;
-  const int n_prefix = prefix_dev ? *prefix_dev : 0;
-  const int n_total = n_prefix + tail;
-  const int key0 = split * keys_per_wg;
-  if (key0 >= n_total) return;
-  const int key_end = min(key0 + keys_per_wg, n_total);
-  const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
-  const bf16_t* Kh = Kc + (size_t)kvh * s_max * 128;
-  const bf16_t* Vh = Vc + (size_t)kvh * s_max * 128;
-  const int nchunk = (key_end - key0 + ATT_CHUNK - 1) / ATT_CHUNK;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-  const float sqrt_hd = 11.313708498984761f;
-  const float rsqrt_hd = 1.0f / sqrt_hd;
-  // staging map: thread -> 4 x 16 B of K and of V per chunk (row = s>>4, 16-B column = s&15), rows past the end are
-  // clamped to the last valid key (never visible: masked by key >= n_total) so every load stays unconditional
-  const int last_key = n_total - 1;
-
-  {
-    // one q-tile per workgroup (blockIdx.z): with GQA the G*MT q-tiles of a KV head re-read its K/V through L2, which keeps
-    // the grid wide (Qwen2.5-VL has only 4 KV heads) at no extra HBM traffic
-    const int qt = blockIdx.z;
-    const int head = kvh * G + qt / MT, m0 = (qt % MT) * 32;
-    const int mrow = m0 + j;
-    const bool qvalid = mrow < M;
-    uint4 qf[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)(qvalid ? mrow : 0) * ldq + head * 128 + ks * 16 + hi * 8);
-    const unsigned long long mbits = (qvalid && mask) ? mask[mrow] : 0ull;
-    float m_run = NEG_INF, l_run = 0.f;
-    f32x16 O[2];
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[hb][r] = 0.f;
-
-    // staging registers as named scalars + macros: arrays captured by a lambda (or conditionally written in the loop) were
-    // kept in scratch memory by hipcc (scratch_store/scratch_load around every chunk)
-    uint4 k0r, k1r, k2r, k3r, v0r, v1r, v2r, v3r;
-    const int srow = threadIdx.x >> 4, sc16 = threadIdx.x & 15;  // + 16 rows per p
-#define ATT_G1(kk, vv, p, ch)                                                               \
-  {                                                                                         \
-    const int key_ = min(key0 + (ch) * ATT_CHUNK + srow + 16 * (p), last_key);              \
-    kk = *reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8);               \
-    vv = *reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8);               \
-  }
-#define ATT_GLOAD(ch) ATT_G1(k0r, v0r, 0, ch) ATT_G1(k1r, v1r, 1, ch) ATT_G1(k2r, v2r, 2, ch) ATT_G1(k3r, v3r, 3, ch)
-#define ATT_W1(kk, vv, p, sK_, sV_)                                                         \
-  *reinterpret_cast<uint4*>(sK_ + att_swz(srow + 16 * (p), sc16 * 16)) = kk;                \
-  *reinterpret_cast<uint4*>(sV_ + att_swz(srow + 16 * (p), sc16 * 16)) = vv;
-#define ATT_LWRITE(buf)                                                                     \
-  {                                                                                         \
-    unsigned char* sK_ = smem + (buf) * (2 * ATT_CHUNK * 256);                              \
-    unsigned char* sV_ = sK_ + ATT_CHUNK * 256;                                             \
-    ATT_W1(k0r, v0r, 0, sK_, sV_) ATT_W1(k1r, v1r, 1, sK_, sV_) ATT_W1(k2r, v2r, 2, sK_, sV_) ATT_W1(k3r, v3r, 3, sK_, sV_) \
-  }
-    ATT_GLOAD(0)
-    ATT_LWRITE(0)
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < nchunk) { ATT_GLOAD(ch + 1) }  // in flight during the MFMA work below
-      const unsigned char* sK = smem + buf * (2 * ATT_CHUNK * 256);
-      const unsigned char* sV = sK + ATT_CHUNK * 256;
-      const int kbase = key0 + ch * ATT_CHUNK + kt * 32;
-      if (kbase < key_end) {
-        f32x16 S;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        const int krow = kt * 32 + j;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
-          S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
-        }
-        float mx = NEG_INF;
-        // eager scores: bf16(bf16(S) / sqrt(hd)).  The quotient comes from one FMA-corrected reciprocal multiply — bit-identical to
-        // the IEEE division for every bf16 input in the normal range (tools/div_check.hip, exhaustive) at a third of the instructions.
-        if (kbase + 32 <= n_prefix) {  // wave-uniform: the whole 32-key tile lies in the committed context, every key visible
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float sc;
-            if (EAGER) {
-              const float xb = rdbf(S[r]);
-              float q = xb * rsqrt_hd;
-              q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
-              sc = rdbf(q);
-            } else {
-              sc = S[r] * scale;
-            }
-            S[r] = sc;
-            mx = fmaxf(mx, sc);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float sc;
-            if (EAGER) {
-              const float xb = rdbf(S[r]);
-              float q = xb * rsqrt_hd;
-              q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
-              sc = rdbf(q);
-            } else {
-              sc = S[r] * scale;
-            }
-            bool vis = key < n_prefix;
-            if (!vis && key < n_total) vis = (mbits >> (key - n_prefix)) & 1ull;
-            sc = vis ? sc : NEG_INF;
-            S[r] = sc;
-            mx = fmaxf(mx, sc);
-          }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
-        float psum = 0.f;
-        unsigned pb[8];
-        const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;  // a row with nothing visible yet: exp(-inf - 0) = 0, never inf - inf
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float p0 = __expf(S[r] - m_sub);
-          const float p1 = __expf(S[r + 1] - m_sub);
-          psum += p0 + p1;
-          pb[r >> 1] = pack2(p0, p1);
-        }
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {  // the running maximum settles after the first chunks: most chunks rescale nothing
-#pragma unroll
-          for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[hb][r] *= alpha;
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const uint4 pB = make_uint4(pb[kb * 4 + 0], pb[kb * 4 + 1], pb[kb * 4 + 2], pb[kb * 4 + 3]);
-#pragma unroll
-          for (int hb = 0; hb < 2; ++hb) {
-            const int col = ((dh * 2 + hb) * 32 + j) * 2;
-            unsigned va[4];
-#pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2) {
-              const int ta = 2 * t2, tb = 2 * t2 + 1;
-              const int ra = kt * 32 + (ta & 3) + 8 * (ta >> 2) + 4 * hi + 16 * kb;
-              const int rb = kt * 32 + (tb & 3) + 8 * (tb >> 2) + 4 * hi + 16 * kb;
-              const unsigned lo = *reinterpret_cast<const bf16_t*>(sV + att_swz(ra, col));
-              const unsigned hi16 = *reinterpret_cast<const bf16_t*>(sV + att_swz(rb, col));
-              va[t2] = lo | (hi16 << 16);
-            }
-            const uint4 vA = make_uint4(va[0], va[1], va[2], va[3]);
-            O[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vA), as_bf16x8(pB), O[hb], 0, 0, 0);
-          }
-        }
-      }
-      if (ch + 1 < nchunk) ATT_LWRITE(buf ^ 1)  // buffer buf^1 was last read before the previous barrier
-      __syncthreads();
-    }
-    // ---- merge the two key-tile waves of each head_dim half (the (m,l) of equal-kt waves are bit-identical) ----
-    float* sM = reinterpret_cast<float*>(smem + 2 * 2 * ATT_CHUNK * 256);  // [2 kt][32] m, then [2][32] l
-    float* sO = reinterpret_cast<float*>(smem);                            // [128 hd][32 q] fp32 (aliases buffer 0)
-    if (dh == 0 && hi == 0) sM[kt * 32 + j] = m_run;
-    __syncthreads();
-    const float m_all = fmaxf(sM[j], sM[32 + j]);
-    const float f = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_all);
-    if (dh == 0 && hi == 0) sM[64 + kt * 32 + j] = l_run * f;
-    for (int t = 0; t < 2; ++t) {
-      if (kt == t) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int drow = (dh * 2 + hb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float v = O[hb][r] * f;
-            if (t == 0) sO[drow * 32 + j] = v; else sO[drow * 32 + j] += v;
-          }
-      }
-      __syncthreads();
-    }
-    const size_t pidx = ((size_t)(kvh * NQT + qt) * nsplit + split);
-    float4* po = reinterpret_cast<float4*>(part_o + pidx * (128 * 32));
-    for (int e = threadIdx.x; e < 128 * 32 / 4; e += 256) po[e] = reinterpret_cast<const float4*>(sO)[e];
-    if (threadIdx.x < 32) {
-      part_ml[pidx * 64 + threadIdx.x] = fmaxf(sM[threadIdx.x], sM[32 + threadIdx.x]);
-      part_ml[pidx * 64 + 32 + threadIdx.x] = sM[64 + threadIdx.x] + sM[96 + threadIdx.x];
-    }
-  }
-}
-
-// ---- round-2 form of the partial kernel -----------------------------------------------------------------------------------------
-// Same contract (one partial (m, l, O^T) per (q-tile, key split)), different work distribution:
+// ---- the partial kernel (round-2 form; round 1's ran two head_dim-half waves per key tile) ---------------------------
+// One partial (m, l, O^T) per (q-tile, key split):
 //   * a workgroup stages 128-key chunks; each of the 4 waves owns ONE 32-key tile of the chunk completely — QK^T, softmax and P·V
 //     over all 128 head_dim columns — so nothing is computed twice (the first form ran QK^T + softmax in both head_dim-half waves);
 //   * the V^T operand of P·V comes from the hardware transposing read (ds_read_b64_tr_b16: 16 per 32-key tile instead of 64

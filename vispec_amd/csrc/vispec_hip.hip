@@ -313,6 +313,10 @@ static size_t packed_elems(int N, int K) { return (size_t)((N + 31) / 32) * 32 *
 // tuning / A-B switch (VISPEC_MT2_SINGLE_BLOCK=1): two-tile GEMMs with one row block per workgroup, the round-2a form
 static const bool g_mt2_single_block = getenv("VISPEC_MT2_SINGLE_BLOCK") && atoi(getenv("VISPEC_MT2_SINGLE_BLOCK")) != 0;
 
+// fp8 tiles keep one row block per workgroup in the two-tile form: the paired instantiation needs 256 VGPRs + 76 B of scratch
+#ifndef VISPEC_W8_PAIR
+#define VISPEC_W8_PAIR 0
+#endif
 static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
   if (K % 16) return fail("pack: K %% 16");
   hipLaunchKernelGGL(pack_w32_kernel, dim3(K / 16, (N + 31) / 32), dim3(64), 0, s, (const bf16_t*)W, N, K, (bf16_t*)P);
@@ -371,7 +375,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 #define VISPEC_GEMM_NT(EPI_, W8_, TILES, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                     \
   do {                                                                                                                  \
     bool done_ = false;                                                                                                 \
-    if constexpr (MT == 2 && !(W8_)) { /* fp8 tiles: the up-conversion temporaries push the paired form into scratch */ \
+    if constexpr (MT == 2 && (VISPEC_W8_PAIR || !(W8_))) {                                                             \
       if ((TILES) % 2 == 0 && !g_mt2_single_block) {                                                                    \
         VISPEC_GEMM(2, EPI_, W8_, dim3((TILES) / 2, SPLITS), (TILES) / 2, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE);   \
         done_ = true;                                                                                                   \
