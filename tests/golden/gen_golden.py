@@ -515,6 +515,52 @@ def g10_qwen():
                         k0=f32(data[0, 0, :, : L + Tn]), v1=f32(data[3, 0, :, : L + Tn]))
 
 
+def g15_qwen_rope_index():
+    """The reference's own Qwen2_5_VLForConditionalGeneration.get_rope_index (modeling_qwen2_5_vl_kv.py:1789-1975) on prompts with image
+    runs, video runs (temporal index scaled by second_per_grid_ts * tokens_per_second) and both: pins vispec_amd.synth.qwen_rope_index,
+    the function the product's Qwen prefill positions and rope_delta come from.  Stored: prompts, grids, the reference's outputs."""
+    from types import SimpleNamespace as NS
+    from vispec.model import modeling_qwen2_5_vl_kv as q
+    IMG, VID, VS = 900, 901, 902
+    rng = np.random.default_rng(1500)
+    txt = lambda n: rng.integers(3, 800, n)
+    run = lambda tok, g: np.concatenate([[VS], np.full(g[0] * (g[1] // 2) * (g[2] // 2), tok)])
+    cases = [
+        dict(parts=[("t", 5), ("i", (1, 6, 8)), ("t", 7)], sec=None, tps=2),
+        dict(parts=[("t", 3), ("i", (1, 4, 4)), ("t", 2), ("i", (1, 8, 6)), ("t", 4)], sec=None, tps=2),
+        dict(parts=[("t", 4), ("v", (3, 4, 6)), ("t", 5)], sec=[1.0], tps=2),
+        dict(parts=[("t", 2), ("v", (4, 4, 4)), ("t", 3)], sec=None, tps=2),          # second_per_grid_ts absent -> 1.0
+        dict(parts=[("t", 2), ("i", (1, 4, 6)), ("t", 1), ("v", (5, 6, 4)), ("t", 6)], sec=[0.5], tps=25),
+        dict(parts=[("v", (2, 4, 4)), ("t", 3), ("v", (3, 4, 4)), ("i", (1, 4, 4)), ("t", 2)], sec=[2.0, 0.3], tps=2),
+        dict(parts=[("t", 9)], sec=None, tps=2),                                        # text only
+    ]
+    out = {"n_cases": np.int64(len(cases)), "ids_image": np.int64(IMG), "ids_video": np.int64(VID)}
+    for ci, c in enumerate(cases):
+        ids, ig, vg = [], [], []
+        for kind, v in c["parts"]:
+            if kind == "t":
+                ids.append(txt(v))
+            elif kind == "i":
+                ids.append(run(IMG, v)); ig.append(v)
+            else:
+                ids.append(run(VID, v)); vg.append(v)
+        ids = np.concatenate(ids).astype(np.int64)
+        fake = NS(config=NS(vision_config=NS(spatial_merge_size=2, tokens_per_second=c["tps"]), image_token_id=IMG, video_token_id=VID,
+                            vision_start_token_id=VS))
+        pos, delta = q.Qwen2_5_VLForConditionalGeneration.get_rope_index(
+            fake, torch.from_numpy(ids)[None], torch.tensor(ig) if ig else None, torch.tensor(vg) if vg else None,
+            torch.tensor(c["sec"], dtype=torch.float32) if c["sec"] is not None else None)
+        out[f"c{ci}_ids"] = ids
+        out[f"c{ci}_image_grids"] = np.asarray(ig, np.int64).reshape(-1, 3)
+        out[f"c{ci}_video_grids"] = np.asarray(vg, np.int64).reshape(-1, 3)
+        out[f"c{ci}_sec"] = np.asarray(c["sec"] if c["sec"] is not None else [], np.float32)
+        out[f"c{ci}_has_sec"] = np.int64(c["sec"] is not None)
+        out[f"c{ci}_tps"] = np.float32(c["tps"])
+        out[f"c{ci}_pos"] = pos[:, 0].numpy().astype(np.int64)
+        out[f"c{ci}_delta"] = np.int64(int(delta.reshape(-1)[0]))
+    np.savez_compressed(os.path.join(OUT, "g15_qwen_rope_index.npz"), **out)
+
+
 def g11_update_inference_inputs():
     """utils.update_inference_inputs in isolation (SURVEY §8c "G7"): accepted ids appended, KV rows gathered from the tree
     slots into [n, n+a+1) of EVERY cache tensor, lengths, the hidden rows handed to the draft, next token — greedy and
@@ -607,9 +653,9 @@ def g12_kvcache():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     fns = dict(g14=g14_tree_levels, g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

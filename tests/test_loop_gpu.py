@@ -790,3 +790,51 @@ def test_qwen2_text_target_with_qkv_bias_and_gqa():
     ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=20)[0].cpu().numpy()
     n = min(len(ar), len(o_out))
     np.testing.assert_array_equal(ar[:n], o_out[:n])
+
+
+def test_qwen25vl_video_prompt_matches_oracle():
+    """Qwen2.5-VL VIDEO input (spec_model_ours.py:421-453 + get_rope_index, modeling_qwen2_5_vl_kv.py:1789-1975): a prompt with one image
+    run and one 3-frame video run.  The reference keeps the LAST mask it built — the video's — as the draft's image mask (the image
+    run is then an ordinary row block for the draft), and the prefill positions take the video's temporal index
+    floor(frame * second_per_grid_ts * tokens_per_second); rope_delta shifts every decode position.  HIP loop == oracle loop == AR."""
+    Q = synth.QWEN_TINY
+    IMG, VID = Q["V"] - 1, Q["V"] - 2
+    tw = synth.make_target_weights(Q["D"], Q["H"], Q["I"], Q["V"], Q["NL"], seed=90, structured=True, qkv_bias=True, H_kv=Q["Hkv"])
+    dw = synth.make_draft_weights(Q["D"], Q["H"], Q["I"], Q["V"], seed=93, structured=True, qkv_bias=True,
+                                  target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    tcfg = TargetConfig(hidden_size=Q["D"], num_heads=Q["H"], num_kv_heads=Q["Hkv"], intermediate_size=Q["I"], vocab_size=Q["V"], num_layers=Q["NL"],
+                        max_position_embeddings=Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True,
+                        architectures=("Qwen2_5_VLForConditionalGeneration",), image_token_index=IMG, video_token_id=VID, attn_impl="sdpa",
+                        mrope_section=Q["mrope_section"], tokens_per_second=2.0)
+    dcfg = DraftConfig(hidden_size=Q["D"], num_heads=Q["H"], intermediate_size=Q["I"], vocab_size=Q["V"], max_position_embeddings=Q["max_pos"],
+                       rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw)
+    ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
+                                        attn_impl="sdpa", mrope_section=Q["mrope_section"]), tw, bf16=True)
+    od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)
+    rng = np.random.default_rng(23)
+    igrid, vgrid, sec = [(1, 4, 4)], [(3, 4, 4)], [1.5]  # 4 image tokens; 3 frames x 4 tokens at temporal index 0, 3, 6
+    ids = np.concatenate([rng.integers(3, VID, 4), np.full(4, IMG), rng.integers(3, VID, 3), np.full(12, VID), rng.integers(3, VID, 6)])
+    ifeat = synth.bf16_grid(rng.standard_normal((4, Q["D"]), dtype=np.float32) * 0.05)
+    vfeat = synth.bf16_grid(rng.standard_normal((12, Q["D"]), dtype=np.float32) * 0.05)
+    tb = lambda a: torch.from_numpy(a).to(torch.bfloat16).cuda()
+    kw = dict(pixel_values=tb(ifeat), image_grid_thw=torch.tensor(igrid), pixel_values_videos=tb(vfeat), video_grid_thw=torch.tensor(vgrid),
+              second_per_grid_ts=torch.tensor(sec))
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=24, log=True, return_acceptance_len=True, **kw)
+    pos3, delta = synth.qwen_rope_index(ids, IMG, igrid, video_token_id=VID, video_grids=vgrid, second_per_grid_ts=sec, tokens_per_second=2.0)
+    assert pos3[0, 11:23].tolist() == [p + int(pos3[0, 11]) for p in (0, 0, 0, 0, 3, 3, 3, 3, 6, 6, 6, 6)] and delta < 0
+    assert sm._rope_delta == delta
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[ids == IMG] = ifeat
+    emb[ids == VID] = vfeat
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, ids, inputs_embeds=emb, image_mask=(ids == VID), max_new_tokens=24, max_pos=Q["max_pos"],
+                                                 position_ids=pos3, rope_delta=delta)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), o_out)
+    assert acc == o_acc and max(acc) >= 3
+    st = sm.engine.state()
+    assert st["draft_len"] == st["n_ctx"] - 12 + (sm.engine.num_q - 1)  # only the video run is compressed
+    ar = sm.baseline_generate(torch.from_numpy(ids)[None], max_new_tokens=20, **kw)
+    n = min(ar.shape[1], len(o_out))
+    np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])
+    with pytest.raises(ValueError, match="Video features and video tokens do not match"):
+        sm.specgenerate(torch.from_numpy(ids)[None], max_new_tokens=4, pixel_values_videos=tb(vfeat[:8]), video_grid_thw=torch.tensor(vgrid))

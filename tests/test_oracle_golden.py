@@ -357,3 +357,21 @@ def test_g13_real_dims_lmhead_topk_and_fusion(golden_dir):
     h2 = o.linear(np.concatenate([g["hid"], np.broadcast_to(g["g"], g["hid"].shape)], -1), w["img_fc.weight"], w["img_fc.bias"])
     fused = o.linear(np.concatenate([g["emb"], h2], -1), w["fc.weight"], w["fc.bias"])
     np.testing.assert_allclose(fused, g["fused"], rtol=0, atol=2e-5 * np.abs(g["fused"]).max())
+
+
+def test_g15_qwen_rope_index_images_and_videos(golden_dir):
+    """vispec_amd.synth.qwen_rope_index == the reference's get_rope_index (modeling_qwen2_5_vl_kv.py:1789-1975) on image runs, video
+    runs with second_per_grid_ts * tokens_per_second temporal scaling (incl. the default 1.0 and a truncating 0.3 s grid), mixed
+    prompts and text only: positions [3, L] and rope_delta, exact."""
+    from vispec_amd import synth
+    g = np.load(os.path.join(golden_dir, "g15_qwen_rope_index.npz"))
+    IMG, VID = int(g["ids_image"]), int(g["ids_video"])
+    for ci in range(int(g["n_cases"])):
+        ids = g[f"c{ci}_ids"]
+        ig = [tuple(int(v) for v in r) for r in g[f"c{ci}_image_grids"]]
+        vg = [tuple(int(v) for v in r) for r in g[f"c{ci}_video_grids"]]
+        sec = g[f"c{ci}_sec"] if int(g[f"c{ci}_has_sec"]) else None
+        pos, delta = synth.qwen_rope_index(ids, IMG, ig, video_token_id=VID, video_grids=vg, second_per_grid_ts=sec,
+                                           tokens_per_second=float(g[f"c{ci}_tps"]))
+        np.testing.assert_array_equal(pos, g[f"c{ci}_pos"], err_msg=f"case {ci}")
+        assert delta == int(g[f"c{ci}_delta"]), ci

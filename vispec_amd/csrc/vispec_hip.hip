@@ -691,6 +691,13 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   const int tiles = (N + 31) / 32;
   const bool no_reduce = variant >= 10000;  // time the GEMM kernel alone
   const int dbg = variant / 10000 >= 2 ? variant / 10000 - 1 : 0;  // 2xxxx: no activation loads, 3xxxx: no epilogue
+  if (variant / 10000 == 7) {  // 7xxxx: the prefill kernel (128 x 128 workgroup tiles, activations shared through LDS), any M
+    BigA a;
+    a.src0 = x; a.ld0 = ldx; a.k_split = K;
+    BigEpi e;
+    e.Y = (bf16_t*)Y; e.ldy = ldy;
+    return launch_gemm_big(s, BIG_PLAIN, a, M, P, K, 0, tiles, e);
+  }
   variant %= 10000;
   const int S = variant / 100, nwc = (variant / 10) % 10, unc = variant % 10;
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");

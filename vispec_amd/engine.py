@@ -31,6 +31,7 @@ class TargetConfig:
     attn_impl: str = "eager"          # LLaVA-family KV-Llama is eager (modeling_llama_kv.py:602-623); Qwen2.5-VL runs SDPA
     mrope_section: Optional[tuple] = None  # Qwen2.5-VL multimodal rotary sections (16, 24, 24)
     video_token_id: int = -1
+    tokens_per_second: float = 2.0    # Qwen2.5-VL vision_config.tokens_per_second: temporal rotary index of video frames (get_rope_index)
 
     @property
     def head_dim(self):

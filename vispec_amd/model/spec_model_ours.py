@@ -259,41 +259,42 @@ class SpecModel:
         elif arch == "Qwen2_5_VLForConditionalGeneration":  # :380-453
             pixel_values, grid = kwargs.get("pixel_values"), kwargs.get("image_grid_thw")
             pixel_values_videos, vgrid = kwargs.get("pixel_values_videos"), kwargs.get("video_grid_thw")
-            if pixel_values_videos is not None or vgrid is not None:
-                # HF get_rope_index scales the temporal index of video grids by second_per_grid_ts * tokens_per_second and a prompt may
-                # mix image and video runs; the multimodal rotary positions built here (synth.qwen_rope_index) cover image grids only
-                raise NotImplementedError("Qwen2.5-VL video inputs (pixel_values_videos / video_grid_thw) are out of scope: their M-RoPE "
-                                          "temporal scaling is not implemented")
-            tok_id = self.base_model.config.image_token_id
             if inputs_embeds is None:
                 inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
-                for pv, g_, tid in ((pixel_values, grid, self.base_model.config.image_token_id),
-                                    (pixel_values_videos, vgrid, self.base_model.cfg.video_token_id)):
+                for pv, g_, tid, what in ((pixel_values, grid, self.base_model.config.image_token_id, "Image"),
+                                          (pixel_values_videos, vgrid, self.base_model.cfg.video_token_id, "Video")):
                     if pv is None:
                         continue
-                    feats = self.base_model.get_image_features(pv, image_grid_thw=g_)
+                    feats = self.base_model.get_image_features(pv, image_grid_thw=g_)  # the same visual tower serves both (:393-395, 426-428)
                     mask = input_ids == tid
                     if int(mask.sum()) != feats.shape[0]:  # :403-406 / :435-438
-                        raise ValueError(f"Image features and image tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")
+                        raise ValueError(f"{what} features and {what.lower()} tokens do not match: tokens: {int(mask.sum())}, features {feats.shape[0]}")
                     inputs_embeds = inputs_embeds.clone()
                     inputs_embeds[mask] = feats.to(inputs_embeds.dtype)
-                    special_image_mask = mask  # the reference keeps the LAST mask it built (:420,453)
-                    tok_id, grid = tid, g_
+                    special_image_mask = mask  # the reference keeps the LAST mask it built (:420,453): with a video, the draft compresses
+                    #                            the video runs and sees image tokens as ordinary rows
             draft_embeds = inputs_embeds
-            position_ids, rope_delta = self._qwen_rope(input_ids, grid, tok_id)
+            # multimodal rotary positions of the prefill + rope_delta of the decode rounds: get_rope_index over image AND video grids,
+            # video frames at floor(frame * second_per_grid_ts * tokens_per_second) (modeling_qwen2_5_vl_kv.py:1789-1975, 2157-2163)
+            position_ids, rope_delta = self._qwen_rope(input_ids, grid, video_grid=vgrid, second_per_grid_ts=kwargs.get("second_per_grid_ts"))
         elif arch in ("LlamaForCausalLM", "Qwen2ForCausalLM"):
             pass  # text targets (Qwen2 = the same decoder with q/k/v bias, modeling_qwen2_kv.py): the draft embeds the ids itself (cnets_ours.py:1099-1107)
         else:
             raise NotImplementedError(f"target architecture {arch}")
         return inputs_embeds, special_image_mask, draft_embeds, position_ids, rope_delta
 
-    def _qwen_rope(self, input_ids, grid, tok_id=None):
-        """Multimodal rotary positions [3, L] + rope_delta of a Qwen2.5-VL prompt (HF get_rope_index, image grids), cached on the target
-        like the reference's prefill does (modeling_qwen2_5_vl_kv.py `self.rope_deltas`; read back by utils.tree_decoding, utils.py:398-400)."""
+    def _qwen_rope(self, input_ids, grid, video_grid=None, second_per_grid_ts=None):
+        """Multimodal rotary positions [3, L] + rope_delta of a Qwen2.5-VL prompt (get_rope_index: image and video grids), cached on the
+        target like the reference's prefill does (modeling_qwen2_5_vl_kv.py `self.rope_deltas`; read back by utils.tree_decoding, utils.py:398-400)."""
         from ..synth import qwen_rope_index
-        tok_id = self.base_model.config.image_token_id if tok_id is None else tok_id
-        grids = [] if grid is None else [tuple(int(v) for v in g3) for g3 in (grid.tolist() if torch.is_tensor(grid) else grid)]
-        pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), tok_id, grids)
+        as_grids = lambda g: [] if g is None else [tuple(int(v) for v in g3) for g3 in (g.tolist() if torch.is_tensor(g) else g)]
+        sec = None
+        if second_per_grid_ts is not None:
+            sec = [float(v) for v in (second_per_grid_ts.tolist() if torch.is_tensor(second_per_grid_ts) else second_per_grid_ts)]
+        cfg = self.base_model.cfg
+        pos3, rope_delta = qwen_rope_index(input_ids[0].cpu().numpy(), self.base_model.config.image_token_id, as_grids(grid),
+                                           video_token_id=cfg.video_token_id if cfg.video_token_id >= 0 else None,
+                                           video_grids=as_grids(video_grid), second_per_grid_ts=sec, tokens_per_second=cfg.tokens_per_second)
         self.base_model.rope_deltas = torch.tensor([[rope_delta]], device=input_ids.device)
         return torch.from_numpy(pos3), int(rope_delta)
 

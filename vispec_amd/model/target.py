@@ -82,7 +82,8 @@ class TargetLM:
             architectures=list(cfg.architectures), num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
             num_key_value_heads=cfg.num_kv_heads, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
             vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
-            image_token_index=cfg.image_token_index, image_token_id=cfg.image_token_index, eos_token_id=cfg.eos_token_id,
+            image_token_index=cfg.image_token_index, image_token_id=cfg.image_token_index, video_token_id=cfg.video_token_id,
+            eos_token_id=cfg.eos_token_id,
             vision_feature_layer=-2, vision_feature_select_strategy="default")
         self.lm_head = _Head(weights.lm_head)
         self.vision = vision or SyntheticVision(cfg.hidden_size)

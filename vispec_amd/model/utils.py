@@ -48,13 +48,14 @@ def reset_past_key_values(passed_key_values):  # utils.py:341-358
 
 def initialize_tree(input_ids, model, past_key_values, logits_processor, inputs_embeds=None, embed_weights=None,
                     image_mask=None, **kwargs):
-    """utils.py:266-327: target prefill -> first token -> first topK_genrate.  For Qwen2.5-VL pass `image_grid_thw` (the processor
-    output the reference hands to its prefill as a kwarg): the multimodal rotary positions and rope_deltas are built from it as in
+    """utils.py:266-327: target prefill -> first token -> first topK_genrate.  For Qwen2.5-VL pass `image_grid_thw` / `video_grid_thw` /
+    `second_per_grid_ts` (the processor outputs the reference hands to its prefill as kwargs): the multimodal rotary positions and rope_deltas are built from it as in
     SpecModel.specgenerate."""
     sampling = _enable(model, logits_processor)
     position_ids, rope_delta = None, 0
     if model.base_model.config.architectures[0] == "Qwen2_5_VLForConditionalGeneration":
-        pos3, rope_delta = model._qwen_rope(input_ids, kwargs.get("image_grid_thw"))
+        pos3, rope_delta = model._qwen_rope(input_ids, kwargs.get("image_grid_thw"), video_grid=kwargs.get("video_grid_thw"),
+                                            second_per_grid_ts=kwargs.get("second_per_grid_ts"))
         position_ids = pos3[:, None, :]
     outputs, orig, hidden_states = model(input_ids, past_key_values=past_key_values, output_orig=True, inputs_embeds=inputs_embeds,
                                          position_ids=position_ids)

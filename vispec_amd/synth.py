@@ -139,22 +139,36 @@ TINY = dict(D=256, H=2, I=704, V=1008, NL=2, max_pos=512)
 QWEN_TINY = dict(D=512, H=4, Hkv=2, I=704, V=1024, NL=2, max_pos=512, mrope_section=(16, 24, 24), theta=1e6, eps=1e-6)
 
 
-def qwen_rope_index(input_ids: np.ndarray, image_token_id: int, grids, spatial_merge: int = 2):
-    """3-component (t, h, w) position ids [3, L] and rope_delta for a prompt with image runs — the image branch of HF's
-    Qwen2_5_VLForConditionalGeneration.get_rope_index (called by the reference's prefill, modeling_qwen2_5_vl_kv.py forward):
-    text tokens advance all three components together; an image run of grid (t, h, w) gets t-index 0.., h-index, w-index over
-    its (h/merge)x(w/merge) tokens, offset by the running text position; the next text token continues from max+1.
-    grids: list of (t, h, w) in patches, one per image run, in order."""
+def qwen_rope_index(input_ids: np.ndarray, image_token_id: int, grids, spatial_merge: int = 2, video_token_id: int | None = None,
+                    video_grids=(), second_per_grid_ts=None, tokens_per_second: float = 2.0):
+    """3-component (t, h, w) position ids [3, L] and rope_delta of a Qwen2.5-VL prompt — HF's / the reference's
+    Qwen2_5_VLForConditionalGeneration.get_rope_index (modeling_qwen2_5_vl_kv.py:1789-1975, called by the reference's prefill):
+    text tokens advance all three components together; a vision run of grid (t, h, w) covers t * (h/merge) * (w/merge) tokens with
+    h-index, w-index over the merged grid and temporal index  floor(frame * second_per_grid_t * tokens_per_second)  — 0 for every
+    frame of an IMAGE (second_per_grid_t = 0 there, :1899), second_per_grid_ts[v] (default 1.0, :1909-1912) for VIDEO v — all offset
+    by the running position; the next text token continues from max + 1 (:1926-1930).
+    grids / video_grids: (t, h, w) in patches, one per image / video run, in prompt order."""
     L = input_ids.shape[0]
     pos = np.zeros((3, L), np.int64)
-    i, st, gi = 0, 0, 0
+    i, st, gi, vi = 0, 0, 0, 0
     while i < L:
-        if input_ids[i] == image_token_id:
-            t, h, w = grids[gi]
-            gi += 1
+        tok = input_ids[i]
+        is_img = tok == image_token_id
+        is_vid = video_token_id is not None and tok == video_token_id
+        if is_img or is_vid:
+            if is_img:
+                t, h, w = grids[gi]
+                gi += 1
+                sec = 0.0
+            else:
+                t, h, w = video_grids[vi]
+                sec = 1.0 if second_per_grid_ts is None else float(second_per_grid_ts[vi])
+                vi += 1
             lh, lw = h // spatial_merge, w // spatial_merge
             n = t * lh * lw
-            tt = np.repeat(np.arange(t), lh * lw)
+            # float32 like torch (arange(int64) * python float / fp32 tensor element -> float32 tensor, then .long() truncates)
+            frame_t = (np.arange(t, dtype=np.float32) * np.float32(sec) * np.float32(tokens_per_second)).astype(np.int64)
+            tt = np.repeat(frame_t, lh * lw)
             hh = np.tile(np.repeat(np.arange(lh), lw), t)
             ww = np.tile(np.arange(lw), t * lh)
             pos[:, i : i + n] = np.stack([tt, hh, ww]) + st

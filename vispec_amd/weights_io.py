@@ -40,6 +40,7 @@ def load_target_dir(path):
         rs = tc.get("rope_scaling") or tc.get("rope_parameters") or cfg.get("rope_scaling") or {}
         kw = dict(qkv_bias=True, attn_impl="sdpa", mrope_section=tuple(rs.get("mrope_section", (16, 24, 24))),
                   image_token_index=cfg.get("image_token_id", 151655), video_token_id=cfg.get("video_token_id", 151656),
+                  tokens_per_second=float((cfg.get("vision_config") or {}).get("tokens_per_second", 2)),
                   max_position_embeddings=4096)  # kv_cache.py:88-119 sizes Qwen's cache at 4096 rows
         rope_theta = tc.get("rope_theta") or rs.get("rope_theta") or 1e6
     else:
