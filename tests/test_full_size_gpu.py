@@ -94,3 +94,77 @@ def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
     for (toks, new_token, idx, acc), w in zip(got, want):
         assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3])
     del mb
+
+
+def test_full_width_two_layer_model_against_the_oracle_floats():
+    """FLOAT parity at the real LLaVA-7B WIDTH (D = 4096, H = 32, hd = 128, I = 11008, V = 32064) on a 2-layer target + its draft — the
+    sizes at which the numpy oracle still answers in seconds: (1) the PyTorch-ROCm prefill (hipBLASLt GEMMs, flash SDPA where the
+    reference is eager fp32-softmax, HIP element-wise steps) against the oracle's eager prefill: final hidden rows, last-row logits and
+    the K/V rows it wrote; (2) the draft prefill with image-token compression: last hidden row; (3) the verify forward of the first
+    30-node tree (all skinny GEMMs at their real K, tree attention at real head_dim): hidden and logits; (4) integer logic exact.
+    Tolerances: 2^-5 of the tensor's largest magnitude (bf16 with different accumulation orders over K = 4096 / 11008), written below."""
+    from helpers import synth
+    from vispec_amd.engine import DraftConfig, TargetConfig
+    from vispec_amd.model import SpecModel
+    from test_loop_gpu import check_tree_exact
+    D, H, I, V, NL, MAXP = 4096, 32, 11008, 32064, 2, 1024
+    IMG = 32000
+    tw = synth.make_target_weights(D, H, I, V, NL, seed=300)
+    dw = synth.make_draft_weights(D, H, I, V, seed=301, target_embed=tw["model.embed_tokens.weight"])
+    tcfg = TargetConfig(hidden_size=D, num_heads=H, num_kv_heads=H, intermediate_size=I, vocab_size=V, num_layers=NL, max_position_embeddings=MAXP,
+                        image_token_index=IMG)
+    dcfg = DraftConfig(hidden_size=D, num_heads=H, intermediate_size=I, vocab_size=V, max_position_embeddings=MAXP)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw)
+    ot = vo.TargetLlama(vo.TargetConfig(D, H, H, I, V, NL, MAXP), tw, bf16=True)
+    od = vo.DraftModel(vo.DraftConfig(D, H, I, V, MAXP), dw, bf16=True)
+    eng = sm.engine
+    rng = np.random.default_rng(302)
+    n_pre, n_img, n_post = 24, 150, 40
+    ids = np.concatenate([rng.integers(3, IMG, n_pre), np.full(n_img, IMG), rng.integers(3, IMG, n_post)])
+    L = len(ids)
+    feats = synth.bf16_grid(rng.standard_normal((n_img, D), dtype=np.float32) * 0.05)
+    hidden, demb, mask_np, first = sm._start_request(torch.from_numpy(ids)[None], None,
+                                                     dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda()), max_new_tokens=64)
+    # ---- (1) target prefill
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[ids == IMG] = feats
+    pkv, pkv_data, cur = vo.initialize_past_key_values(NL, H, MAXP, D // H)
+    lg, hid = ot.forward(pkv, inputs_embeds=emb)
+    tol = lambda want: 2.0 ** -5 * float(np.abs(want).max())
+    got_h = hidden.float().cpu().numpy()
+    np.testing.assert_allclose(got_h, hid, rtol=0, atol=tol(hid))
+    kvd = eng.target_kv.float().cpu().numpy()  # [2*NL, 1, H, max_pos, hd]
+    want_kv = pkv_data[0][:, 0, :, :L]
+    np.testing.assert_allclose(kvd[:, 0, :, :L], want_kv, rtol=0, atol=tol(want_kv))
+    first_tok = int(first.cpu()[0])
+    top2 = np.sort(lg[-1])[-2:]
+    if top2[1] - top2[0] > tol(lg[-1]):  # the first token is unambiguous at the test's tolerance
+        assert first_tok == int(np.argmax(lg[-1]))
+    # ---- (2) draft prefill on the DEVICE's hidden states (only the draft's arithmetic is compared)
+    e_np = demb.float().cpu().numpy()
+    e_shift = np.concatenate([e_np[1:], od.ops.rd(od.w["embed_tokens.weight"][[first_tok]])], 0)
+    od.reset_kv()
+    out_c, kv, _ = od.forward_prefill(got_h, e_shift, mask_np.astype(bool))
+    dlast = eng.buffer("draft_last", (16, D))[:1].float().cpu().numpy()
+    np.testing.assert_allclose(dlast, out_c[-1:], rtol=0, atol=tol(out_c[-1:]))
+    assert eng.state()["draft_len"] >= L - n_img + (eng.num_q - 1)
+    tok, pos, tmask, ret = check_tree_exact(eng)
+    # ---- (3) verify forward of the first tree, oracle on ITS OWN prefill KV (two independent computations of the same model)
+    eng.target_forward()
+    Tn = len(tok)
+    got_logits = eng.buffer("logits", (64, V))[:Tn].float().cpu().numpy()
+    got_hidden = eng.buffer("hidden_new", (64, D))[:Tn].float().cpu().numpy()
+    ot.tree_mask = tmask
+    want_logits, want_hidden = ot.forward(pkv, input_ids=tok, position_ids=pos + L)
+    np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=tol(want_hidden))
+    np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=tol(want_logits))
+    rel = np.abs(got_logits - want_logits) / np.abs(want_logits).max()
+    print(f"full-width verify logits: mean rel err {rel.mean():.2e}, max {rel.max():.2e}; prefill hidden max err "
+          f"{np.abs(got_h - hid).max() / np.abs(hid).max():.2e} of scale")
+    assert rel.mean() <= 3e-3
+    # ---- (4) accept on the device's logits == the oracle's evaluate_posterior on the same numbers
+    cand = np.concatenate([tok, [-1]])[ret]
+    best, a, _ = vo.evaluate_posterior_greedy(got_logits[ret], cand)
+    eng.accept()
+    st = eng.state()
+    assert (st["accept_len"], st["n_ctx"]) == (a, L + a + 1)
