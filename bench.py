@@ -264,6 +264,7 @@ def self_launch(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")  # what torch.distributed.run sets for nproc > 1: N ranks x lanes must not each spin up a 256-thread pool
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [pr.wait() for pr in procs]
@@ -359,6 +360,7 @@ def main():
         def f():
             tok = rnd = 0
             accs = []
+            t_lane = time.time()
             torch.cuda.set_device(device)  # HIP's current device is per host thread; a new thread starts on device 0
             with torch.cuda.stream(streams[lane]):
                 for s_ in range(lo, hi):
@@ -383,6 +385,8 @@ def main():
                             rnd += idx + 1
                             accs += acc
                 streams[lane].synchronize()
+            if os.environ.get("VISPEC_BENCH_DEBUG"):
+                log(f"[rank {rank} lane {lane}] steps {lo}..{hi}: {time.time() - t_lane:.2f} s, {tok} tokens, {rnd} rounds")
             return tok, rnd, accs
         return f
 
