@@ -248,6 +248,43 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
                         f"de-fusing of the weights {t_copy:.0f}s (not timed)"))
 
 
+def cpu_config0_leg(sm, tcfg, rounds=8, ar_steps=3, budget_s=40.0):
+    """BASELINE.json configs[0] — "the reference's own CPU-runnable case" (SURVEY.md §8d cfg 1): one LLaVA-1.5-7B-shaped request END TO
+    END on the host cores, target prefill included: L = 576 image + 32 + 35 text tokens, LLaVA-1.5 semantics (the draft sees token ids, no
+    image-token compression: SURVEY.md fact 0.7), the oracle on its PyTorch-CPU back end with the weight pair the GPU benchmark uses
+    (LLaVA-1.5-7B and v1.6-vicuna-7B share every dimension).  Opt-in (--cpu-config0): ~1 minute of host time.  Checker-side code only."""
+    from oracle import torch_cpu as tc
+    from oracle import vispec_oracle as vo
+    cores = min(CPU_THREADS, os.cpu_count())
+    torch.set_num_threads(cores)
+    eng = sm.engine
+    ot = vo.TargetLlama(vo.TargetConfig(tcfg.hidden_size, tcfg.num_heads, tcfg.num_kv_heads, tcfg.intermediate_size, tcfg.vocab_size, tcfg.num_layers,
+                                        tcfg.max_position_embeddings, rms_norm_eps=tcfg.rms_norm_eps, rope_theta=tcfg.rope_theta,
+                                        attn_impl=tcfg.attn_impl, mrope_section=tcfg.mrope_section), tc.split_fused_target(eng.tw, tcfg))
+    dcfg = eng.dcfg
+    od = vo.DraftModel(vo.DraftConfig(dcfg.hidden_size, dcfg.num_heads, dcfg.intermediate_size, dcfg.vocab_size, max(eng.kv_max_pos, eng.draft_max_pos),
+                                      rms_norm_eps=dcfg.rms_norm_eps, rope_theta=dcfg.rope_theta, num_q=eng.num_q, total_token=eng.total_token,
+                                      depth=eng.depth, top_k=eng.top_k), tc.split_fused_draft(eng.dw))
+    ot.ops, od.ops = tc.TorchOps(), tc.TorchOps()
+    n_pre, n_img, n_post = 35, 576, 32
+    from vispec_amd import synth
+    ids, emb, mask = synth.make_request(tcfg.vocab_size, tcfg.hidden_size, n_pre, n_img, n_post, seed=9000, image_token_id=tcfg.image_token_index,
+                                        embed=ot.w["model.embed_tokens.weight"])
+    L = len(ids)
+    r = tc.timed_request(ot, od, ids, emb, None, rounds=rounds, ar_steps=ar_steps, max_pos=L + 64 * (rounds + 2), budget_s=budget_s,
+                         draft_sees_embeds=False)
+    n_rounds = len(r["verify_s"])
+    new_tok = int(sum(a + 1 for a in r["accept_lengths"]))
+    t_dec = sum(r["verify_s"]) + sum(r["draft_s"])
+    wall = r["prefill_s"] + r["draft_prefill_s"] + t_dec
+    t_ar = float(np.mean(r["ar_s"]))
+    return dict(workload=f"LLaVA-1.5-7B-shaped request, L={L} (576 image + 67 text tokens), no image-token compression, whole request on {cores} host threads",
+                prefill_s=round(r["prefill_s"], 2), draft_prefill_s=round(r["draft_prefill_s"], 2), rounds=n_rounds, new_tokens=new_tok,
+                seconds_per_round=round(t_dec / n_rounds, 3), tau_measured=round(float(np.mean(r["accept_lengths"])), 3),
+                tokens_per_s_decode=round(new_tok / t_dec, 3), tokens_per_s_end_to_end=round(new_tok / wall, 3),
+                ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar_decode=round(new_tok / t_dec * t_ar, 3), cores=cores)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on 127.0.0.1) —
     the same environment `python -m torch.distributed.run --nproc-per-node N` would set.  Rank 0's stdout carries the JSON line."""
@@ -277,6 +314,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-config0", action="store_true", help="also run BASELINE configs[0] (LLaVA-1.5-7B shape, L=643) end to end on the host cores (~1 min)")
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
@@ -535,6 +573,11 @@ def main():
                 extra["cpu_baseline"] = cpu_baseline_leg(sm, tcfg, get_req(plan[0][W][0]))
             except Exception as e:  # never lose the GPU line to the CPU leg
                 extra["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(e).__name__}: {e}"[:300])
+            if args.cpu_config0 and MODEL == "llava7b":
+                try:
+                    extra["cpu_baseline"]["config0_end_to_end"] = cpu_config0_leg(sm, tcfg)
+                except Exception as e:
+                    extra["cpu_baseline"]["config0_end_to_end"] = f"failed: {type(e).__name__}: {e}"[:300]
         per_step = (f"{args.requests} independent requests sharded round-robin over the {world} replica(s) and their lanes" if args.requests
                     else f"{CO} request{'s' if CO > 1 else ''} on each of {R} concurrent lanes per GPU")
         if CO == 2:

@@ -136,10 +136,12 @@ def split_fused_draft(dw) -> Dict[str, np.ndarray]:
 
 
 def timed_request(target: "vo.TargetLlama", draft: "vo.DraftModel", input_ids, inputs_embeds, image_mask, rounds: int, ar_steps: int,
-                  max_pos: int, position_ids=None, rope_delta: int = 0, prefilled=None, budget_s: float = 1e9):
+                  max_pos: int, position_ids=None, rope_delta: int = 0, prefilled=None, budget_s: float = 1e9, draft_sees_embeds: bool = True):
     """One request of the bench workload on the host cores: SpecModel.specgenerate's call sequence (spec_model_ours.py:247-547) for
     `rounds` greedy draft-and-verify rounds, then `ar_steps` plain AR steps (gen_baseline_answer_coco_caption.py:111-129) continuing from
     the same context.  -> dict of wall times and the measured accept lengths.
+    draft_sees_embeds=False is LLaVA-1.5: the target consumes the merged embeddings while the draft embeds the ids with
+    its own table and never compresses (no image mask).
     prefilled = (kv [2*layers, H_kv, L, hd], hidden [L, D], last_logits [V]): the target prefill was done elsewhere (bench.py hands over
     the GPU's: a 2704-token prefill is 36 TFLOP, minutes on host cores, and not what the steady-state rate measures) — the cache is
     seeded with it (KVCache.cat semantics) and the timed part starts at the draft prefill.  budget_s bounds the round loop (>= 2 rounds)."""
@@ -164,7 +166,8 @@ def timed_request(target: "vo.TargetLlama", draft: "vo.DraftModel", input_ids, i
     t_prefill = tick() - t0
     token = vo.argmax_first(logits[-1])
     t0 = tick()
-    dt, ri, tm, tp = draft.topK_genrate(hidden, np.concatenate([input_ids, [token]]), target.lm_head, inputs_embeds=inputs_embeds, image_mask=image_mask)
+    dt, ri, tm, tp = draft.topK_genrate(hidden, np.concatenate([input_ids, [token]]), target.lm_head,
+                                        inputs_embeds=inputs_embeds if draft_sees_embeds else None, image_mask=image_mask if draft_sees_embeds else None)
     t_draft_prefill = tick() - t0
     st = vo.LoopState(input_ids, dt, ri, tm, tp)
     t_verify, t_draft = [], []
