@@ -227,14 +227,16 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   constexpr int XTILE = UNROLL * XS_STEP;  // one staged group of one activation tile; per wave: [2 buffers][MT tiles]
   constexpr int XBUFS = gemm_w32_xbufs<MT, NT>();  // same-wave LDS traffic is processed in issue order: one buffer is enough for correctness
   unsigned char* xs = smem_g + wave * (MT * XBUFS * XTILE);
-  const bf16_t* sx[MT][NINST];
+  // one running base pointer + 32-bit per-row element offsets (8 address registers less than a pointer per row at MT = 2)
+  const bf16_t* xbase = X + (size_t)w_lo * KSTEP + seg * 8;
+  unsigned xo[MT][NINST];
   int woff[NINST];
 #pragma unroll
   for (int i = 0; i < NINST; ++i) {
     const int row = srow0 + i * RPI;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)  // rows >= M read row 0, never stored
-      sx[mt][i] = X + (size_t)(row_ok(32 * mt + row) ? 32 * mt + row : 0) * ldx + (size_t)w_lo * KSTEP + seg * 8;
+      xo[mt][i] = (unsigned)(row_ok(32 * mt + row) ? 32 * mt + row : 0) * (unsigned)ldx;
     woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
   const int roff = hi * XS_HALF + j * 16;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < NINST; ++i) g.x[mt][i] = *reinterpret_cast<const uint4*>(sx[mt][i]);
+        for (int i = 0; i < NINST; ++i) g.x[mt][i] = *reinterpret_cast<const uint4*>(xbase + xo[mt][i]);
     }
 #pragma unroll
     for (int u = 0; u < LOADS; ++u) {
@@ -257,10 +259,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     }
     pa0 += 64 * LOADS;
     pa1 += 64 * LOADS;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int i = 0; i < NINST; ++i) sx[mt][i] += 16 * UNROLL;
+    xbase += 16 * UNROLL;
   };
   auto compute = [&](const Regs& g, int buf) {
     unsigned char* xb = xs + (XBUFS == 2 ? buf : 0) * (MT * XTILE);

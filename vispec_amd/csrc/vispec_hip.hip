@@ -313,9 +313,10 @@ static size_t packed_elems(int N, int K) { return (size_t)((N + 31) / 32) * 32 *
 // tuning / A-B switch (VISPEC_MT2_SINGLE_BLOCK=1): two-tile GEMMs with one row block per workgroup, the round-2a form
 static const bool g_mt2_single_block = getenv("VISPEC_MT2_SINGLE_BLOCK") && atoi(getenv("VISPEC_MT2_SINGLE_BLOCK")) != 0;
 
-// fp8 tiles keep one row block per workgroup in the two-tile form: the paired instantiation needs 256 VGPRs + 76 B of scratch
+// fp8 tiles too: the paired instantiation needs 256 VGPRs + 76 B of scratch per lane and still wins clearly — with half-size weights the
+// activation re-read is FOUR times the weight bytes in the single-block form (Qwen2.5-VL-7B fp8, 4 lanes x cohort 2: 1155 -> 1465 tok/s)
 #ifndef VISPEC_W8_PAIR
-#define VISPEC_W8_PAIR 0
+#define VISPEC_W8_PAIR 1
 #endif
 static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
   if (K % 16) return fail("pack: K %% 16");
@@ -534,9 +535,8 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
                      (const float*)wscale, re, m_tile)
   if (Mk <= 32) { if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
-  else if (wscale) VISPEC_QKV(true, 2, 1);
-  else if (g_mt2_single_block) VISPEC_QKV(false, 2, 1);
-  else VISPEC_QKV(false, 2, 2);  // N %% 128 == 0: the tile count is even
+  else if (g_mt2_single_block || (wscale && !VISPEC_W8_PAIR)) { if (wscale) VISPEC_QKV(true, 2, 1); else VISPEC_QKV(false, 2, 1); }
+  else { if (wscale) VISPEC_QKV(true, 2, 2); else VISPEC_QKV(false, 2, 2); }  // N %% 128 == 0: the tile count is even
 #undef VISPEC_QKV
   KCHK();
   prof_end(s);
