@@ -30,7 +30,7 @@ for M in [int(m) for m in os.environ.get("MS", "30,8").split(",")]:
         Y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         res = []
         for v in variants:
-            if v // 10000 != 7 and ((v % 10000) // 100) * (64 if M > 32 else 32) * N > 8 * 64 * 16384:
+            if v // 10000 != 7 and ((v % 10000) // 100) * (128 if M > 64 else 64 if M > 32 else 32) * N > 8 * 64 * 16384:
                 continue
             for w in Ws[:2]:
                 L.check(lib.vispec_gemm_skinny_tune(eng.h, v, st(), p(X), K + PAD, p(w), p(Y), N, M, N, K))

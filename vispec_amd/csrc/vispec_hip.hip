@@ -704,6 +704,13 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
+  if (M > 64) {  // 8xxxx: FOUR activation tiles, one row block per workgroup (what a cohort of four would run) — measurement only
+    if (dbg != 7 || M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: M > 64 needs variant 8xxxx, M <= 128 and a partial workspace of S*128*N");
+    hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, false, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 4>()), s, x, ldx, w, 0,
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+    KCHK();
+    return 0;
+  }
   if (M > 32) {  // two activation tiles (the cohort / wide-tree instantiation): S x 4 waves x UNROLL 4 only
     if (M > 64 || (size_t)S * 64 * N > ctx->gemm_part_elems) return fail("tune: bad M / split for two tiles");
 #define V2(DBG_)                                                                                                                   \
