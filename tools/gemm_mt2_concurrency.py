@@ -24,7 +24,7 @@ def layer(si, it, code):
     s = C.c_void_p(streams[si].cuda_stream)
     for n, N, K, S in SHAPES:
         L.check(lib.vispec_gemm_skinny_tune(engs[si].h, code * 10000 + S * 100, s, p(X[K]), K, p(W[n][(it * NS + si) % NB]), p(Y), N, M, N, K))
-for code, name in (((8, "MT=4 NT=1"),) if M > 64 else ((1, "NT=1"), (5, "NT=2"))):
+for code, name in (((8, "MT=4 NT=1"),) if M > 64 else ((1, "NT=1"), (5, "NT=2"), (6, "NT=2, half the activation loads (upper bound)"))):
     for ns in (1, 2, 3, 4):
         for it in range(3):
             for si in range(ns): layer(si, it, code)

@@ -189,7 +189,7 @@ constexpr int gemm_w32_lds_bytes() {
                                                                                            : (NW * NT * MT * 4096);
 }
 
-template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue
+template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
 __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES : 2) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   auto load = [&](Regs& g) {  // all loads unconditional plain global loads; X first (it is consumed first, through LDS)
     if (DBG != 1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < (DBG == 3 ? 1 : MT); ++mt)
 #pragma unroll
         for (int i = 0; i < NINST; ++i) g.x[mt][i] = *reinterpret_cast<const uint4*>(xbase + xo[mt][i]);
     }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     unsigned char* xb = xs + (XBUFS == 2 ? buf : 0) * (MT * XTILE);
     if (DBG != 1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < (DBG == 3 ? 1 : MT); ++mt)
 #pragma unroll
         for (int i = 0; i < NINST; ++i) *reinterpret_cast<uint4*>(xb + mt * XTILE + woff[i]) = g.x[mt][i];
     }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const uint4 bv = (DBG == 1) ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
-                                      : *reinterpret_cast<const uint4*>(xb + mt * XTILE + u * XS_STEP + roff);
+                                      : *reinterpret_cast<const uint4*>(xb + (DBG == 3 ? 0 : mt) * XTILE + u * XS_STEP + roff);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t][mt], 0, 0, 0);

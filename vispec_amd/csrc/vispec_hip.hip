@@ -716,7 +716,10 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #define V2(DBG_)                                                                                                                   \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, DBG_, false, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 2>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
-    if (dbg == 4) {  // 5xxxx: two row blocks per workgroup (NT = 2) sharing every staged activation group: half the L2 -> CU activation traffic
+    if (dbg == 5) {  // 6xxxx: the paired form with only HALF of the activations loaded (wrong results; what halving that traffic again would buy)
+      hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 3, false, 2>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s, x,
+                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+    } else if (dbg == 4) {  // 5xxxx: two row blocks per workgroup (NT = 2) sharing every staged activation group: half the L2 -> CU activation traffic
       if (tiles & 1) return fail("tune: NT=2 needs an even tile count");
       hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 0, false, 2>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s, x,
                          ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
