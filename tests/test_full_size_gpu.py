@@ -96,6 +96,34 @@ def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
     del mb
 
 
+def test_ragged_cohort_at_full_size(model_full):
+    """A cohort whose two requests have nothing in common: the bench request (thousands of context rows, image compression) next to a
+    SHORT text-only prompt — attention key splits sized for the long one run mostly empty for the short one, the draft caches differ by
+    an order of magnitude, and the short request gets a smaller token budget so that it finishes (and freezes on the device) long before
+    its partner.  Each must still produce exactly what it produces alone."""
+    import bench
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    sm, tcfg, name = model_full
+    if name not in ("llava7b", "qwen7b"):
+        pytest.skip("one LLaVA and one Qwen configuration are enough for this property")
+    bench.MODEL = name
+    dev = torch.device("cuda:0")
+    long_req = bench.make_request(tcfg, 11, dev)
+    rng = np.random.default_rng(12)
+    short_ids = torch.from_numpy(rng.integers(3, min(tcfg.image_token_index, 30000), size=(1, 211))).to(dev)
+    want_long = sm.specgenerate(long_req[0], max_new_tokens=80, log=True, return_acceptance_len=True, **long_req[1])
+    want_short = sm.specgenerate(short_ids, max_new_tokens=24, log=True, return_acceptance_len=True)
+    mb = sm.make_cohort_member()
+    for order in (0, 1):  # the short request as member, then as leader
+        reqs = [long_req, (short_ids, {})] if order == 0 else [(short_ids, {}), long_req]
+        budgets = [80, 24] if order == 0 else [24, 80]
+        got = specgenerate_cohort([sm, mb], reqs, max_new_tokens=budgets)
+        wants = [want_long, want_short] if order == 0 else [want_short, want_long]
+        for (toks, new_token, idx, acc), w in zip(got, wants):
+            assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3])
+    del mb
+
+
 def test_full_width_two_layer_model_against_the_oracle_floats():
     """FLOAT parity at the real LLaVA-7B WIDTH (D = 4096, H = 32, hd = 128, I = 11008, V = 32064) on a 2-layer target + its draft — the
     sizes at which the numpy oracle still answers in seconds: (1) the PyTorch-ROCm prefill (hipBLASLt GEMMs, flash SDPA where the

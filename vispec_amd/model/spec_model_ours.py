@@ -432,7 +432,7 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     """Two independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
 
     models   = [leader, member]  (member built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
-    requests = [(input_ids [1,L], specgenerate kwargs), (input_ids, kwargs)]
+    requests = [(input_ids [1,L], specgenerate kwargs), (input_ids, kwargs)]; max_new_tokens may be a pair (one budget per request)
     Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — exactly what
     `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` returns for that request alone, token for token: the prefills run
     per request, every decode round launches each GEMM once on both requests' rows (Engine.cohort_round), and a request that finishes
@@ -443,8 +443,9 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     if memb.engine.leader is not lead.engine:
         raise ValueError("models[1] must have been built with cohort_leader=models[0]")
     seeds = seeds or [0, 0]
-    for m, (ids, kw), sd in zip(models, requests, seeds):
-        m._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=sd, max_new_tokens=max_new_tokens, is_llama3=is_llama3)
+    budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens, max_new_tokens]  # per request
+    for m, (ids, kw), sd, mx in zip(models, requests, seeds, budgets):
+        m._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=sd, max_new_tokens=mx, is_llama3=is_llama3)
     rounds_cap = max_length - lead.spec_layer.total_tokens - 10  # :270
     alive = [True, True]
     final = [m.engine.state() for m in models]
@@ -458,7 +459,7 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
             st = m.engine.state()
             final[t], idxs[t] = st, idx
             accs[t].append(int(st["accept_len"]))
-            if (st["done"] & 1) or st["new_token"] > max_new_tokens or (st["done"] & 4):  # :544 / :546 / KV full
+            if (st["done"] & 1) or st["new_token"] > budgets[t] or (st["done"] & 4):  # :544 / :546 / KV full
                 if st["done"] & 4 and not (st["done"] & 3):
                     import warnings
                     warnings.warn(f"cohort request {t} stopped after {st['new_token']} new tokens: the next round would not fit a KV cache",
