@@ -90,19 +90,27 @@ def split_fused_target(tw, tcfg) -> Dict[str, np.ndarray]:
     """vispec_amd.engine.TargetWeights (device, fused q|k|v and gate|up rows) -> the reference's state-dict names, fp32 on the host."""
     f = lambda t: t.detach().to("cpu", torch.float32).numpy()
     hd = tcfg.head_dim
+
+    def fw(lw, k):  # fp8 target weights: `k` holds the e4m3 codes, `k_scale` their per-row factors -> the de-quantised matrix
+        w = f(lw[k])
+        return w if lw.get(k + "_scale") is None else w * f(lw[k + "_scale"])[:, None]
+
     nq, nk = tcfg.num_heads * hd, tcfg.num_kv_heads * hd
     I = tcfg.intermediate_size
-    sd = {"model.embed_tokens.weight": f(tw.embed), "model.norm.weight": f(tw.norm), "lm_head.weight": f(tw.lm_head)}
+    head = f(tw.lm_head)
+    if getattr(tw, "lm_head_scale", None) is not None:
+        head = head * f(tw.lm_head_scale)[:, None]
+    sd = {"model.embed_tokens.weight": f(tw.embed), "model.norm.weight": f(tw.norm), "lm_head.weight": head}
     for i, lw in enumerate(tw.layers):
         p = f"model.layers.{i}."
-        wqkv, wgu = f(lw["wqkv"]), f(lw["wgu"])
+        wqkv, wgu = fw(lw, "wqkv"), fw(lw, "wgu")
         sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = wqkv[:nq], wqkv[nq:nq + nk], wqkv[nq + nk:]
         if lw.get("bqkv") is not None:
             b = f(lw["bqkv"])
             sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"] = b[:nq], b[nq:nq + nk], b[nq + nk:]
-        sd[p + "self_attn.o_proj.weight"] = f(lw["wo"])
+        sd[p + "self_attn.o_proj.weight"] = fw(lw, "wo")
         sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = wgu[:I], wgu[I:]
-        sd[p + "mlp.down_proj.weight"] = f(lw["wdown"])
+        sd[p + "mlp.down_proj.weight"] = fw(lw, "wdown")
         sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = f(lw["ln1"]), f(lw["ln2"])
     return sd
 

@@ -389,8 +389,8 @@ def build_qwen_fp8():
 
 def test_fp8_target_weights_loop_matches_oracle():
     """BASELINE config 5 shape of model: Qwen2.5-VL-like target with fp8 (e4m3, per-output-channel) weights in every streamed
-    GEMM incl. lm_head; bf16 draft.  Oracle = same quantised model (numpy e4m3).  The product prefill runs on the dequantised
-    bf16 weights (torch), so KV differs from the oracle's at the rounding level; the structured pair keeps tokens identical."""
+    GEMM incl. lm_head; bf16 draft.  Oracle = same quantised model (numpy e4m3); the product prefill (torch GEMMs) multiplies by the same
+    codes and scales on an fp32 accumulator (test_fp8_prefill_computes_with_codes_and_scales_like_the_decode_gemms)."""
     sm, ot, od, IMG = build_qwen_fp8()
     Q = synth.QWEN_TINY
     rng = np.random.default_rng(19)
@@ -411,6 +411,39 @@ def test_fp8_target_weights_loop_matches_oracle():
                               image_grid_thw=torch.tensor(grids), max_new_tokens=20)
     n = min(ar.shape[1], len(o_out))
     np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])
+
+
+def test_fp8_prefill_computes_with_codes_and_scales_like_the_decode_gemms():
+    """fp8 target weights: the PyTorch prefill multiplies by the e4m3 CODES (exact in bf16) on an fp32 accumulator and applies the
+    per-output-channel scale before the one bf16 rounding — the W8A16 arithmetic of the decode kernels and of the oracle's quantised
+    model — not by weights rounded a second time when de-quantised.  Prefill hidden rows, K/V rows and last-row logits vs the oracle."""
+    sm, ot, od, IMG = build_qwen_fp8()
+    Q = synth.QWEN_TINY
+    rng = np.random.default_rng(29)
+    grids = [(1, 6, 8)]
+    ids = np.concatenate([rng.integers(3, IMG, 7), np.full(12, IMG), rng.integers(3, IMG, 9)])
+    mask = ids == IMG
+    feats = synth.bf16_grid(rng.standard_normal((12, Q["D"]), dtype=np.float32) * 0.05)
+    hidden, demb, mask_np, first = sm._start_request(torch.from_numpy(ids)[None], None,
+                                                     dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(), image_grid_thw=torch.tensor(grids)),
+                                                     max_new_tokens=16)
+    pos3, delta = synth.qwen_rope_index(ids, IMG, grids)
+    emb = ot.w["model.embed_tokens.weight"][ids].copy()
+    emb[mask] = feats
+    pkv, pkv_data, cur = vo.initialize_past_key_values(Q["NL"], Q["Hkv"], Q["max_pos"], Q["D"] // Q["H"])
+    lg, hid = ot.forward(pkv, inputs_embeds=emb, position_ids=pos3)
+    L_ = len(ids)
+    got_h = hidden.float().cpu().numpy()
+    np.testing.assert_allclose(got_h, hid, rtol=0, atol=2.0 ** -6 * np.abs(hid).max())
+    kvd = sm.engine.target_kv.float().cpu().numpy()
+    want_kv = pkv_data[0][:, 0, :, :L_]
+    np.testing.assert_allclose(kvd[:, 0, :, :L_], want_kv, rtol=0, atol=2.0 ** -6 * np.abs(want_kv).max())
+    # most entries are bit-equal (same products, same single rounding; only the accumulation order differs)
+    assert np.mean(kvd[:, 0, :, :L_] == want_kv) > 0.8
+    assert int(first.cpu()[0]) == int(np.argmax(lg[-1]))
+    # the API-parity handle base_model.lm_head applies the scales too
+    h_last = hidden[-1:].contiguous()
+    np.testing.assert_allclose(sm.base_model.lm_head(h_last).float().cpu().numpy()[0], lg[-1], rtol=0, atol=2.0 ** -6 * np.abs(lg[-1]).max())
 
 
 @pytest.mark.parametrize("temperature,seed", [(1.0, 0), (0.7, 3), (6.0, 11)])

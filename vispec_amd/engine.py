@@ -139,6 +139,7 @@ class TargetWeights:
     def __init__(self, cfg: TargetConfig, device):
         self.cfg, self.device = cfg, device
         self.embed = self.norm = self.lm_head = None
+        self.lm_head_scale = None  # fp8 target weights: lm_head then holds the e4m3 codes (as bf16) and this their per-row scales
         self.layers = []  # dicts: wqkv, bqkv, wo, wgu, wdown, ln1, ln2
 
     @classmethod
@@ -261,8 +262,10 @@ class Engine:
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
         self.target_weight_dtype = target_weight_dtype
         if target_weight_dtype == "fp8":
-            # BASELINE config 5: fp8 (e4m3, per-output-channel scales) target weights.  The row-major bf16 copies that the
-            # PyTorch prefill uses are replaced by the DEQUANTISED weights so prefill and decode see the same model.
+            # BASELINE config 5: fp8 (e4m3, per-output-channel scales) target weights.  The row-major copies that the PyTorch prefill
+            # uses become the e4m3 CODES held in bf16 (exact) next to their scales (`<name>_scale`): the prefill then computes
+            # bf16( (x . codes) * scale + bias ) with an fp32 accumulator — the arithmetic of the W8A16 decode GEMMs — instead of
+            # multiplying by weights that were rounded once more when de-quantised to bf16.
             if not hasattr(tw, "packed8"):
                 tw.packed8, tw.scales8, tw.codes8 = [], [], []  # codes8: row-major e4m3 codes (kept for inspection / tests)
                 for lw in tw.layers:
@@ -271,13 +274,14 @@ class Engine:
                         q, s_ = quantize_fp8(lw[k])
                         qp = qkv_rope_order(q, tcfg.num_heads + tcfg.num_kv_heads) if k == "wqkv" else (swiglu_order(q) if k == "wgu" else q)
                         pk[k], sc[k], cd[k] = pack_weight_fp8(qp), s_, q
-                        lw[k] = (q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16)
+                        lw[k], lw[k + "_scale"] = q.view(torch.float8_e4m3fn).to(torch.bfloat16), s_
                     tw.packed8.append(pk)
                     tw.scales8.append(sc)
                     tw.codes8.append(cd)
                 q, s_ = quantize_fp8(tw.lm_head)
                 tw.p_lm_head8, tw.s_lm_head8, tw.c_lm_head8 = pack_weight_fp8(q), s_, q
-                tw.lm_head.copy_((q.view(torch.float8_e4m3fn).float() * s_[:, None]).to(torch.bfloat16))
+                tw.lm_head.copy_(q.view(torch.float8_e4m3fn).to(torch.bfloat16))
+                tw.lm_head_scale = s_
         elif target_weight_dtype != "bf16":
             raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
         if target_weight_dtype == "bf16" and not hasattr(tw, "packed"):

@@ -50,14 +50,30 @@ def _sdpa_try(q, k, v, gqa):
             return F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=gqa)
 
 
+def scaled_linear(x, w, b=None, scale=None):
+    """nn.Linear on a row-major weight.  scale != None: `w` holds fp8 (e4m3) codes as bf16 and `scale` their per-output-channel factors —
+    bf16( (x . w^T) * scale + b ) on an fp32 accumulator, the rounding points of the library's W8A16 GEMMs (kernels.h epilogues)."""
+    if scale is None:
+        return F.linear(x, w, b)
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch.mm(x2, w.t(), out_dtype=torch.float32) * scale
+    if b is not None:
+        y = y + b.float()
+    return y.to(x.dtype).reshape(*x.shape[:-1], w.shape[0])
+
+
 class _Head:
     """stand-in for nn.Linear lm_head: the reference passes `base_model.lm_head` into topK_genrate (utils.py:300)."""
 
-    def __init__(self, weight):
-        self.weight = weight
+    def __init__(self, weights):
+        self._w = weights  # the Engine may quantise the head in place after this object exists: read weight / scale at call time
+
+    @property
+    def weight(self):
+        return self._w.lm_head
 
     def __call__(self, x):
-        return F.linear(x, self.weight)
+        return scaled_linear(x, self._w.lm_head, None, getattr(self._w, "lm_head_scale", None))
 
 
 class SyntheticVision:
@@ -85,7 +101,7 @@ class TargetLM:
             image_token_index=cfg.image_token_index, image_token_id=cfg.image_token_index, video_token_id=cfg.video_token_id,
             eos_token_id=cfg.eos_token_id,
             vision_feature_layer=-2, vision_feature_select_strategy="default")
-        self.lm_head = _Head(weights.lm_head)
+        self.lm_head = _Head(weights)
         self.vision = vision or SyntheticVision(cfg.hidden_size)
         self.engine: Optional[Engine] = None  # attached by SpecModel
         self.tree_mask = None  # reference stores it on base_model.model (spec_model_ours.py:486-489); kept for API parity
@@ -163,19 +179,19 @@ class TargetLM:
 
         for i, lw in enumerate(self.w.layers):
             h = rmsnorm(x, lw["ln1"])
-            qkv = F.linear(h, lw["wqkv"], lw["bqkv"])  # [L, QKV]
+            qkv = scaled_linear(h, lw["wqkv"], lw["bqkv"], lw.get("wqkv_scale"))  # [L, QKV]
             # rotary at position m (bf16 rounding points of the reference) on q in place; k (rotated) and v -> cache rows [0, L)
             L.check(lib.vispec_rope_append(eng.h, st, p(qkv), Ln, H, Hk, hd, p(cos), p(sin), None, None, p(kv[2 * i]), p(kv[2 * i + 1]), S, None))
             q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
             a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0]
-            x = x + F.linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"])
+            x = x + scaled_linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"], None, lw.get("wo_scale"))
             h = rmsnorm(x, lw["ln2"])
-            gu = F.linear(h, lw["wgu"])
+            gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
             L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
-            x = x + F.linear(act, lw["wdown"])
+            x = x + scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))
         hidden = rmsnorm(x, self.w.norm)
-        logits = F.linear(hidden if all_logits else hidden[-1:], self.w.lm_head).float()
+        logits = scaled_linear(hidden if all_logits else hidden[-1:], self.w.lm_head, None, getattr(self.w, "lm_head_scale", None)).float()
         return logits, hidden.contiguous()
 
     def eval(self):
