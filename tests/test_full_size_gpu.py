@@ -124,6 +124,48 @@ def test_ragged_cohort_at_full_size(model_full):
     del mb
 
 
+def test_default_bench_configuration_reproduces_single_request_tokens():
+    """The configuration bench.py's headline line runs — 4 concurrent lanes (host threads + streams, one weight copy) x cohorts of 2 at
+    the LLaVA-7B sizes — against the same 16 requests run ONE AT A TIME on one stream: every request's tokens, round count and accept
+    lengths must be identical (concurrency and weight-pass sharing change throughput, never a token)."""
+    import gc
+    import bench
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    bench.MODEL = "llava7b"
+    dev = torch.device("cuda:0")
+    R, STEPS, NEW = 4, 2, 72
+    pairs, tcfg, _ = bench.build_models(dev, 0, 0, 1, R, 2)
+    reqs = {i: bench.make_request(tcfg, 100 + i, dev) for i in range(2 * R * STEPS)}
+    streams = [torch.cuda.Stream(dev) for _ in range(R)]
+    torch.cuda.synchronize()
+
+    def lane(l):
+        def f():
+            torch.cuda.set_device(dev)
+            out = {}
+            with torch.cuda.stream(streams[l]):
+                for s_ in range(STEPS):
+                    ia, ib = (s_ * R + l) * 2, (s_ * R + l) * 2 + 1
+                    got = specgenerate_cohort(pairs[l], [reqs[ia], reqs[ib]], max_new_tokens=NEW, seeds=[ia, ib])
+                    out[ia], out[ib] = got
+                streams[l].synchronize()
+            return out
+        return f
+
+    res = {}
+    for d in bench.run_lanes([lane(l) for l in range(R)]):
+        res.update(d)
+    sm = pairs[0][0]
+    for i, (ids, pix) in reqs.items():
+        w = sm.specgenerate(ids, max_new_tokens=NEW, log=True, return_acceptance_len=True, **pix)
+        toks, new_token, idx, acc = res[i]
+        assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3]), f"request {i}"
+    assert sum(r[1] for r in res.values()) >= len(reqs) * NEW
+    del pairs, sm
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_full_width_two_layer_model_against_the_oracle_floats():
     """FLOAT parity at the real LLaVA-7B WIDTH (D = 4096, H = 32, hd = 128, I = 11008, V = 32064) on a 2-layer target + its draft — the
     sizes at which the numpy oracle still answers in seconds: (1) the PyTorch-ROCm prefill (hipBLASLt GEMMs, flash SDPA where the
