@@ -280,7 +280,8 @@ def test_argmax_rows_first_max_wins(lib):
     assert out[3].item() == 100 and out[4].item() == V - 1 and out[5].item() == 0
 
 
-@pytest.mark.parametrize("M,V,k", [(1, 32064, 8), (8, 1008, 8), (8, 152064, 8), (3, 1008, 16)])
+@pytest.mark.parametrize("M,V,k", [(1, 32064, 8), (8, 1008, 8), (8, 152064, 8), (3, 1008, 16),
+                                   (3, 1003, 8), (3, 200000, 8)])  # the last two take the multi-pass form (V % 8 != 0; V > 163 840)
 def test_logsoftmax_topk(lib, engine, M, V, k):
     rng = np.random.default_rng(V + M)
     o = vo.Ops(True)
