@@ -171,7 +171,9 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 // 33.8 KB of LDS and 152 VGPRs instead of 67.6 KB / 181 -> three workgroups per CU instead of two (1030 -> 1048 tok/s for one cohort
 // lane).  What the second tile really costs is the activation traffic itself: tools/gemm_bench.py (MS=30,60, variants 10100 / 20100)
 // — gate|up 37.4 us at M = 30, 49.3 us at M = 60, 38.4 us at M = 60 WITHOUT the activation loads: every one of the 688 workgroups
-// re-reads the whole 64 x 4096 block from L2 (360 MB per launch, ~33 TB/s: the L2's own limit).
+// re-reads the whole 64 x 4096 block from L2 (360 MB per launch, ~33 TB/s: the L2's own limit).  The library therefore launches the
+// two-tile GEMMs in the PAIRED form (NT = 2: two row blocks per workgroup, each staged activation fragment feeds both — 238 VGPRs,
+// 2 waves per SIMD); the single-block two-tile form above remains for odd tile counts and for the A/B switch VISPEC_MT2_SINGLE_BLOCK.
 #ifndef VISPEC_MT2_LDSBUF
 #define VISPEC_MT2_LDSBUF 1
 #endif
