@@ -184,7 +184,10 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #define VISPEC_MT2NT2_LDSBUF 1
 #endif
 template <int MT, int NT = 1>
-constexpr int gemm_w32_xbufs() { return MT == 2 ? (NT == 2 ? VISPEC_MT2NT2_LDSBUF : VISPEC_MT2_LDSBUF) : (MT > 2 ? 1 : 2); }
+#ifndef VISPEC_MT1_LDSBUF
+#define VISPEC_MT1_LDSBUF 2
+#endif
+constexpr int gemm_w32_xbufs() { return MT == 2 ? (NT == 2 ? VISPEC_MT2NT2_LDSBUF : VISPEC_MT2_LDSBUF) : (MT > 2 ? 1 : VISPEC_MT1_LDSBUF); }
 template <int NT, int UNROLL, int NW, int MT = 1>
 constexpr int gemm_w32_lds_bytes() {
   return (NW * MT * gemm_w32_xbufs<MT, NT>() * UNROLL * XS_STEP) > (NW * NT * MT * 4096) ? (NW * MT * gemm_w32_xbufs<MT, NT>() * UNROLL * XS_STEP)
