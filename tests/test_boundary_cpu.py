@@ -104,3 +104,26 @@ def test_weights_io_reads_hf_and_vispec_checkpoint_dirs(tmp_path):
         np.testing.assert_array_equal(sd[k].float().numpy(), tw[k])
     dcfg, dsd = weights_io.load_draft_dir(str(ddir), tcfg)
     assert set(dsd) == set(dw) and dcfg.hidden_size == T["D"]
+
+
+def test_bench_byte_model_reproduces_the_surveys_figures():
+    """bench.py prices a round with SURVEY.md §8(d)'s formula; the figures the survey prints for the BASELINE models are reproduced
+    (B_target 13.215 GB, draft layer 0.539 GB, lm_head 0.263 GB, KV 524 288 B per context row, 18.03 GB per round at n = 2960 / n_c = 820
+    for LLaVA-7B; 25.7 GB target for 13B; 14.14 GB / 7.07 GB target and a 1.09 GB lm_head for Qwen2.5-VL-7B bf16 / fp8)."""
+    import bench
+    from vispec_amd.engine import LLAVA_16_7B, LLAVA_16_13B, QWEN25_VL_7B, TargetConfig
+    t7, t13, tq = TargetConfig(**LLAVA_16_7B), TargetConfig(**LLAVA_16_13B), TargetConfig(**QWEN25_VL_7B)
+    ar0 = bench.algorithmic_bytes_per_ar_step(t7, 0)
+    assert ar0 == 2 * 6_607_339_520                                                   # B_target, exact
+    assert bench.algorithmic_bytes_per_ar_step(t7, 1) - ar0 == 524_288                # KV_t per context row
+    r0 = bench.algorithmic_bytes_per_round(t7, 0, 0)
+    per_pass = (r0 - ar0) / 4                                                         # (1 + d) = 4 draft passes: layer + lm_head
+    assert abs(per_pass - (0.539e9 + 0.263e9)) < 2e6
+    assert bench.algorithmic_bytes_per_round(t7, 0, 1) - r0 == 4 * 16_384             # KV_d per compressed row, 4 passes
+    assert abs(bench.algorithmic_bytes_per_round(t7, 2960, 820) / 1e9 - 18.03) < 0.01
+    assert abs(bench.algorithmic_bytes_per_ar_step(t13, 0) / 1e9 - 25.7) < 0.05
+    assert abs(bench.algorithmic_bytes_per_ar_step(tq, 0) / 1e9 - 14.14) < 0.01
+    assert abs(bench.algorithmic_bytes_per_ar_step(tq, 0, fp8=True) / 1e9 - 7.07) < 0.01
+    assert bench.algorithmic_bytes_per_ar_step(tq, 1) - bench.algorithmic_bytes_per_ar_step(tq, 0) == 57_344
+    lm = 2 * tq.vocab_size * tq.hidden_size
+    assert abs(lm / 1e9 - 1.09) < 0.005
