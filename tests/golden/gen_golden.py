@@ -561,6 +561,40 @@ def g15_qwen_rope_index():
     np.savez_compressed(os.path.join(OUT, "g15_qwen_rope_index.npz"), **out)
 
 
+def g16_multi_image_repaired():
+    """MULTI-IMAGE draft prefill.  The reference as published cannot run it: the scatter matrix of Model.forward takes its row counts from
+    the FIRST run's blocks (`h_s[0]`, `h_s[1]`, cnets_ours.py:939-940) and crashes on the second image.  The rows it
+    meant are the current run's (`h_s[-2]`, `h_s[-1]`): the reference's own forward is re-compiled here with exactly those two index
+    expressions replaced — nothing else — and run on prompts with two and three image runs (one of them touching the end of the prompt).
+    Fixtures from this function are REFERENCE-INTENT (repaired), parity unpinned upstream.  Stored: inputs, the compressed K/V, real_len,
+    the last global feature g and the output row topK_genrate consumes (out[:, -1])."""
+    import inspect
+    import textwrap
+    src = textwrap.dedent(inspect.getsource(cnets_ours.Model.forward))
+    a, b = "eye_m[img_id_start : img_id_start + h_s[0].shape[0], :]", "eye_m[img_id_end - h_s[1].shape[0] : img_id_end, :]"
+    assert src.count(a) == 1 and src.count(b) == 1, "the reference's scatter-matrix lines moved: re-derive the repair"
+    src = src.replace(a, a.replace("h_s[0]", "h_s[-2]")).replace(b, b.replace("h_s[1]", "h_s[-1]"))
+    ns = {}
+    exec(compile(src, "<repaired Model.forward>", "exec"), vars(cnets_ours), ns)
+    repaired = ns["forward"]
+    out = {}
+    cases = {"two": (2, [(4, 13), (6, 9)], 7), "three_q3": (3, [(3, 8), (2, 11), (5, 6)], 4), "image_last": (2, [(5, 10), (4, 12)], 0)}
+    for tag, (q, runs, n_tail) in cases.items():
+        m, _ = build_draft(num_q=q, seed=16)
+        rng = np.random.default_rng(1600 + q + len(runs) + n_tail)
+        mask = np.concatenate([np.concatenate([np.zeros(nt, bool), np.ones(ni, bool)]) for nt, ni in runs] + [np.zeros(n_tail, bool)])[None]
+        L = mask.shape[1]
+        hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
+        embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+        o, kv = repaired(m, t(hidden), inputs_embeds=t(embeds), use_cache=True, image_mask=torch.from_numpy(mask))
+        out[f"{tag}_hidden"], out[f"{tag}_embeds"], out[f"{tag}_mask"], out[f"{tag}_q"] = hidden[0], embeds[0], mask[0], np.int64(q)
+        out[f"{tag}_out_last"] = f32(o)[0, -1]
+        out[f"{tag}_k"], out[f"{tag}_v"] = f32(kv[0][0])[0], f32(kv[0][1])[0]
+        out[f"{tag}_real_len"] = np.int64(int(kv[0][2]))
+        out[f"{tag}_g"] = f32(m.last_img_hidden)
+    np.savez_compressed(os.path.join(OUT, "g16_multi_image_repaired.npz"), **out)
+
+
 def g11_update_inference_inputs():
     """utils.update_inference_inputs in isolation (SURVEY §8c "G7"): accepted ids appended, KV rows gathered from the tree
     slots into [n, n+a+1) of EVERY cache tensor, lengths, the hidden rows handed to the draft, next token — greedy and
@@ -653,9 +687,9 @@ def g12_kvcache():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     fns = dict(g14=g14_tree_levels, g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index, g16=g16_multi_image_repaired)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

@@ -375,3 +375,20 @@ def test_g15_qwen_rope_index_images_and_videos(golden_dir):
                                            tokens_per_second=float(g[f"c{ci}_tps"]))
         np.testing.assert_array_equal(pos, g[f"c{ci}_pos"], err_msg=f"case {ci}")
         assert delta == int(g[f"c{ci}_delta"]), ci
+
+
+@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last"])
+def test_g16_multi_image_prefill_against_the_repaired_reference(golden_dir, tag):
+    """MULTI-IMAGE draft prefill (BASELINE config 2: Qwen2.5-VL multi-turn with several images).  The published reference crashes on the
+    second image run; the fixture comes from the reference's own Model.forward with the two scatter-matrix index
+    expressions repaired (`h_s[0]`/`h_s[1]` -> `h_s[-2]`/`h_s[-1]`, tests/golden/gen_golden.py g16): REFERENCE-INTENT, parity unpinned
+    upstream.  The oracle's compression — every run compressed to q-1 tokens on its last image positions, the global feature g carried
+    from run to run into the text rows that follow — must reproduce its compressed K/V, real_len, final g and the consumed output row."""
+    g = load(golden_dir, "g16_multi_image_repaired.npz")
+    d, _ = oracle_draft(num_q=int(g[f"{tag}_q"]), seed=16)
+    out, kv, pos = d.forward_prefill(g[f"{tag}_hidden"], g[f"{tag}_embeds"], g[f"{tag}_mask"])
+    close(kv[0], g[f"{tag}_k"])
+    close(kv[1], g[f"{tag}_v"])
+    assert kv[2] == int(g[f"{tag}_real_len"])
+    close(d.last_img_hidden, g[f"{tag}_g"])
+    close(out[-1], g[f"{tag}_out_last"])
