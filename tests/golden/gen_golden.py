@@ -580,12 +580,15 @@ def g16_multi_image_repaired():
     out = {}
     cases = {"two": (2, [(4, 13), (6, 9)], 7), "three_q3": (3, [(3, 8), (2, 11), (5, 6)], 4), "image_last": (2, [(5, 10), (4, 12)], 0)}
     for tag, (q, runs, n_tail) in cases.items():
-        m, _ = build_draft(num_q=q, seed=16)
+        m, w16 = build_draft(num_q=q, seed=16)
         rng = np.random.default_rng(1600 + q + len(runs) + n_tail)
         mask = np.concatenate([np.concatenate([np.zeros(nt, bool), np.ones(ni, bool)]) for nt, ni in runs] + [np.zeros(n_tail, bool)])[None]
         L = mask.shape[1]
         hidden = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32))
         embeds = synth.bf16_grid(rng.standard_normal((1, L, T["D"]), dtype=np.float32) * 0.05)
+        first_tok = int(rng.integers(3, T["V"] - 1))
+        embeds[0, -1] = w16["embed_tokens.weight"][first_tok]  # topK_genrate's last shifted row is the draft's embedding of the sampled token (:1081-1082)
+        out[f"{tag}_first_tok"] = np.int64(first_tok)
         o, kv = repaired(m, t(hidden), inputs_embeds=t(embeds), use_cache=True, image_mask=torch.from_numpy(mask))
         out[f"{tag}_hidden"], out[f"{tag}_embeds"], out[f"{tag}_mask"], out[f"{tag}_q"] = hidden[0], embeds[0], mask[0], np.int64(q)
         out[f"{tag}_out_last"] = f32(o)[0, -1]

@@ -129,6 +129,36 @@ def test_draft_prefill_stage(num_q, n_pre, n_img, n_post):
     assert tok[0] == ids[L]
 
 
+@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last"])
+def test_multi_image_draft_prefill_against_the_repaired_reference_fixture(golden_dir, tag):
+    """The HIP draft prefill on MULTI-IMAGE prompts, compared DIRECTLY with fixture G16 — the reference's own Model.forward with its two
+    scatter-matrix indices repaired (reference-intent; the published code crashes on a second image run): compressed
+    K/V of every run, the final global feature g and the draft length.  The fixture is at the level of Model.forward (embeddings
+    already shifted by one, last row = the draft's embedding of the sampled token); the C-ABI takes the un-shifted rows + that token."""
+    g = np.load(os.path.join(golden_dir, "g16_multi_image_repaired.npz"))
+    q = int(g[f"{tag}_q"])
+    sm, ot, od = build(20, 16, False, arch="LlavaNextForConditionalGeneration", num_q=q)
+    eng = sm.engine
+    hidden, shifted, mask = g[f"{tag}_hidden"], g[f"{tag}_embeds"], g[f"{tag}_mask"]
+    L = hidden.shape[0]
+    unshifted = np.concatenate([np.zeros((1, T["D"]), np.float32), shifted[:-1]], 0)  # row 0 is never read (cnets_ours.py:1081)
+    ids = np.random.default_rng(5).integers(3, IMG_TOK, size=L)
+    eng.begin_request(ids, 64)
+    first = torch.tensor([int(g[f"{tag}_first_tok"])], dtype=torch.int32, device="cuda")
+    eng.draft_prefill(torch.from_numpy(hidden).to(torch.bfloat16).cuda(), torch.from_numpy(unshifted).to(torch.bfloat16).cuda(), mask, first)
+    check_tree_exact(eng)
+    want_k, want_v = g[f"{tag}_k"], g[f"{tag}_v"]  # [H, L_c, hd]
+    Lc = want_k.shape[1]
+    assert eng.state()["draft_len"] == Lc
+    kv = eng.draft_kv.float().cpu().numpy()
+    tol = lambda a, b: np.testing.assert_allclose(a, b, rtol=2.0 ** -6, atol=2.0 ** -6 * np.abs(b).max())
+    tol(kv[0][:, :Lc], want_k)
+    tol(kv[1][:, :Lc], want_v)
+    tol(eng.buffer("draft_g", (1, T["D"])).float().cpu().numpy(), g[f"{tag}_g"])
+    dlast = eng.buffer("draft_last", (16, T["D"]))[:1].float().cpu().numpy()
+    np.testing.assert_allclose(dlast[0], g[f"{tag}_out_last"], rtol=0, atol=2.0 ** -5 * np.abs(g[f"{tag}_out_last"]).max())
+
+
 def test_draft_prefill_stage_on_the_prefill_gemm():
     """Stages of >= 64 rows run on the prefill GEMM (csrc/gemm_prefill.h: 128 x 128 tiles, operand rows gathered / concatenated while
     staged, K|V scatter and rotary+append epilogues) instead of 32-row passes of the skinny kernel.  A draft wide enough for the
