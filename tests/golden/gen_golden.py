@@ -578,7 +578,8 @@ def g16_multi_image_repaired():
     exec(compile(src, "<repaired Model.forward>", "exec"), vars(cnets_ours), ns)
     repaired = ns["forward"]
     out = {}
-    cases = {"two": (2, [(4, 13), (6, 9)], 7), "three_q3": (3, [(3, 8), (2, 11), (5, 6)], 4), "image_last": (2, [(5, 10), (4, 12)], 0)}
+    cases = {"two": (2, [(4, 13), (6, 9)], 7), "three_q3": (3, [(3, 8), (2, 11), (5, 6)], 4), "image_last": (2, [(5, 10), (4, 12)], 0),
+             "one_q5": (5, [(9, 17)], 6)}  # a single run through the same (repaired) code path
     for tag, (q, runs, n_tail) in cases.items():
         m, w16 = build_draft(num_q=q, seed=16)
         rng = np.random.default_rng(1600 + q + len(runs) + n_tail)

@@ -129,7 +129,7 @@ def test_draft_prefill_stage(num_q, n_pre, n_img, n_post):
     assert tok[0] == ids[L]
 
 
-@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last"])
+@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last", "one_q5"])
 def test_multi_image_draft_prefill_against_the_repaired_reference_fixture(golden_dir, tag):
     """The HIP draft prefill on MULTI-IMAGE prompts, compared DIRECTLY with fixture G16 — the reference's own Model.forward with its two
     scatter-matrix indices repaired (reference-intent; the published code crashes on a second image run): compressed

@@ -377,7 +377,7 @@ def test_g15_qwen_rope_index_images_and_videos(golden_dir):
         assert delta == int(g[f"c{ci}_delta"]), ci
 
 
-@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last"])
+@pytest.mark.parametrize("tag", ["two", "three_q3", "image_last", "one_q5"])
 def test_g16_multi_image_prefill_against_the_repaired_reference(golden_dir, tag):
     """MULTI-IMAGE draft prefill (BASELINE config 2: Qwen2.5-VL multi-turn with several images).  The published reference crashes on the
     second image run; the fixture comes from the reference's own Model.forward with the two scatter-matrix index
