@@ -599,6 +599,47 @@ def g16_multi_image_repaired():
     np.savez_compressed(os.path.join(OUT, "g16_multi_image_repaired.npz"), **out)
 
 
+def repaired_forward():
+    """The reference's Model.forward with the two scatter-matrix index expressions of cnets_ours.py:939-940 taken from the CURRENT run
+    (see g16_multi_image_repaired); compiled from the reference's own source at generation time."""
+    import inspect
+    import textwrap
+    src = textwrap.dedent(inspect.getsource(cnets_ours.Model.forward))
+    a, b = "eye_m[img_id_start : img_id_start + h_s[0].shape[0], :]", "eye_m[img_id_end - h_s[1].shape[0] : img_id_end, :]"
+    assert src.count(a) == 1 and src.count(b) == 1, "the reference's scatter-matrix lines moved: re-derive the repair"
+    src = src.replace(a, a.replace("h_s[0]", "h_s[-2]")).replace(b, b.replace("h_s[1]", "h_s[-1]"))
+    ns = {}
+    exec(compile(src, "<repaired Model.forward>", "exec"), vars(cnets_ours), ns)
+    return ns["forward"]
+
+
+def g17_multi_image_loop():
+    """Whole draft-and-verify loop on a MULTI-IMAGE prompt (three image runs, structured pair, the loop body of g8's image case) with the
+    repaired draft forward installed for the duration: token stream + accept lengths.  REFERENCE-INTENT (the published code crashes on the
+    second image run), parity unpinned upstream."""
+    base, tw = build_target(seed=70, structured=True)
+    draft, _ = build_draft(seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    sm = build_spec(base, draft)
+    rng = np.random.default_rng(1700)
+    E = tw["model.embed_tokens.weight"]
+    ids, mask = [], []
+    for n_txt, n_img in ((4, 14), (3, 22), (6, 9)):
+        ids += rng.integers(3, T["V"] - 1, size=n_txt).tolist() + [T["V"] - 1] * n_img
+        mask += [False] * n_txt + [True] * n_img
+    ids += rng.integers(3, T["V"] - 1, size=7).tolist()
+    mask += [False] * 7
+    ids, mask = np.array(ids, np.int64), np.array(mask)
+    emb = E[ids].copy()
+    emb[mask] = synth.bf16_grid(rng.standard_normal((int(mask.sum()), T["D"]), dtype=np.float32) * 0.05)
+    orig = cnets_ours.Model.forward
+    cnets_ours.Model.forward = repaired_forward()
+    try:
+        o, acc = image_loop(sm, ids, emb, mask, max_new_tokens=30)
+    finally:
+        cnets_ours.Model.forward = orig
+    np.savez_compressed(os.path.join(OUT, "g17_multi_image_loop.npz"), ids=ids, emb=emb, mask=mask, out=o, acc=np.array(acc))
+
+
 def g11_update_inference_inputs():
     """utils.update_inference_inputs in isolation (SURVEY §8c "G7"): accepted ids appended, KV rows gathered from the tree
     slots into [n, n+a+1) of EVERY cache tensor, lengths, the hidden rows handed to the draft, next token — greedy and
@@ -691,9 +732,9 @@ def g12_kvcache():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     fns = dict(g14=g14_tree_levels, g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index, g16=g16_multi_image_repaired)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index, g16=g16_multi_image_repaired, g17=g17_multi_image_loop)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

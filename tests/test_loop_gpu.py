@@ -298,6 +298,23 @@ def test_multi_image_prompt_matches_oracle():
     assert st["draft_len"] == st["n_ctx"] - int(mask.sum()) + len(segs) * (sm.engine.num_q - 1)
 
 
+def test_multi_image_loop_matches_the_repaired_reference_fixture(golden_dir):
+    """Fixture g17: the reference's loop body on a prompt with THREE image runs, its draft forward repaired (reference-intent, see
+    tests/golden/gen_golden.py): the HIP loop's token stream and accept lengths are the reference's, bit for bit."""
+    g = np.load(os.path.join(golden_dir, "g17_multi_image_loop.npz"))
+    sm, ot, od = build(70, 71, True, arch="LlavaNextForConditionalGeneration")
+    ids, emb, mask = g["ids"].copy(), g["emb"], g["mask"]
+    feats = torch.from_numpy(emb[mask]).to(torch.bfloat16)
+    out, new_token, idx, acc = sm.specgenerate(torch.from_numpy(ids)[None], pixel_values=feats.cuda(), max_new_tokens=30, log=True,
+                                               return_acceptance_len=True)
+    out = out[0].cpu().numpy()
+    L = len(ids)
+    np.testing.assert_array_equal(out[L:], g["out"][L:])
+    np.testing.assert_array_equal(acc, g["acc"])
+    st = sm.engine.state()
+    assert st["draft_len"] == st["n_ctx"] - int(mask.sum()) + 3 * (sm.engine.num_q - 1)
+
+
 def test_llava15_semantics_no_compression(golden_dir):
     """BASELINE config 0 semantics (LLaVA-1.5): image features reach the target, the draft never compresses."""
     sm, ot, od = build(70, 71, True, arch="LlavaForConditionalGeneration")

@@ -392,3 +392,15 @@ def test_g16_multi_image_prefill_against_the_repaired_reference(golden_dir, tag)
     assert kv[2] == int(g[f"{tag}_real_len"])
     close(d.last_img_hidden, g[f"{tag}_g"])
     close(out[-1], g[f"{tag}_out_last"])
+
+
+def test_g17_whole_loop_on_a_multi_image_prompt(golden_dir):
+    """Three image runs through the whole draft-and-verify loop: token stream and per-round accept lengths of the reference's loop body
+    with its draft forward repaired (fixture g17, reference-intent: the published code crashes on the second run)."""
+    g = load(golden_dir, "g17_multi_image_loop.npz")
+    t, tw = oracle_target(seed=70, structured=True)
+    d, _ = oracle_draft(seed=71, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    out, new_token, idx, acc = vo.specgenerate(t, d, g["ids"], inputs_embeds=g["emb"], image_mask=g["mask"], max_new_tokens=30, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(out, g["out"])
+    np.testing.assert_array_equal(acc, g["acc"])
+    assert max(acc) == 4 and d.stable_kv[0].shape[1] < len(out) - 40  # three runs compressed to q-1 rows each
