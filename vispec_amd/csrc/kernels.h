@@ -1249,6 +1249,158 @@ __global__ __launch_bounds__(1024) void lstk_row_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- chunked form for LARGE vocabularies (Qwen2.5-VL: V = 152 064): the one-workgroup row kernel above walks 300 KB per row on ONE CU
+// (62-73 us per call); here a row is cut into C chunks of <= 32 768 logits, each handled by its own 1024-thread workgroup with the row
+// kernel's in-register technique, in three short launches: per-chunk (max, sum-exp) -> per-chunk top-k keys under the GLOBAL lse (the
+// key is the ROUNDED log-prob, so the lse must be known before anything can be ranked) -> merge of the C*k survivors.
+template <int NV>
+__device__ __forceinline__ void lstk2_load(const bf16_t* x, int lo, int hi, uint4 (&raw)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e0 = lo + (i * 1024 + (int)threadIdx.x) * 8;
+    raw[i] = e0 < hi ? *reinterpret_cast<const uint4*>(x + e0) : make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);  // -inf
+  }
+}
+template <int NV>
+__global__ __launch_bounds__(1024) void lstk2_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, float* __restrict__ stats) {
+  __shared__ float s_red[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, C = gridDim.y, c = blockIdx.y;
+  const int lo = c * chunk, hi = min(V, lo + chunk);  // chunk and V are multiples of 8
+  uint4 raw[NV];
+  lstk2_load<NV>(logits + (size_t)blockIdx.x * ld, lo, hi, raw);
+  float mx = NEG_INF;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, bf2f(e[j]));
+  }
+  mx = wave_max_dpp(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = s_red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_red[w]);
+  __syncthreads();
+  float se = 0.f;
+  if (mx != NEG_INF) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) se += __expf(bf2f(e[j]) - mx);
+    }
+  }
+  se = wave_sum_dpp(se);
+  if (lane == 0) s_red[wave] = se;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += s_red[w];  // fixed order
+    stats[((size_t)blockIdx.x * C + c) * 2 + 0] = mx;
+    stats[((size_t)blockIdx.x * C + c) * 2 + 1] = tot;
+  }
+}
+template <int NV>
+__global__ __launch_bounds__(1024) void lstk2_select_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, int k,
+                                                            const float* __restrict__ stats, unsigned long long* __restrict__ cand) {
+  __shared__ unsigned long long s_lmax[1024];
+  __shared__ unsigned long long s_cand[TOPK_MAX * 8 * NV];
+  __shared__ unsigned long long s_thr;
+  __shared__ int s_n;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, C = gridDim.y, c = blockIdx.y;
+  const int lo = c * chunk, hi = min(V, lo + chunk);
+  uint4 raw[NV];
+  lstk2_load<NV>(logits + (size_t)blockIdx.x * ld, lo, hi, raw);
+  if (tid == 0) s_n = 0;
+  // global lse from the C chunk statistics, the same fixed order in every workgroup of the row
+  const float* st = stats + (size_t)blockIdx.x * C * 2;
+  float mx = NEG_INF;
+  for (int q = 0; q < C; ++q) mx = fmaxf(mx, st[2 * q]);
+  float tot = 0.f;
+  for (int q = 0; q < C; ++q) tot += st[2 * q + 1] * __expf(st[2 * q] - mx);  // an empty chunk contributes 0 * exp(-inf) = 0 * 0
+  const float lse = mx + __logf(tot);
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+    const int e0 = lo + (i * 1024 + tid) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned long long key = (e0 + j < hi) ? lstk_key(rdbf(bf2f(e[j]) - lse), e0 + j) : 0ull;
+      best = key > best ? key : best;
+    }
+  }
+  s_lmax[tid] = best;
+  __syncthreads();
+  if (wave == 0) {  // threshold = k-th largest of the 1024 lane maxima
+    unsigned long long cq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cq[q] = s_lmax[lane + 64 * q];
+    unsigned long long thr = 0ull;
+    for (int sel = 0; sel < k; ++sel) {
+      unsigned long long m = cq[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) m = cq[q] > m ? cq[q] : m;
+      thr = wave_max_u64(m);
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (cq[q] == thr) cq[q] = 0ull;
+    }
+    if (lane == 0) s_thr = thr;
+  }
+  __syncthreads();
+  const unsigned long long thr = s_thr;
+  if (best >= thr && best != 0ull) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[i]);
+      const int e0 = lo + (i * 1024 + tid) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long key = (e0 + j < hi) ? lstk_key(rdbf(bf2f(e[j]) - lse), e0 + j) : 0ull;
+        if (key >= thr && key != 0ull) {
+          const int slot = atomicAdd(&s_n, 1);
+          if (slot < TOPK_MAX * 8 * NV) s_cand[slot] = key;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = min(s_n, TOPK_MAX * 8 * NV);
+    for (int sel = 0; sel < k; ++sel) {
+      unsigned long long m = 0ull;
+      for (int q = lane; q < n; q += 64) {
+        const unsigned long long key = s_cand[q];
+        m = key > m ? key : m;
+      }
+      const unsigned long long w = wave_max_u64(m);
+      for (int q = lane; q < n; q += 64)
+        if (s_cand[q] == w) s_cand[q] = 0ull;
+      if (lane == 0) cand[((size_t)blockIdx.x * C + c) * TOPK_MAX + sel] = w;  // 0 = this chunk has fewer than k elements
+    }
+  }
+}
+__global__ __launch_bounds__(64) void lstk2_merge_kernel(const unsigned long long* __restrict__ cand, int C, int k, int* __restrict__ out_idx,
+                                                         float* __restrict__ out_logp) {
+  __shared__ unsigned long long s_c[64 * TOPK_MAX];
+  const int lane = threadIdx.x, n = C * k;
+  for (int q = lane; q < n; q += 64) s_c[q] = cand[((size_t)blockIdx.x * C + q / k) * TOPK_MAX + q % k];
+  __syncthreads();
+  for (int sel = 0; sel < k; ++sel) {
+    unsigned long long m = 0ull;
+    for (int q = lane; q < n; q += 64) m = s_c[q] > m ? s_c[q] : m;
+    const unsigned long long w = wave_max_u64(m);
+    for (int q = lane; q < n; q += 64)
+      if (s_c[q] == w) s_c[q] = 0ull;
+    if (lane == 0) {
+      out_idx[blockIdx.x * k + sel] = lstk_key_index(w);
+      out_logp[blockIdx.x * k + sel] = lstk_key_value(w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void lstk_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, float* __restrict__ stats) {
   __shared__ float s_red[4];
   const bf16_t* x = logits + (size_t)blockIdx.x * ld;

@@ -58,6 +58,7 @@ struct vispec_ctx {
   float *part_o, *part_ml;
   float *lstk_stats = nullptr, *lstk_cv = nullptr;  // log-softmax/top-k scratch [64 rows][LSTK_CHUNKS]...
   int* lstk_ci = nullptr;
+  unsigned long long* lstk2_cand = nullptr;  // chunked form (large vocabularies): [64 rows][<= 64 chunks][TOPK_MAX] keys; statistics in lstk_stats
   float* gemm_part = nullptr;  // split-K partial sums [S<=8][32][N]
   size_t gemm_part_elems = 0;
   size_t part_cap_tiles = 0;  // number of (q-tile, split) partial tiles that fit
@@ -192,6 +193,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     if (leader) ctx->gemm_part = leader->gemm_part;  // launches of a cohort are stream-ordered: one partial workspace serves both
     else A(gemm_part, ctx->gemm_part_elems);
     A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
+    A(lstk2_cand, 64 * LSTK_CHUNKS * TOPK_MAX);
   }
 #undef A
 #undef AL
@@ -618,7 +620,28 @@ static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int
   if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
   if (M < 1 || M > 64) return fail("logsoftmax_topk: M must be in [1,64]");
   // one launch: a 1024-thread workgroup per row keeps the row in registers (8 * NV logits per thread)
-  if (V % 8 == 0 && ld % 8 == 0 && V <= 1024 * 8 * 20) {
+  static const int row_max_v = getenv("VISPEC_LSTK_ROW_MAX_V") ? atoi(getenv("VISPEC_LSTK_ROW_MAX_V")) : 1024 * 8 * 20;  // experiments
+  // large vocabularies (Qwen2.5-VL's 152 064): a row is cut into chunks of <= 32 768 logits, one workgroup each — three short launches
+  // instead of one workgroup walking 300 KB on a single CU (tools/lstk_bench.py: 62-73 us -> see DESIGN.md)
+  static const int chunk_min_v = getenv("VISPEC_LSTK_CHUNK_MIN_V") ? atoi(getenv("VISPEC_LSTK_CHUNK_MIN_V")) : 65536;
+  if (ctx && V % 8 == 0 && ld % 8 == 0 && V > chunk_min_v && V <= 32768 * LSTK_CHUNKS) {
+    int C = (V + 32767) / 32768;
+    if (C < 8) C = 8;
+    const int chunk = ((V / 8 + C - 1) / C) * 8, nv = (chunk / 8 + 1023) / 1024;
+    const bf16_t* lg = (const bf16_t*)logits;
+#define LSTK2(NV_)                                                                                                                 \
+  do {                                                                                                                             \
+    hipLaunchKernelGGL(lstk2_stats_kernel<NV_>, dim3(M, C), dim3(1024), 0, s, lg, ld, V, chunk, ctx->lstk_stats);                  \
+    hipLaunchKernelGGL(lstk2_select_kernel<NV_>, dim3(M, C), dim3(1024), 0, s, lg, ld, V, chunk, k, ctx->lstk_stats, ctx->lstk2_cand); \
+  } while (0)
+    if (nv <= 1) LSTK2(1); else if (nv == 2) LSTK2(2); else if (nv == 3) LSTK2(3); else LSTK2(4);
+#undef LSTK2
+    KCHK();
+    hipLaunchKernelGGL(lstk2_merge_kernel, dim3(M), dim3(64), 0, s, ctx->lstk2_cand, C, k, out_idx, out_logp);
+    KCHK();
+    return 0;
+  }
+  if (V % 8 == 0 && ld % 8 == 0 && V <= 1024 * 8 * 20 && V <= row_max_v) {
     if (V <= 1024 * 8 * 4) hipLaunchKernelGGL(lstk_row_kernel<4>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
     else if (V <= 1024 * 8 * 8) hipLaunchKernelGGL(lstk_row_kernel<8>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
     else hipLaunchKernelGGL(lstk_row_kernel<20>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
