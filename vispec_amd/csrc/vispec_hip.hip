@@ -320,6 +320,11 @@ static const bool g_mt2_single_block = getenv("VISPEC_MT2_SINGLE_BLOCK") && atoi
 #ifndef VISPEC_W8_PAIR
 #define VISPEC_W8_PAIR 1
 #endif
+// fp8 tiles at ONE activation tile: the bf16 activations are already twice the weight bytes there (the ratio the bf16 path only has
+// with two tiles), so the paired form is tried for them as well
+#ifndef VISPEC_W8_PAIR_MT1
+#define VISPEC_W8_PAIR_MT1 1
+#endif
 static int launch_pack(hipStream_t s, const void* W, int N, int K, void* P) {
   if (K % 16) return fail("pack: K %% 16");
   hipLaunchKernelGGL(pack_w32_kernel, dim3(K / 16, (N + 31) / 32), dim3(64), 0, s, (const bf16_t*)W, N, K, (bf16_t*)P);
@@ -378,7 +383,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
 #define VISPEC_GEMM_NT(EPI_, W8_, TILES, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                     \
   do {                                                                                                                  \
     bool done_ = false;                                                                                                 \
-    if constexpr (MT == 2 && (VISPEC_W8_PAIR || !(W8_))) {                                                             \
+    if constexpr ((MT == 2 && (VISPEC_W8_PAIR || !(W8_))) || (MT == 1 && (W8_) && VISPEC_W8_PAIR_MT1)) {               \
       if ((TILES) % 2 == 0 && !g_mt2_single_block) {                                                                    \
         VISPEC_GEMM(2, EPI_, W8_, dim3((TILES) / 2, SPLITS), (TILES) / 2, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE);   \
         done_ = true;                                                                                                   \
@@ -536,7 +541,7 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT_>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
                      (const float*)wscale, re, m_tile)
-  if (Mk <= 32) { if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
+  if (Mk <= 32) { if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV(true, 1, 2); else if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
   else if (g_mt2_single_block || (wscale && !VISPEC_W8_PAIR)) { if (wscale) VISPEC_QKV(true, 2, 1); else VISPEC_QKV(false, 2, 1); }
   else { if (wscale) VISPEC_QKV(true, 2, 2); else VISPEC_QKV(false, 2, 2); }  // N %% 128 == 0: the tile count is even
 #undef VISPEC_QKV
