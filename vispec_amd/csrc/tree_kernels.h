@@ -386,17 +386,28 @@ __device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, in
     for (int r = 0; r < nrem; ++r) rem |= removed[r] == v;
     if (!rem) loc += (double)expf(bf2f(row[v]) / T - m);
   }
-  s_d[tid] = loc;
-  __syncthreads();
-  if (tid == 0) {  // exclusive scan over 1024 partial sums + locate the chunk (sequential: 1024 adds, once per round)
-    double run = 0.0;
-    for (int t = 0; t < 1024; ++t) { const double x = s_d[t]; s_d[t] = run; run += x; }
-    const double target = (double)u * run;
-    int t = 0;
-    while (t + 1 < 1024 && s_d[t + 1] <= target) ++t;
-    s_i[0] = t;
-    s_d[1024] = target;
+  // exclusive scan over the 1024 partial sums + locate the chunk holding the target mass: wave-level shuffles, 16 wave totals through LDS
+  // (the first form did this on one thread: 1024 dependent LDS round trips, ~27 us per draw)
+  double inc = loc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double up = __shfl_up(inc, d, 64);
+    if ((tid & 63) >= d) inc += up;
   }
+  double* s_w = s_d + 1026;  // 16 wave totals (s_d has 1025 + 17 entries, see the callers)
+  if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+  __syncthreads();
+  double off = 0.0, run = 0.0;
+  for (int w = 0; w < 16; ++w) {  // fixed order
+    const double x = s_w[w];
+    if (w < (tid >> 6)) off += x;
+    run += x;
+  }
+  const double target = (double)u * run;
+  s_d[tid] = off + (inc - loc);
+  if (tid == 0) { s_d[1024] = target; s_i[0] = 0; }
+  __syncthreads();
+  if (s_d[tid] <= target && (tid == 1023 || s_d[tid + 1] > target)) s_i[0] = tid;  // the last chunk whose start is <= target: exactly one thread
   __syncthreads();
   const int tsel = s_i[0];
   if (tid == tsel) {
@@ -419,7 +430,7 @@ __device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, in
 __global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restrict__ row, int V, float T, int top_k, unsigned long long seed,
                                                           int* out) {
   __shared__ float s_f[16];
-  __shared__ double s_d[1025];
+  __shared__ double s_d[1025 + 17];
   __shared__ int s_i[2];
   __shared__ int s_hist[258];
   float m, Z;
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   __shared__ int removed[TREE_MAX_T];
   __shared__ int sh[8];  // 0 accept_length, 1 best, 2 adjust, 3 nrem, 4 fi, 5 accepted-this-level
   __shared__ float s_f[16];
-  __shared__ double s_d[1025];
+  __shared__ double s_d[1025 + 17];
   __shared__ int s_i[2];
   __shared__ int s_hist[258];
   const int tid = threadIdx.x;
