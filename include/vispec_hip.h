@@ -74,8 +74,9 @@ const char* vispec_last_error(void);
 int  vispec_version(void);
 
 int  vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out);
-/* Cohort member: a second request context whose 64-row activation workspaces are the second 32-row tiles of `leader`'s, so that the
-   cohort round functions below can launch every GEMM once for both requests (same config as the leader; destroy it before the leader).
+/* Cohort member: another request context whose activation workspaces are one 32-row tile of `leader`'s 128-row workspaces (the first
+   member owns tile 1, the second tile 2, the third tile 3; a fourth is refused), so that the cohort round functions below can launch
+   every GEMM once for all requests (same config as the leader; destroy it before the leader).
    A member is otherwise an ordinary ctx: own round state, tree, KV caches (vispec_set_kv), prefill calls. */
 int  vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out);
 void vispec_ctx_destroy(vispec_ctx* ctx);
@@ -109,6 +110,12 @@ int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const 
    (modeling_llama_kv.py: o_proj -> +residual -> post_attention_layernorm ; down_proj -> +residual -> next input_layernorm) */
 int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
                             const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M, int N, int K);
+/* The GEMM of a cohort round at unit level (tests): n_req = 2..4 requests of m_tile <= 32 rows each; request t's rows are rows
+   32t .. 32t + m_tile - 1 of X / Y / R (which therefore span 32 n_req rows; rows beyond m_tile of a tile are neither read for results
+   nor written).  Same epilogues as vispec_gemm_skinny (0 none, 1 +R, 2 SwiGLU).  Row for row bit-identical to vispec_gemm_skinny on the
+   request's own rows. */
+int vispec_gemm_cohort(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* wscale /* fp8 image: per-row scales, else NULL */,
+                       const void* bias, void* Y, int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue);
 /* tuning hook for tools/gemm_bench.py: explicit decomposition, variant = S*100 + {0:4,1:8 waves}*10 + {0:4,1:8,2:16 unroll} */
 int vispec_gemm_skinny_tune(vispec_ctx*, int variant, void* stream, const void* X, int ldx, const void* W, void* Y, int ldy,
                             int M, int N, int K);
@@ -188,6 +195,12 @@ int vispec_draft_round(vispec_ctx*, void* stream);
    bit.  A request that has finished (done != 0) is frozen on the device while its partner completes.  total_token <= 32. */
 int vispec_cohort_verify_accept(vispec_ctx* leader, vispec_ctx* member, void* stream, int forced_accept);
 int vispec_cohort_draft_round(vispec_ctx* leader, vispec_ctx* member, void* stream);
+/* The same for n = 2..4 requests: ctxs[0] = the leader, the others its members owning activation tiles 1 .. n-1 (any order).  With
+   three or four requests the GEMMs run on csrc/gemm_wide.h's kernel (16 waves = 4 weight row blocks x 4 K-quarters sharing each staged
+   activation group; per-row arithmetic identical to the single-request kernel), attention takes all requests in one partial + one
+   reduce launch.  Same guarantees: every request's tokens are those of the same request alone, bit for bit. */
+int vispec_cohortn_verify_accept(vispec_ctx* const* ctxs, int n, void* stream, int forced_accept);
+int vispec_cohortn_draft_round(vispec_ctx* const* ctxs, int n, void* stream);
 
 /* second stop token of the current request (`is_llama3`: "<|eot_id|>", spec_model_ours.py:268-269,540-542); call after
    vispec_begin_request, which clears it; -1 = none */

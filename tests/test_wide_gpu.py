@@ -1,0 +1,166 @@
+"""Wide cohorts: three or four independent requests share one weight pass (csrc/gemm_wide.h: 16 waves = 4 weight row blocks x 4
+K-quarters sharing each staged activation group).  The bar is the cohort bar of round 2: every request's rows come out BIT-IDENTICAL to
+the single-request kernel's, so a request in a cohort of four produces exactly the tokens it produces alone — and those are the
+oracle's / the reference fixtures'."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from helpers import T, vo  # noqa: E402
+from vispec_amd import lib as L, synth  # noqa: E402
+from vispec_amd.model.spec_model_ours import specgenerate_cohort  # noqa: E402
+
+from test_kernels_gpu import dev, engine, lib, p, packed, stream, tb  # noqa: E402,F401
+from test_loop_gpu import IMG_TOK, build  # noqa: E402
+
+
+# shapes: whole groups only / leftover k-steps (704 = 44 steps: quarters of 11) / split-K with uneven quarters (11008) / a ragged last
+# workgroup (1008 rows = 31.5 tiles; 96 rows = 3 tiles) / one k-step per quarter (K = 64) / the real layer shapes
+@pytest.mark.parametrize("N,K", [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (12288, 4096), (4096, 11008), (64, 64),
+                                 (32064, 512), (22016 // 2, 4096)])
+@pytest.mark.parametrize("n_req,m_tile", [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi):
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    if N * K > 2e7 and (m_tile not in (30,) or epi == 1):
+        pytest.skip("large shapes: the bench configurations only")
+    rng = np.random.default_rng(N + 3 * K + 17 * n_req + m_tile + epi)
+    rows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    X, W, B, R = tb(x), packed(w, swiglu=(epi == 2)), tb(b), tb(r)
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(W), None, p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+    for t in range(n_req):
+        Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
+        Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
+        L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(Xt), K, p(W), p(B), p(Y1), N, p(Rt), N, m_tile, N, K, epi))
+        torch.cuda.synchronize()
+        got, want = Y[32 * t:32 * t + 32].view(torch.int16).cpu().numpy(), Y1.view(torch.int16).cpu().numpy()
+        np.testing.assert_array_equal(got[:m_tile], want[:m_tile], err_msg=f"request {t}")
+        assert (Y[32 * t + m_tile:32 * t + 32].float() == 7.0).all(), "padding rows of a tile must stay untouched"
+
+
+@pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008)])
+@pytest.mark.parametrize("n_req", [3, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, epi):
+    from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    m_tile = 30
+    rng = np.random.default_rng(N + K + n_req + epi)
+    rows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    q_u8, sc = quantize_fp8(tb(w))
+    P8 = pack_weight_fp8(swiglu_order(q_u8) if epi == 2 else q_u8)
+    X, B, R = tb(x), tb(b), tb(r)
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+    for t in range(n_req):
+        Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
+        Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
+        L.check(lib.vispec_gemm_skinny_fp8(engine.h, stream(), p(Xt), K, p(P8), p(sc), p(B), p(Y1), N, p(Rt), N, m_tile, N, K, epi))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(Y[32 * t:32 * t + m_tile].view(torch.int16).cpu().numpy(), Y1[:m_tile].view(torch.int16).cpu().numpy())
+
+
+def single(sm, ids, kw, **gen):
+    return sm.specgenerate(ids, log=True, return_acceptance_len=True, **gen, **kw)
+
+
+@pytest.mark.parametrize("n_req", [3, 4])
+def test_cohort_of_three_and_four_equals_the_single_requests(golden_dir, n_req):
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    members = [sm.make_cohort_member() for _ in range(n_req - 1)]
+    rng = np.random.default_rng(91)
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    n_img = 23
+    ids_img = np.concatenate([rng.integers(3, IMG_TOK, 5), np.full(n_img, IMG_TOK), rng.integers(3, IMG_TOK, 9)])
+    feats = synth.bf16_grid(rng.standard_normal((n_img, T["D"]), dtype=np.float32) * 0.05)
+    reqs = [(torch.from_numpy(g["succ0_ids"])[None], {}),
+            (torch.from_numpy(ids_img)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda())),
+            (torch.from_numpy(g["succ1_ids"])[None], {}),
+            (torch.from_numpy(rng.integers(3, IMG_TOK, 21))[None], {})][:n_req]
+    budgets = [30, 22, 41, 17][:n_req]  # ragged: the requests finish in different rounds and freeze one after the other
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    models = [sm] + members
+    got = specgenerate_cohort(models, reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    # ... and request 0 is the oracle's / the reference fixture's stream
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, g["succ0_ids"], max_new_tokens=30, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(got[0][0][0].cpu().numpy(), o_out)
+    assert got[0][3] == o_acc
+    n = min(len(o_out), len(g["succ0_out"]))
+    np.testing.assert_array_equal(o_out[:n], g["succ0_out"][:n])
+    # a smaller round on the same contexts afterwards (the graph cache is keyed by the member set), then the leader alone
+    got2 = specgenerate_cohort(models[:2], [reqs[1], reqs[0]], max_new_tokens=[budgets[1], budgets[0]])
+    np.testing.assert_array_equal(got2[0][0][0].cpu().numpy(), want[1][0][0].cpu().numpy())
+    np.testing.assert_array_equal(got2[1][0][0].cpu().numpy(), want[0][0][0].cpu().numpy())
+    again = single(sm, *reqs[0], max_new_tokens=budgets[0])
+    np.testing.assert_array_equal(again[0][0].cpu().numpy(), want[0][0][0].cpu().numpy())
+
+
+def test_cohort_of_four_on_a_side_stream_with_sampling_seeds():
+    sm, ot, od = build(50, 60, True)
+    models = [sm] + [sm.make_cohort_member() for _ in range(3)]
+    rng = np.random.default_rng(92)
+    reqs = [(torch.from_numpy(rng.integers(3, T["V"], size=n))[None], {}) for n in (14, 19, 9, 25)]
+    seeds = [3, 5, 7, 11]
+    want = [sm.specgenerate(r[0], temperature=6.0, top_k=8, seed=sd, max_new_tokens=20, log=True, return_acceptance_len=True) for r, sd in zip(reqs, seeds)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = specgenerate_cohort(models, reqs, temperature=6.0, top_k=8, seeds=seeds, max_new_tokens=20)
+        s.synchronize()
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())
+        assert acc == w[3]
+    assert sm.engine.graph_stats()["replays"] > 0
+
+
+def test_member_slots_and_cohort_shape_errors():
+    sm, _, _ = build(50, 60, True)
+    other, _, _ = build(50, 60, True)
+    m1, m2, m3 = (sm.make_cohort_member() for _ in range(3))
+    with pytest.raises(RuntimeError, match="three members"):
+        sm.make_cohort_member()
+    with pytest.raises(RuntimeError, match="member of the first"):
+        other.engine.cohort_round([m1.engine])
+    with pytest.raises(RuntimeError, match="tiles 1 .. n-1"):
+        sm.engine.cohort_round([m3.engine])  # a two-request round needs the member that owns tile 1
+    with pytest.raises(RuntimeError, match="same member twice|tiles 1"):
+        sm.engine.cohort_round([m1.engine, m1.engine])
+    with pytest.raises(RuntimeError, match="total_token <= 32"):
+        sm.engine.set_total_token(40)  # a leader with live members owns one 32-row tile
+
+
+def test_step_api_keeps_stepping_after_done_outside_cohorts():
+    """Round-2 advice: the freeze of a finished request belongs to cohort rounds only.  The single-request entry points (vispec_verify_accept,
+    vispec_accept via utils.update_inference_inputs, vispec_ar_step) keep producing fresh results when a caller with its own stop rule goes
+    on after the library's `done` flags are set (here: the token budget, bit 1)."""
+    sm, _, _ = build(50, 60, True)
+    rng = np.random.default_rng(93)
+    ids = torch.from_numpy(rng.integers(3, T["V"], size=12))[None]
+    eng = sm.engine
+    sm._start_request(ids, None, {}, max_new_tokens=3)
+    seen = []
+    for _ in range(8):
+        eng.verify_accept()
+        eng.draft_round()
+        st = eng.state()
+        seen.append((st["n_ctx"], st["done"], st["rounds"]))
+    assert seen[-1][1] & 2, "the budget flag must be set by now"
+    assert all(b[0] > a[0] and b[2] == a[2] + 1 for a, b in zip(seen, seen[1:])), f"every step must advance the request, done or not: {seen}"

@@ -16,7 +16,7 @@ M = int(os.environ.get("M", "60"))
 SHAPES = [("qkv", 12288, 4096, 1), ("o_proj", 4096, 4096, 4), ("gate_up", 22016, 4096, 1), ("down", 4096, 11008, 4)]
 NB = 6
 W = {n: [pack_weight((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(NB)] for n, N, K, S in SHAPES}
-X = {K: torch.randn(M, K, device=dev, dtype=torch.bfloat16) for K in (4096, 11008)}
+X = {K: torch.randn(max(M, 128), K, device=dev, dtype=torch.bfloat16) for K in (4096, 11008)}  # (the wide kernel reads whole 32-row tiles)
 Y = torch.empty(128, 22016, device=dev, dtype=torch.bfloat16)
 streams = [torch.cuda.Stream(dev) for _ in range(NS)]
 bytes_layer = sum(N * K * 2 for n, N, K, S in SHAPES)
@@ -24,7 +24,7 @@ def layer(si, it, code):
     s = C.c_void_p(streams[si].cuda_stream)
     for n, N, K, S in SHAPES:
         L.check(lib.vispec_gemm_skinny_tune(engs[si].h, code * 10000 + S * 100, s, p(X[K]), K, p(W[n][(it * NS + si) % NB]), p(Y), N, M, N, K))
-for code, name in (((8, "MT=4 NT=1"),) if M > 64 else ((1, "NT=1"), (5, "NT=2"), (6, "NT=2, half the activation loads (upper bound)"))):
+for code, name in (((8, "MT=4 NT=1"), (9, "wide (16 waves, shared staging)")) if M > 96 else ((9, "wide NL=3"),) if M > 64 else ((1, "NT=1"), (5, "NT=2"), (6, "NT=2, half the activation loads (upper bound)"))):
     for ns in (1, 2, 3, 4):
         for it in range(3):
             for si in range(ns): layer(si, it, code)

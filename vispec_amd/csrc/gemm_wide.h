@@ -1,0 +1,328 @@
+// Wide-cohort GEMM: up to FOUR requests (activation tiles of 32 rows each, `m_tile` live rows per tile) share ONE pass over a
+// W32-packed weight.   Y[128, N] = X[128, K] · W[N, K]^T, every weight byte streamed from HBM exactly once per launch.
+//
+// Why a new kernel (and not gemm_w32_kernel<…, MT = 4>): with four activation tiles per weight tile the skinny kernel's per-wave
+// activation staging moves 4 bytes of X through ds_write/L1 per weight byte (measured 2.3 TB/s on three streams, tools/
+// gemm_mt2_concurrency.py M=120) — the LDS store path (ds_write_b128 ≈ 79 B/clk/CU, MI355X_MICROARCH.md §LDS) and the TA, not HBM, set
+// its pace.  Here a workgroup is 16 waves = 4 row blocks x 4 K-quarters: the four row-block waves of a K-quarter SHARE one staged
+// X image per 64-k group (LDS, double-buffered, same padded layout as the skinny kernel), so the workgroup moves one byte of X per
+// byte of W — the ratio of the single-request kernel — while each weight tile held in registers feeds four MFMAs.
+//
+// Bit-identity with the single-request kernel (what keeps "a cohort request == the same request alone" exact): wave (rb, kq)
+// accumulates row block rb over exactly the k-steps wave kq of gemm_w32_kernel<1, …, NW = 4> would own for the same split (same
+// ks_lo/ks_hi and w_lo/w_hi formulas), in ascending k order, one v_mfma_f32_32x32x16_bf16 per step with the same operands; the four
+// quarter sums are then added as ((q0 + q1) + q2) + q3 — the order of the skinny kernel's LDS reduction — and the epilogues apply
+// the same fp32 -> bf16 rounding points.
+//
+// Epilogues: as gemm_w32_kernel (NONE / RESIDUAL / SWIGLU / PARTIAL / ROPE).  Tile t of X/Y belongs to request t (`n_live` requests).
+#pragma once
+#include "kernels.h"
+
+// LDS image of the staged activations (no padding: LDS-DMA writes lane-linear 1 KiB pieces):
+//   K-quarter kq: + kq * 32 KiB ; buffer b: + b * 16 KiB ; activation tile mt: + mt * 4 KiB ; piece pc (8 rows x 64 k): + pc * 1 KiB ;
+//   row r of the piece: + r * 128 B ; 16-byte slot c of the row holds k-segment  g = c ^ ((4 pc + (r >> 1)) & 7)  of that row.
+// The XOR is applied on the SOURCE address of the DMA (the destination of a global_load_lds is fixed: base + lane x 16) and again by the
+// fragment reads; with f(row j) = (j >> 1) & 7 the 16 lanes of every ds_read_b128 service group hit 16 different 16-byte bank slots.
+#define WIDE_QBYTES (32 * 1024)
+#define WIDE_BUFBYTES (16 * 1024)
+#define WIDE_LDS_BYTES (4 * WIDE_QBYTES)               // 128 KiB: one workgroup per CU
+#define WIDE_MPAD 128
+
+// Hand-counted memory pipeline.  hipcc's own s_waitcnt placement cannot express it: with an LDS-DMA in flight it waits vmcnt(0) at every use
+// of an ordinary load (MI355X guide, "three .s-level traps"), and around a loop back-edge it falls back to vmcnt(0) for the weight
+// registers as well — either way the whole HBM latency of the last weight tile lands on every 64-k group.  So every VMEM operation of the
+// main loop is an asm statement the compiler does not see, and the waits are counted by hand (the queue is in order):
+//   top of a steady-state group:  [w0 .. w(L-1)]                 (this group's tiles, issued during the previous group)
+//   + NL activation pieces of the NEXT group by LDS-DMA:         [w0 .. w(L-1), D x NL]
+//   step u waits vmcnt(L - 1 + NL) (tile u landed), runs its MFMAs, then re-issues its register for the next group: the queue
+//   keeps that length; before the barrier vmcnt(L) retires the DMAs and leaves the L weight tiles in flight.
+template <int N>
+__device__ __forceinline__ void wide_wait_vm(u32x4_t& w) {  // "+v": nothing that consumes w may be scheduled above the wait
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "i"(N) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void wide_load_w(u32x4_t& w, unsigned voff, const unsigned char* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(w) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void wide_dma16(unsigned voff, const unsigned char* sbase, unsigned lds_dst) {
+  unsigned keep;  // M0 (the DMA's LDS base) is compiler-reserved: save, set, use and restore it inside ONE statement
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wide_wait_barrier() {  // own DMAs landed (N younger loads may stay in flight), own LDS reads drained, rendezvous
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "i"(N) : "memory");
+}
+
+// NL = live activation tiles (requests) — a template parameter: runtime guards around the MFMAs made hipcc branch around every
+// one of them and keep the accumulators in scratch memory.
+template <int EPI, bool W8, int NL>
+__global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+                                                             const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
+                                                             const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,
+                                                             const float* __restrict__ wscale, RopeEpi re, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rb = wave & 3, kq = wave >> 2;  // row block of the workgroup / K-quarter
+  const int j = lane & 31, hi = lane >> 5;
+  const int split = blockIdx.y;
+  const int tile_raw = blockIdx.x * 4 + rb;
+  const bool tile_ok = tile_raw < tiles;
+  const int tile = tile_ok ? tile_raw : 0;  // a ragged last workgroup streams tile 0 again and stores nothing
+  constexpr int KSTEP = W8 ? 32 : 16;       // k per 1 KiB weight tile
+  constexpr int LOADS = W8 ? 2 : 4;         // weight tiles per 64-k group
+  const int KS = K / KSTEP;
+  const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
+  const int len = ks_hi - ks_lo;
+  const int w_lo = ks_lo + (int)((long)len * kq / 4), w_hi = ks_lo + (int)((long)len * (kq + 1) / 4);
+  const int n_steps = w_hi - w_lo;
+  const int G = n_steps / LOADS;  // 64-k groups of this K-quarter (quarter-uniform)
+  int Gmax = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = ks_lo + (int)((long)len * q / 4), b = ks_lo + (int)((long)len * (q + 1) / 4);
+    Gmax = max(Gmax, (b - a) / LOADS);
+  }
+  const uint4* pa = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * 64 + lane + (size_t)w_lo * 64;
+  f32x16 acc[NL];
+#pragma unroll
+  for (int mt = 0; mt < NL; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  // ---- staging of this K-quarter's activations: its 4 waves move [32 NL rows] x [64 k] per group as 4 NL pieces of 8 rows x 128 B (whole
+  // lines), NL pieces per wave, by LDS-DMA (no staging registers, no ds_write pass).  Rows past m_tile of a tile are fetched too (the
+  // workspaces hold 32 rows per tile) and only ever reach output rows that are not stored.
+  unsigned char* xq = smem_w + kq * WIDE_QBYTES;
+  const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xq;
+  unsigned xoff[NL], xdst[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int q = rb * NL + i, mt = q >> 2, pc = q & 3;
+    const int row = 32 * mt + 8 * pc + (lane >> 3), g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
+    xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;
+    xdst[i] = lds_q + (unsigned)(mt * 4 + pc) * 1024u;
+  }
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X + (size_t)w_lo * KSTEP);  // + 128 B per group
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + ((size_t)tile * KS + w_lo) * 1024;  // + LOADS KiB per group
+  const unsigned wvo = lane * 16;
+  // fragment reads: lane (j, hi) takes k-segment s of row j: bf16 step u -> s = 2u + hi ; fp8 tile c -> s = 4c + 2hi and s + 1
+  const unsigned rrow = (unsigned)(j >> 3) * 1024u + (unsigned)(j & 7) * 128u, fsw = (unsigned)(j >> 1) & 7u;
+  unsigned ro[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned sseg = W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi);
+    ro[t] = rrow + ((sseg ^ fsw) << 4);
+  }
+  u32x4_t w[LOADS];
+#define WIDE_DMA(grp, buf)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < NL; ++i)                                                                \
+      wide_dma16(xoff[i], xsrc + (size_t)(grp) * 128, xdst[i] + (buf) * WIDE_BUFBYTES);
+  // one k-step (one weight tile register) against the NL staged activation tiles
+#define WIDE_MFMA(u, xb)                                                                                        \
+  if constexpr (!W8) {                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
+      const uint4 bv = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[u]);                               \
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[u]), as_bf16x8(bv), acc[mt], 0, 0, 0); \
+    }                                                                                                           \
+  } else {                                                                                                      \
+    uint4 a_lo, a_hi;                                                                                           \
+    fp8x16_to_bf16(make_uint4(w[u].x, w[u].y, w[u].z, w[u].w), a_lo, a_hi);                                     \
+    _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
+      const uint4 b0 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u)) & 3]);                   \
+      const uint4 b1 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u) + 1) & 3]);               \
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), acc[mt], 0, 0, 0);      \
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[mt], 0, 0, 0);      \
+    }                                                                                                           \
+  }
+#define WIDE_STEP_PREF(u)                                                                                       \
+  if constexpr ((u) < LOADS) {                                                                                            \
+    wide_wait_vm<LOADS - 1 + NL>(w[(u) < LOADS ? (u) : 0]);                                                     \
+    WIDE_MFMA((u) < LOADS ? (u) : 0, xb)                                                                        \
+    wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[(u) < LOADS ? (u) : 0], wvo, wn);                             \
+  }
+#define WIDE_STEP_LAST(u)                                                                                       \
+  if constexpr ((u) < LOADS) {                                                                                            \
+    wide_wait_vm<((u) < LOADS ? LOADS - 1 - (u) : 0)>(w[(u) < LOADS ? (u) : 0]);                                \
+    WIDE_MFMA((u) < LOADS ? (u) : 0, xb)                                                                        \
+  }
+  if (G > 0) {
+    WIDE_DMA(0, 0)
+    wide_load_w<0>(w[0], wvo, wsrc);
+    wide_load_w<1024>(w[1], wvo, wsrc);
+    if constexpr (LOADS > 2) {
+      wide_load_w<2048>(w[LOADS > 2 ? 2 : 0], wvo, wsrc);
+      wide_load_w<3072>(w[LOADS > 2 ? 3 : 0], wvo, wsrc);
+    }
+  }
+  if (Gmax > 0) wide_wait_barrier<LOADS>();  // (a quarter without groups has nothing in flight: the count is harmless)
+  // single-path loop body (an if / else-if / else around the two unrolled bodies made hipcc shuffle the accumulators through scratch):
+  // steady-state groups, then the quarter's last group, then barrier-only rounds so that every wave of the workgroup executes the same
+  // number of s_barrier whatever its quarter's group count (the quarters share nothing but the rendezvous itself)
+  for (int g = 0; g + 1 < G; ++g) {  // group g + 1 is fetched while group g is on the matrix cores
+    const unsigned char* xb = xq + (g & 1) * WIDE_BUFBYTES;
+    const unsigned char* wn = wsrc + (size_t)(g + 1) * (LOADS * 1024);
+    WIDE_DMA(g + 1, (g + 1) & 1)  // that buffer was last read before the previous barrier
+    WIDE_STEP_PREF(0) WIDE_STEP_PREF(1) WIDE_STEP_PREF(2) WIDE_STEP_PREF(3)
+    wide_wait_barrier<LOADS>();
+  }
+  if (G > 0) {  // the quarter's last group: nothing left to fetch
+    const unsigned char* xb = xq + ((G - 1) & 1) * WIDE_BUFBYTES;
+    WIDE_STEP_LAST(0) WIDE_STEP_LAST(1) WIDE_STEP_LAST(2) WIDE_STEP_LAST(3)
+    wide_wait_barrier<0>();
+  }
+  for (int e = G; e < Gmax; ++e) wide_wait_barrier<0>();
+#undef WIDE_STEP_PREF
+#undef WIDE_STEP_LAST
+#undef WIDE_MFMA
+#undef WIDE_DMA
+  {  // leftover steps of this wave's K range (fewer than a group): fragment-shaped X loads straight from global
+    const uint4* pl = pa + (size_t)G * LOADS * 64;
+    const size_t k0 = (size_t)(w_lo + G * LOADS) * KSTEP + (W8 ? hi * 16 : hi * 8);
+    for (int s = G * LOADS; s < n_steps; ++s) {
+      const uint4 av = *pl;
+#pragma unroll
+      for (int mt = 0; mt < NL; ++mt) {
+          const bf16_t* px = X + (size_t)(j < m_tile ? 32 * mt + j : 0) * ldx + k0 + (size_t)(s - G * LOADS) * KSTEP;
+          const uint4 bv = *reinterpret_cast<const uint4*>(px);
+          if (!W8) {
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[mt], 0, 0, 0);
+          } else {
+            const uint4 bv1 = *reinterpret_cast<const uint4*>(px + 8);
+            uint4 a_lo, a_hi;
+            fp8x16_to_bf16(av, a_lo, a_hi);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(bv), acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[mt], 0, 0, 0);
+          }
+        }
+      pl += 64;
+    }
+  }
+  // ---- K-quarter reduction through LDS (aliases the staging area): quarters 1..3 publish two activation tiles per pass, the
+  // quarter-0 wave of each row block adds them in the fixed order ((q0 + q1) + q2) + q3 and keeps the result in registers.
+  // Layout [q-1][rb][tile of the pass][4-register group][lane] x 16 B: conflict-free 16-byte LDS accesses.
+  float4* red = reinterpret_cast<float4*>(smem_w);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();  // pass 0: the main loop's / leftover reads of the staging area are over; pass 1: pass 0's reads are over
+    if (kq > 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          if (2 * pass + t >= NL) continue;
+          const f32x16& a = acc[2 * pass + t < NL ? 2 * pass + t : 0];
+          red[((((kq - 1) * 4 + rb) * 2 + t) * 4 + r4) * 64 + lane] = make_float4(a[4 * r4], a[4 * r4 + 1], a[4 * r4 + 2], a[4 * r4 + 3]);
+        }
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            if (2 * pass + t >= NL) continue;
+            const float4 v = red[((((q - 1) * 4 + rb) * 2 + t) * 4 + r4) * 64 + lane];
+            f32x16& a = acc[2 * pass + t < NL ? 2 * pass + t : 0];
+            a[4 * r4] += v.x; a[4 * r4 + 1] += v.y; a[4 * r4 + 2] += v.z; a[4 * r4 + 3] += v.w;
+          }
+    }
+  }
+  if (kq != 0 || !tile_ok) return;
+  // ---- epilogues (the arithmetic of gemm_w32_kernel's, on the sums held in registers).  D[i = n][j = m]: register 4q + r of a
+  // lane is column 8q + 4hi + r of the tile for row j of the activation tile.
+#pragma unroll
+  for (int mt = 0; mt < NL; ++mt) {
+    if (j >= m_tile) continue;
+    const int m = 32 * mt + j;
+    if (EPI == EPI_ROPE) {
+      const PosSpec& ps_ = re.ps[mt];
+      const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + j;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
+        const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
+        if (h < re.H + re.H_kv) {
+          const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of the pair
+          const int pos = (ps_.base ? *ps_.base : 0) + (ps_.base2 ? *ps_.base2 : 0) + ps_.add + (ps_.off ? ps_.off[j] : (ps_.row ? j : 0));
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
+            if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+            if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
+            x1 = rdbf(x1);
+            x2 = rdbf(x2);
+            const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
+            o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
+            o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
+          }
+          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
+                                   : re.kc[mt] + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
+            if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+            if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
+            o1[r] = rdbf(x1);
+            o2[r] = rdbf(x2);
+          }
+          bf16_t* dst = re.vc[mt] + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        }
+      }
+    } else if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int n = tile * 16 + 8 * qq + 4 * hi;  // output column; gate row n, up row N + n of the natural weight
+        if (n >= N) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = acc[mt][4 * qq + r], u = acc[mt][4 * (qq + 2) + r];
+          if (W8) { y *= wscale[n + r]; u *= wscale[N + n + r]; }
+          if (bias) { y += bf2f(bias[n + r]); u += bf2f(bias[N + n + r]); }
+          y = rdbf(y);
+          u = rdbf(u);
+          const float act = rdbf(y / (1.0f + __expf(-y)));
+          o[r] = rdbf(act * u);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = tile * 32 + 8 * q + 4 * hi;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[mt][4 * q + r];
+          if (W8) v[r] *= wscale[n + r];  // per-output-channel dequantisation scale on the fp32 accumulator
+        }
+        if (EPI == EPI_PARTIAL) {
+          float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * WIDE_MPAD + m) * N + n;
+          *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float y = v[r];
+            if (bias) y += bf2f(bias[n + r]);
+            y = rdbf(y);
+            if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+            o[r] = y;
+          }
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        }
+      }
+    }
+  }
+}

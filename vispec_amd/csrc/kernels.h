@@ -106,14 +106,14 @@ struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m 
 // meet in one lane, so the q and k rows of the weight are packed in "rope order": 32-row tile t of a head holds
 // d = 16t..16t+15 followed by d+64 (qkv_rope_perm(); v rows keep their order).  q goes to Y at its natural column, k / v
 // go straight to cache row *kv_base + kv_add + m.
-// Cohort mode (m_tile > 0, two requests sharing one weight pass): activation tile mt belongs to request mt, which has its own
+// Cohort mode (m_tile > 0, up to four requests sharing one weight pass): activation tile mt belongs to request mt, which has its own
 // positions and its own KV cache -> index [mt]; otherwise index 0 serves every row.
 struct RopeEpi {
   const bf16_t* cosT = nullptr;
   const bf16_t* sinT = nullptr;
-  PosSpec ps[2];
-  bf16_t* kc[2] = {nullptr, nullptr};
-  bf16_t* vc[2] = {nullptr, nullptr};
+  PosSpec ps[4];
+  bf16_t* kc[4] = {nullptr, nullptr, nullptr, nullptr};
+  bf16_t* vc[4] = {nullptr, nullptr, nullptr, nullptr};
   int s_max = 0, H = 0, H_kv = 0;
 };
 
@@ -711,7 +711,7 @@ __device__ __forceinline__ int att_swz(int row, int colbyte) { return row * 256 
 //     over all 128 head_dim columns — so nothing is computed twice (the first form ran QK^T + softmax in both head_dim-half waves);
 //   * the V^T operand of P·V comes from the hardware transposing read (ds_read_b64_tr_b16: 16 per 32-key tile instead of 64
 //     ds_read_u16 + packing); V rows keep their natural order in LDS, 64-byte blocks XOR-ed with (row & 3) -> conflict-free;
-//   * up to two requests per launch (blockIdx.z / NQT): a cohort's two attention calls run side by side.
+//   * up to four requests per launch (blockIdx.z / NQT): a cohort's attention calls run side by side.
 // LDS: K 32 KB + V 32 KB, single-buffered (the next chunk waits in registers while the current one is on the matrix cores); two
 // workgroups per CU.  The four waves' (m, l, O) are merged through the same 64 KB at the end.
 #define ATT2_CHUNK 128
@@ -726,7 +726,8 @@ struct AttnReq {
   float* part_ml;
   bf16_t* out;  // (reduce kernel)
 };
-struct AttnArgs { AttnReq r[2]; };
+struct AttnArgs { AttnReq r[4]; };  // up to four requests of a cohort per launch
+__device__ __forceinline__ AttnReq attn_req(const AttnArgs& a, int rq) { return rq == 0 ? a.r[0] : rq == 1 ? a.r[1] : rq == 2 ? a.r[2] : a.r[3]; }
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int att_vswz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 3) << 6)); }
 
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
   unsigned char* sV = smem + ATT2_CHUNK * 256;
   const int split = blockIdx.x, kvh = blockIdx.y;
   const int rq = blockIdx.z / NQT, qt = blockIdx.z - rq * NQT;
-  const AttnReq R = rq ? args.r[1] : args.r[0];
+  const AttnReq R = attn_req(args, rq);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
   const int n_prefix = R.prefix_dev ? *R.prefix_dev : 0;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
 __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, int H, int H_kv, int M, int tail,
                                                                int keys_per_wg, int nsplit, int ldo) {
   // blockIdx.z = request of a cohort (0 otherwise)
-  const AttnReq R = blockIdx.z ? args.r[1] : args.r[0];
+  const AttnReq R = attn_req(args, blockIdx.z);
   const float* __restrict__ part_o = R.part_o;
   const float* __restrict__ part_ml = R.part_ml;
   const int* __restrict__ prefix_dev = R.prefix_dev;

@@ -238,10 +238,12 @@ __global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
 // am[i] = argmax of the target logits at tree node i.  sel[j] = tree node accepted at depth j (j = 0..a).
 __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __restrict__ am, int* __restrict__ tokens,
                                      int tokens_cap, int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
-                                     int forced_accept, int* __restrict__ draft_ids) {
+                                     int forced_accept, int* __restrict__ draft_ids, int cohort) {
   __shared__ int acc[TREE_MAX_T];
   const int tid = threadIdx.x;
-  if (st->done) {  // finished request (its cohort partner is still running): freeze
+  // cohort rounds only: a finished request (its partners are still running) freezes.  The single-request entry points keep
+  // stepping whatever `done` says — a caller driving the step API past EOS with its own stop rule gets fresh results every step.
+  if (cohort && st->done) {
     __syncthreads();
     if (tid == 0) st->frozen = 1;
     return;
@@ -404,10 +406,14 @@ __device__ __forceinline__ int vs_multinomial(const bf16_t* __restrict__ row, in
     run += x;
   }
   const double target = (double)u * run;
-  s_d[tid] = off + (inc - loc);
+  // exclusive prefix of a chunk = the INCLUSIVE prefix of its left neighbour (never inc - loc: a prefix built by subtraction is not
+  // guaranteed non-decreasing in floating point); the winner is the LAST chunk whose start is <= target, resolved with atomicMax so
+  // that equal starts (empty chunks) cannot race
+  const double left = __shfl_up(inc, 1, 64);
+  s_d[tid] = off + ((tid & 63) ? left : 0.0);
   if (tid == 0) { s_d[1024] = target; s_i[0] = 0; }
   __syncthreads();
-  if (s_d[tid] <= target && (tid == 1023 || s_d[tid + 1] > target)) s_i[0] = tid;  // the last chunk whose start is <= target: exactly one thread
+  if (s_d[tid] <= target) atomicMax(&s_i[0], tid);
   __syncthreads();
   const int tsel = s_i[0];
   if (tid == tsel) {
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
                                                                     int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
                                                                     int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
-                                                                    int* __restrict__ draft_ids) {
+                                                                    int* __restrict__ draft_ids, int cohort) {
   __shared__ int cand[TREE_MAX_T][TREE_RET_W];
   __shared__ int s_eq[TREE_MAX_T];
   __shared__ int accept_cand[TREE_RET_W];
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
   __shared__ int s_i[2];
   __shared__ int s_hist[258];
   const int tid = threadIdx.x;
-  if (st->done) {  // finished request (its cohort partner is still running): freeze
+  if (cohort && st->done) {  // finished request of a cohort (its partners are still running): freeze
     __syncthreads();
     if (tid == 0) st->frozen = 1;
     return;

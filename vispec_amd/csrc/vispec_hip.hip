@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "gemm_prefill.h"
+#include "gemm_wide.h"
 #include "tree_kernels.h"
 
 static thread_local std::string g_err;
@@ -70,21 +71,24 @@ struct vispec_ctx {
   // argument or shapes the launch sequence — compared field by field (a hashed single integer could collide and replay a graph
   // with the wrong sampling parameters).
   struct GraphKey {
-    int n_hint = -1, forced_accept = 0, total_token = 0, sample_top_k = 0;
-    float temperature = 0.f;
-    unsigned long long seed = 0;
-    int n_hint2 = -1, sample_top_k2 = 0;  // the second request of a cohort round
-    float temperature2 = 0.f;
-    unsigned long long seed2 = 0;
+    int n_req = 0, forced_accept = 0, total_token = 0;
+    // per request of the (cohort) round, leader first.  `who` = the ctx itself: a captured graph bakes that request's pointers in
+    // (state, tree, KV, selections ...), so the same leader with a DIFFERENT member set must not replay it.
+    const void* who[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_hint[4] = {-1, -1, -1, -1}, sample_top_k[4] = {0, 0, 0, 0};
+    float temperature[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long seed[4] = {0, 0, 0, 0};
     bool operator==(const GraphKey& o) const {
-      return n_hint == o.n_hint && forced_accept == o.forced_accept && total_token == o.total_token && sample_top_k == o.sample_top_k &&
-             memcmp(&temperature, &o.temperature, sizeof(float)) == 0 && seed == o.seed && n_hint2 == o.n_hint2 &&
-             sample_top_k2 == o.sample_top_k2 && memcmp(&temperature2, &o.temperature2, sizeof(float)) == 0 && seed2 == o.seed2;
+      return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && memcmp(who, o.who, sizeof(who)) == 0 &&
+             memcmp(n_hint, o.n_hint, sizeof(n_hint)) == 0 && memcmp(sample_top_k, o.sample_top_k, sizeof(sample_top_k)) == 0 &&
+             memcmp(temperature, o.temperature, sizeof(temperature)) == 0 && memcmp(seed, o.seed, sizeof(seed)) == 0;
     }
   };
   struct GraphSlot { hipGraphExec_t exec = nullptr; GraphKey key; };
   GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft;
-  vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are the second 32-row tiles of the leader's
+  vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are 32-row tile `slot` of the leader's
+  int slot = 0;                  // activation tile of this request inside the leader's 128-row workspaces (leader: 0, members: 1..3)
+  vispec_ctx* members[3] = {nullptr, nullptr, nullptr};  // (leader) the member that owns tile 1, 2, 3
   float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
   int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
   unsigned long long seed = 0;
@@ -106,13 +110,19 @@ static int dalloc(vispec_ctx* ctx, T** p, size_t n) {
 extern "C" const char* vispec_last_error(void) { return g_err.c_str(); }
 extern "C" int vispec_version(void) { return 1; }
 
-#define ROWS 64   /* rows of the activation workspaces */
+#define ROWS 128  /* rows of the activation workspaces: four 32-row tiles (a cohort of up to four requests shares one weight pass) */
 #define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
 static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
   if (leader && (leader->leader || memcmp(&leader->c, cfg, sizeof(vispec_config)) != 0))
     return fail("ctx_create_member: the leader must be an ordinary ctx created with the same config");
   if (leader && cfg->total_token > 32) return fail("ctx_create_member: a cohort member owns one 32-row activation tile: total_token <= 32");
+  if (leader && leader->c.total_token > 32) return fail("ctx_create_member: the leader's tree must fit one 32-row activation tile (total_token <= 32)");
+  int slot = 0;
+  if (leader) {
+    for (slot = 1; slot <= 3 && leader->members[slot - 1]; ++slot) {}
+    if (slot > 3) return fail("ctx_create_member: the leader already has three members (a cohort is at most four requests)");
+  }
   const vispec_config& c = *cfg;
   if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
   if (c.hidden_size % 64 || c.intermediate_size % 64 || c.draft_intermediate % 64 || c.vocab_size % 16)
@@ -127,6 +137,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   vispec_ctx* ctx = new vispec_ctx();
   ctx->c = c;
   ctx->leader = leader;
+  ctx->slot = slot;
   ctx->layers.resize(c.num_layers);
   const size_t D = c.hidden_size, I = c.intermediate_size, Id = c.draft_intermediate, V = c.vocab_size;
   const size_t QKV = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
@@ -135,10 +146,10 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     vispec_ctx_destroy(ctx);                      \
     return -1;                                    \
   }
-  // row-wise activation workspaces (ROWS = 64 rows of `ld` elements): a cohort member's are the second 32-row tiles of its leader's,
-  // so that a GEMM launched once on the leader's 64 rows serves both requests
+  // row-wise activation workspaces (ROWS = 128 rows of `ld` elements): a cohort member's are 32-row tile `slot` of its leader's,
+  // so that a GEMM launched once on the leader's rows serves every request of the cohort
 #define AL(p, ld)                                           \
-  if (leader) ctx->p = leader->p + (size_t)32 * (ld);      \
+  if (leader) ctx->p = leader->p + (size_t)32 * slot * (ld); \
   else A(p, (size_t)ROWS * (ld))
   A(st, 1);
   ctx->tokens_cap = c.max_pos + 64;
@@ -189,7 +200,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     size_t nmax = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
     if (nmax < (size_t)3 * c.hidden_size) nmax = (size_t)3 * c.hidden_size;
     if (nmax < 16384) nmax = 16384;
-    ctx->gemm_part_elems = (size_t)8 * 64 * nmax;
+    ctx->gemm_part_elems = (size_t)8 * 128 * nmax;  // [S <= 8][up to four 32-row tiles][N] fp32
     if (leader) ctx->gemm_part = leader->gemm_part;  // launches of a cohort are stream-ordered: one partial workspace serves both
     else A(gemm_part, ctx->gemm_part_elems);
     A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
@@ -205,6 +216,17 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
           hipSuccess) {
     (void)hipGetLastError();  // a device-less build/load check must still be able to create nothing; report lazily
   }
+  {  // the wide-cohort GEMM declares 132 KiB of dynamic LDS
+#define WIDE_ALL_EPI(W8_, NL_)                                                                                                      \
+  (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_>,                   \
+      (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_>,              \
+      (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_>
+    const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4)};
+#undef WIDE_ALL_EPI
+    for (const void* f : wide)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES) != hipSuccess) (void)hipGetLastError();
+  }
+  if (leader) leader->members[slot - 1] = ctx;
   *out = ctx;
   return 0;
 }
@@ -217,6 +239,9 @@ extern "C" int vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* le
 
 extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->leader && ctx->slot >= 1 && ctx->leader->members[ctx->slot - 1] == ctx) ctx->leader->members[ctx->slot - 1] = nullptr;
+  for (vispec_ctx* m : ctx->members)
+    if (m) m->leader = nullptr;  // (a member must not outlive its leader's workspaces; it can no longer join a cohort)
   for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft})
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
   for (void* p : ctx->allocs) (void)hipFree(p);
@@ -441,9 +466,85 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   return 0;
 }
 
+// Three or four requests per weight pass (csrc/gemm_wide.h): tile t of X / Y / R (rows 32t ..) belongs to request t, rows
+// 32t .. 32t + m_tile - 1 are live.  Same decomposition rules as launch_gemm_mt — in particular the SAME split-K factor as the
+// single-request launch of the same GEMM, so every row's partial sums group the same k ranges.
+static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int n_req, int N, int K,
+                            int epi, const GemmOut& o, int force_split, const RopeEpi* re = nullptr) {
+  if (n_req < 3 || n_req > 4 || o.m_tile < 1 || o.m_tile > 32) return fail("gemm_wide: 3 or 4 requests of 1..32 rows");
+  if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_wide: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
+  if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_wide: residual epilogue without R");
+  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
+  const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
+  const int M = 32 * (n_req - 1) + o.m_tile;
+#define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
+  PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r,   \
+          o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
+#define WIDE_D(EPI_, YPTR, LDY, SPLITS)                                                                       \
+  do {                                                                                                        \
+    if (o.wscale) { if (n_req == 3) WIDE_L(EPI_, true, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, true, 4, YPTR, LDY, SPLITS); }     \
+    else { if (n_req == 3) WIDE_L(EPI_, false, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, false, 4, YPTR, LDY, SPLITS); }            \
+  } while (0)
+  if (epi == EPI_ROPE) {
+    if (!re) return fail("gemm_wide: rope epilogue without its arguments");
+    prof_begin(s, PROF_QKV_ROPE, (double)N * K * (o.wscale ? 1.0 : 2.0));
+    WIDE_D(EPI_ROPE, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  if (epi == EPI_SWIGLU) {
+    if (N % 16) return fail("gemm_wide: SwiGLU needs N %% 16 == 0");
+    if (o.norm_w) return fail("gemm_wide: no fused norm after SwiGLU");
+    prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
+    WIDE_D(EPI_SWIGLU, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  int S = 1;
+  if (tiles < 256 || o.norm_w) {
+    S = choose_split(tiles, KS, (double)32 * K * (o.wscale ? 1.0 : 2.0), o.norm_w != nullptr);
+    if (!ctx) S = 1;
+  }
+  if (force_split > 0) S = force_split;
+  if (S == 1 && !o.norm_w) {
+    prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
+    if (epi == EPI_RESIDUAL) WIDE_D(EPI_RESIDUAL, o.Y, o.ldy, 1); else WIDE_D(EPI_NONE, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  if (!ctx) return fail("gemm_wide: split-K needs a ctx (partial workspace)");
+  if ((size_t)S * WIDE_MPAD * N > ctx->gemm_part_elems) return fail("gemm_wide: partial workspace too small");
+  prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
+  {
+    const bf16_t* b_keep = b;
+    b = nullptr;  // bias belongs to the reduce
+    WIDE_D(EPI_PARTIAL, ctx->gemm_part, 0, S);
+    b = b_keep;
+  }
+#undef WIDE_D
+#undef WIDE_L
+  KCHK();
+  prof_end(s);
+  prof_begin(s, 4, 0.0);
+  static const int red_threads = getenv("VISPEC_REDUCE_THREADS") ? atoi(getenv("VISPEC_REDUCE_THREADS")) : 512;
+  PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? red_threads : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, WIDE_MPAD, N, b,
+          epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn, o.eps, o.m_tile);
+  KCHK();
+  prof_end(s);
+  return 0;
+}
+
+// m_tile > 0: cohort mode, M = 32 (n_req - 1) + m_tile with n_req in [2,4] requests of m_tile rows each (tile t = request t)
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1) {
-  if (o.m_tile > 0 && (M != 32 + o.m_tile || o.m_tile > 32)) return fail("gemm_skinny: cohort mode wants M = 32 + m_tile");
+  if (o.m_tile > 0) {
+    const int n_req = (M - o.m_tile) / 32 + 1;
+    if (o.m_tile > 32 || (M - o.m_tile) % 32 || n_req < 2 || n_req > 4) return fail("gemm_skinny: cohort mode wants M = 32 (n - 1) + m_tile, n in [2,4]");
+    if (n_req > 2) return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, epi, o, force_split);
+  }
   if (M <= 32) return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   if (M <= 64) return launch_gemm_mt<2>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   return fail("gemm_skinny: M must be in [1,64]");
@@ -517,25 +618,30 @@ struct QkvReq {  // per-request part of a q|k|v projection: positions and the ca
   void* kc = nullptr;
   void* vc = nullptr;
 };
-// n_req = 1: rows 0 .. M-1 of X belong to rq[0].  n_req = 2 (cohort): request t owns rows 32t .. 32t + M - 1, the weights are
-// streamed once for both.
+// n_req = 1: rows 0 .. M-1 of X belong to rq[0].  n_req = 2..4 (cohort): request t owns rows 32t .. 32t + M - 1, the weights are
+// streamed once for all of them.
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, const QkvReq* rq, int n_req,
                            int s_max) {
   const int N = (H + 2 * H_kv) * 128;
-  const int m_tile = n_req == 2 ? M : 0, Mk = n_req == 2 ? 32 + M : M;
+  const int m_tile = n_req >= 2 ? M : 0, Mk = n_req >= 2 ? 32 * (n_req - 1) + M : M;
   if (!qkv_rope_fused(N)) {
     if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, Mk, N, K, EPI_NONE, wscale, m_tile)) return -1;
     for (int t = 0; t < n_req; ++t)
       if (launch_rope(s, (bf16_t*)qkv + (size_t)32 * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
     return 0;
   }
-  if (M < 1 || Mk > 64) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
+  if (M < 1 || Mk > 128 || (n_req == 1 && M > 64) || (n_req > 1 && M > 32)) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
   for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
+  if (n_req > 2) {  // three or four requests: the wide-cohort kernel
+    GemmOut o;
+    o.wscale = (const float*)wscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
+    return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, EPI_ROPE, o, -1, &re);
+  }
   prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
 #define VISPEC_QKV(W8_, MT_, NT_)                                                                                                         \
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT_>()), s, \
@@ -569,7 +675,7 @@ struct AttnCall {  // per-request part of an attention call
   const unsigned long long* mask;
   void* out;
 };
-// n = 1, or 2 for a cohort: both requests' attention runs in ONE partial launch and ONE reduce launch (blockIdx.z)
+// n = 1, or 2..4 for a cohort: all requests' attention runs in ONE partial launch and ONE reduce launch (blockIdx.z)
 static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int ldq, int s_max, int H, int H_kv, int M, int tail, int ldo,
                               int eager, int max_keys) {
   if (M < 1 || M > 64) return fail("tree_attention: M must be in [1,64]");
@@ -578,7 +684,11 @@ static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int l
   static const int kpw_env = getenv("VISPEC_ATT_KPW") ? atoi(getenv("VISPEC_ATT_KPW")) : 0;  // tuning experiments only
   int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : 256;
   if (max_keys < 1) max_keys = 1;
-  while ((max_keys + kpw - 1) / kpw > 64) kpw *= 2;
+  if (max_keys > s_max) max_keys = s_max;
+  // keys per workgroup from the CACHE CAPACITY, never from the requests' current lengths: the split boundaries (and with them the order in
+  // which partial results are merged) of a request are then the same whatever it shares a launch with — a cohort request stays
+  // bit-identical to the same request alone at every context length
+  while ((s_max + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
   AttnArgs args{};
   for (int t = 0; t < n; ++t) {
@@ -702,6 +812,12 @@ extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, 
   if (epilogue < 0 || epilogue > 2) return fail("gemm_skinny: bad epilogue");
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, M, N, K, epilogue);
 }
+extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* wscale, const void* bias, void* Y,
+                                  int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue) {
+  if (epilogue < 0 || epilogue > 2) return fail("gemm_cohort: bad epilogue");
+  if (n_req < 2 || n_req > 4 || m_tile < 1 || m_tile > 32) return fail("gemm_cohort: 2..4 requests of 1..32 rows");
+  return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 32 * (n_req - 1) + m_tile, N, K, epilogue, wscale, m_tile);
+}
 // skinny GEMM (+bias, +residual R) with the following RMSNorm fused: Y = bf16(R + bf16(X·W^T + b)), normed = norm_w * rms(Y)
 extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
                                        int ldy, const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M,
@@ -732,6 +848,17 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
+  if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
+    if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
+    if (M > 96)
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    else
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    KCHK();
+    return 0;
+  }
   if (M > 64) {  // 8xxxx: FOUR activation tiles, one row block per workgroup (what a cohort of four would run) — measurement only
     if (dbg != 7 || M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: M > 64 needs variant 8xxxx, M <= 128 and a partial workspace of S*128*N");
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, false, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 4>()), s, x, ldx, w, 0,
@@ -892,16 +1019,24 @@ static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& sl
 }
 // sampling = the launch sequence reads temperature / seed / top_k (verify's sampling accept); the draft only switches the row order
 // of its retrieve table on temperature > 0, the AR step uses none of them
-static vispec_ctx::GraphKey graph_key(const vispec_ctx* ctx, int forced_accept, bool sampling_args) {
+static vispec_ctx::GraphKey graph_key_n(vispec_ctx* const* ctxs, int n, int forced_accept, bool sampling_args) {
   vispec_ctx::GraphKey k;
-  k.n_hint = ctx->n_hint;
+  k.n_req = n;
   k.forced_accept = forced_accept;
-  k.total_token = ctx->c.total_token;
-  const bool sampling = ctx->temperature > 1e-5f;
-  k.temperature = sampling_args ? (sampling ? ctx->temperature : 0.f) : (sampling ? 1.f : 0.f);
-  k.seed = sampling_args && sampling ? ctx->seed : 0;
-  k.sample_top_k = sampling_args && sampling ? ctx->sample_top_k : 0;
+  k.total_token = ctxs[0]->c.total_token;
+  for (int t = 0; t < n; ++t) {
+    const vispec_ctx* ctx = ctxs[t];
+    const bool sampling = ctx->temperature > 1e-5f;
+    k.who[t] = ctx;
+    k.n_hint[t] = ctx->n_hint;
+    k.temperature[t] = sampling_args ? (sampling ? ctx->temperature : 0.f) : (sampling ? 1.f : 0.f);
+    k.seed[t] = sampling_args && sampling ? ctx->seed : 0;
+    k.sample_top_k[t] = sampling_args && sampling ? ctx->sample_top_k : 0;
+  }
   return k;
+}
+static vispec_ctx::GraphKey graph_key(vispec_ctx* ctx, int forced_accept, bool sampling_args) {
+  return graph_key_n(&ctx, 1, forced_accept, sampling_args);
 }
 // out[0..2] = {graph replays, graph captures, direct (un-graphed) runs} of the round functions since ctx creation
 extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
@@ -964,11 +1099,12 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
 // each row with the same tiles, in the same order).  n == 1 is the ordinary single-request round.
 struct Cohort {
   int n;
-  vispec_ctx* c[2];
+  vispec_ctx* c[4];
   vispec_ctx* lead() const { return c[0]; }
-  int mt(int rows) const { return n == 2 ? rows : 0; }       // m_tile argument
-  int M(int rows) const { return n == 2 ? 32 + rows : rows; }  // M argument of a shared GEMM
+  int mt(int rows) const { return n >= 2 ? rows : 0; }                    // m_tile argument
+  int M(int rows) const { return n >= 2 ? 32 * (n - 1) + rows : rows; }  // M argument of a shared GEMM
 };
+static Cohort solo_cohort(vispec_ctx* ctx) { return Cohort{1, {ctx, nullptr, nullptr, nullptr}}; }
 
 // bcast_g: (re)write the right half of dx1 with the current global image feature g.  g changes only inside the draft prefill (one new
 // g per image run); vispec_draft_prefill leaves dx1[:, D:2D] = final g for all rows, so the decode rounds never touch it.
@@ -1008,7 +1144,7 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
   vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, Hd = c.draft_heads, k = c.top_k;
-  QkvReq rq[2];
+  QkvReq rq[4];
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* x = co.c[t];
     PosSpec& ps = rq[t].ps;
@@ -1029,7 +1165,7 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
                       co.n, c.draft_max_pos))
     return -1;
   {
-    AttnCall calls[2];
+    AttnCall calls[4];
     int max_keys = 1;
     for (int t = 0; t < co.n; ++t) {
       vispec_ctx* x = co.c[t];
@@ -1098,7 +1234,7 @@ static int draft_round_body(const Cohort& co, hipStream_t s) {
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  const Cohort co{1, {ctx, nullptr}};
+  const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(co, s); });
 }
 
@@ -1108,7 +1244,7 @@ extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* h
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
-  const Cohort solo{1, {ctx, nullptr}};  // the prefill of a request always runs on its own (cohorts form in the decode rounds)
+  const Cohort solo = solo_cohort(ctx);  // the prefill of a request always runs on its own (cohorts form in the decode rounds)
   // the prompt may be as long as the target cache allows (the reference's draft handles it, cnets_ours.py:879-975); what must fit the
   // draft's own cache is the COMPRESSED sequence (checked below), and every row is rotated at its real position < rope_rows
   if (L < 1 || L > ctx->scr_rows) return fail("draft_prefill: prompt does not fit the prefill scratch (max(max_pos, draft_max_pos) rows)");
@@ -1268,7 +1404,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
   const int D = c.hidden_size, H = c.num_heads, Hk = c.num_kv_heads, V = c.vocab_size, I = c.intermediate_size;
   const int QKV = (H + 2 * Hk) * 128;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
-  QkvReq rq[2];
+  QkvReq rq[4];
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* x = co.c[t];
     if (!x->target_kv) return fail("target KV not set");
@@ -1291,7 +1427,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
     if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
       return -1;
     {
-      AttnCall calls[2];
+      AttnCall calls[4];
       int max_keys = 1;
       for (int t = 0; t < co.n; ++t) {
         vispec_ctx* x = co.c[t];
@@ -1336,10 +1472,10 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
     vispec_ctx* ctx = co.c[t];
     if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
       hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
-                         ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids);
+                         ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids, co.n > 1 ? 1 : 0);
     else
       hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
-                         ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids);
+                         ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids, co.n > 1 ? 1 : 0);
     KCHK();
     // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
     // for the draft's catch-up forward
@@ -1354,7 +1490,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
   hipStream_t s = (hipStream_t)stream;
-  const Cohort co{1, {ctx, nullptr}};
+  const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_verify, graph_key(ctx, forced_accept, true), [&]() {
     if (target_forward(co, s, ctx->c.total_token)) return -1;
     return target_accept(co, s, ctx->c.total_token, forced_accept);
@@ -1362,40 +1498,59 @@ extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_ac
 }
 extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
   if (!ctx) return fail("null ctx");
-  return target_forward(Cohort{1, {ctx, nullptr}}, (hipStream_t)stream, ctx->c.total_token);
+  return target_forward(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token);
 }
 extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
   if (!ctx) return fail("null ctx");
-  return target_accept(Cohort{1, {ctx, nullptr}}, (hipStream_t)stream, ctx->c.total_token, forced_accept);
+  return target_accept(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token, forced_accept);
 }
 
-// ---- cohort rounds: two requests (leader + member ctx), one weight pass -----------------------------------------------------------
-static int cohort_check(vispec_ctx* a, vispec_ctx* b) {
-  if (!a || !b) return fail("null ctx");
-  if (b->leader != a) return fail("cohort: the second ctx must have been created as a member of the first (vispec_ctx_create_member)");
-  if (a->c.total_token != b->c.total_token || a->c.total_token > 32) return fail("cohort: both requests need the same tree size <= 32");
+// ---- cohort rounds: two to four requests (leader + member ctxs), one weight pass ------------------------------------------------------
+static int cohort_check(vispec_ctx* const* ctxs, int n, Cohort* co) {
+  if (!ctxs || n < 2 || n > 4) return fail("cohort: 2..4 requests");
+  for (int t = 0; t < n; ++t)
+    if (!ctxs[t]) return fail("null ctx");
+  vispec_ctx* a = ctxs[0];
+  if (a->leader) return fail("cohort: the first ctx must be the leader (an ordinary ctx)");
+  if (a->c.total_token > 32) return fail("cohort: every request needs a tree of <= 32 nodes (one activation tile each)");
+  co->n = n;
+  for (int t = 0; t < 4; ++t) co->c[t] = nullptr;
+  co->c[0] = a;
+  // request t of the round sits in activation tile t: the members must own tiles 1 .. n-1 (any order of creation, no tile twice)
+  for (int t = 1; t < n; ++t) {
+    vispec_ctx* b = ctxs[t];
+    if (b->leader != a) return fail("cohort: every other ctx must have been created as a member of the first (vispec_ctx_create_member)");
+    if (b->c.total_token != a->c.total_token) return fail("cohort: all requests need the same tree size");
+    if (b->slot < 1 || b->slot >= n) return fail("cohort: the members of an n-request round must own activation tiles 1 .. n-1 (create them in order)");
+    if (co->c[b->slot]) return fail("cohort: the same member twice");
+    co->c[b->slot] = b;
+  }
   return 0;
 }
-static vispec_ctx::GraphKey cohort_key(const vispec_ctx* a, const vispec_ctx* b, int forced_accept, bool sampling_args) {
-  vispec_ctx::GraphKey k = graph_key(a, forced_accept, sampling_args);
-  const vispec_ctx::GraphKey kb = graph_key(b, forced_accept, sampling_args);
-  k.n_hint2 = kb.n_hint; k.temperature2 = kb.temperature; k.seed2 = kb.seed; k.sample_top_k2 = kb.sample_top_k;
-  return k;
-}
-extern "C" int vispec_cohort_verify_accept(vispec_ctx* a, vispec_ctx* b, void* stream, int forced_accept) {
-  if (cohort_check(a, b)) return -1;
+extern "C" int vispec_cohortn_verify_accept(vispec_ctx* const* ctxs, int n, void* stream, int forced_accept) {
+  Cohort co;
+  if (cohort_check(ctxs, n, &co)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  const Cohort co{2, {a, b}};
-  return run_graphed(a, s, a->g_cverify, cohort_key(a, b, forced_accept, true), [&]() {
+  vispec_ctx* a = co.c[0];
+  return run_graphed(a, s, a->g_cverify, graph_key_n(co.c, n, forced_accept, true), [&]() {
     if (target_forward(co, s, a->c.total_token)) return -1;
     return target_accept(co, s, a->c.total_token, forced_accept);
   });
 }
-extern "C" int vispec_cohort_draft_round(vispec_ctx* a, vispec_ctx* b, void* stream) {
-  if (cohort_check(a, b)) return -1;
+extern "C" int vispec_cohortn_draft_round(vispec_ctx* const* ctxs, int n, void* stream) {
+  Cohort co;
+  if (cohort_check(ctxs, n, &co)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  const Cohort co{2, {a, b}};
-  return run_graphed(a, s, a->g_cdraft, cohort_key(a, b, 0, false), [&]() { return draft_round_body(co, s); });
+  vispec_ctx* a = co.c[0];
+  return run_graphed(a, s, a->g_cdraft, graph_key_n(co.c, n, 0, false), [&]() { return draft_round_body(co, s); });
+}
+extern "C" int vispec_cohort_verify_accept(vispec_ctx* a, vispec_ctx* b, void* stream, int forced_accept) {
+  vispec_ctx* two[2] = {a, b};
+  return vispec_cohortn_verify_accept(two, 2, stream, forced_accept);
+}
+extern "C" int vispec_cohort_draft_round(vispec_ctx* a, vispec_ctx* b, void* stream) {
+  vispec_ctx* two[2] = {a, b};
+  return vispec_cohortn_draft_round(two, 2, stream);
 }
 __global__ void set_tree_meta_kernel(DevState* st, int n_leaf, int max_depth, int T) {
   if (threadIdx.x == 0) { st->n_leaf = n_leaf; st->max_depth = max_depth; st->tree_T = T; }
@@ -1451,6 +1606,8 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
   if (ctx->leader && total_token > 32) return fail("a cohort member owns one 32-row activation tile: total_token <= 32");
+  for (const vispec_ctx* m : ctx->members)
+    if (m && total_token > 32) return fail("a leader with live cohort members owns one 32-row activation tile: total_token <= 32");
   ctx->c.total_token = total_token;
   // (the tree size is part of every graph key: the captured launch sequences depend on it)
   return 0;
@@ -1499,7 +1656,7 @@ extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
   return run_graphed(ctx, s, ctx->g_ar, graph_key(ctx, -1, false), [&]() {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
     KCHK();
-    const Cohort co{1, {ctx, nullptr}};
+    const Cohort co = solo_cohort(ctx);
     if (target_forward(co, s, 1)) return -1;
     return target_accept(co, s, 1, -1);
   });

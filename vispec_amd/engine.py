@@ -223,8 +223,9 @@ class Engine:
     def __init__(self, tcfg: TargetConfig, dcfg: DraftConfig, tw: TargetWeights, dw: DraftWeightsDev, total_token=30, depth=3,
                  top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None,
                  target_weight_dtype: str = "bf16", leader: Optional["Engine"] = None):
-        """leader: build this engine as a COHORT MEMBER of `leader` (same configs and weights): its activation workspaces alias the
-        leader's second 32-row tiles, so `leader.cohort_round(self)` runs both requests' rounds on one weight pass."""
+        """leader: build this engine as a COHORT MEMBER of `leader` (same configs and weights): its activation workspaces alias one
+        32-row tile of the leader's (up to three members per leader), so `leader.cohort_round([members...])` runs all their rounds on one
+        weight pass."""
         if eager_scores is None:
             eager_scores = tcfg.attn_impl == "eager"
         if not torch.cuda.is_available():
@@ -381,11 +382,14 @@ class Engine:
     def draft_round(self):
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
 
-    def cohort_round(self, member: "Engine", forced_accept: int = -1):
-        """One draft-and-verify round of TWO requests (this engine's and `member`'s, created with leader=self) on one weight pass."""
+    def cohort_round(self, members, forced_accept: int = -1):
+        """One draft-and-verify round of 2..4 requests (this engine's and its members', created with leader=self) on one weight pass."""
+        members = [members] if isinstance(members, Engine) else list(members)
+        hs = [self] + members
+        arr = (C.c_void_p * len(hs))(*[e.h.value for e in hs])
         st = self._stream()
-        L.check(self.lib.vispec_cohort_verify_accept(self.h, member.h, st, int(forced_accept)))
-        L.check(self.lib.vispec_cohort_draft_round(self.h, member.h, st))
+        L.check(self.lib.vispec_cohortn_verify_accept(arr, len(hs), st, int(forced_accept)))
+        L.check(self.lib.vispec_cohortn_draft_round(arr, len(hs), st))
 
     def set_total_token(self, total_token: int):
         L.check(self.lib.vispec_set_total_token(self.h, int(total_token)))

@@ -76,6 +76,9 @@ SIGNATURES = {
     "vispec_draft_round": (c_int, [P, P]),
     "vispec_cohort_verify_accept": (c_int, [P, P, P, c_int]),
     "vispec_cohort_draft_round": (c_int, [P, P, P]),
+    "vispec_cohortn_verify_accept": (c_int, [P, c_int, P, c_int]),
+    "vispec_cohortn_draft_round": (c_int, [P, c_int, P]),
+    "vispec_gemm_cohort": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),
     "vispec_sample_row": (c_int, [P, P, P, c_int, P]),

@@ -429,30 +429,33 @@ class SpecModel:
 @torch.no_grad()
 def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
                         forced_accept=None):
-    """Two independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
+    """Two to four independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
 
-    models   = [leader, member]  (member built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
-    requests = [(input_ids [1,L], specgenerate kwargs), (input_ids, kwargs)]; max_new_tokens may be a pair (one budget per request)
+    models   = [leader, member, ...]  (members built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
+    requests = [(input_ids [1,L], specgenerate kwargs), ...] one per model; max_new_tokens may be a list (one budget per request)
     Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — exactly what
     `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` returns for that request alone, token for token: the prefills run
-    per request, every decode round launches each GEMM once on both requests' rows (Engine.cohort_round), and a request that finishes
-    first is frozen on the device while the other completes."""
-    if len(models) != 2 or len(requests) != 2:
-        raise ValueError("a cohort is two models (leader, member) and two requests")
-    lead, memb = models
-    if memb.engine.leader is not lead.engine:
-        raise ValueError("models[1] must have been built with cohort_leader=models[0]")
-    seeds = seeds or [0, 0]
-    budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens, max_new_tokens]  # per request
+    per request, every decode round launches each GEMM once on all requests' rows (Engine.cohort_round), and a request that finishes
+    first is frozen on the device while the others complete."""
+    n = len(models)
+    if not 2 <= n <= 4 or len(requests) != n:
+        raise ValueError("a cohort is 2..4 models (leader, members...) and one request per model")
+    lead = models[0]
+    for m in models[1:]:
+        if m.engine.leader is not lead.engine:
+            raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
+    seeds = seeds or [0] * n
+    budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * n  # per request
     for m, (ids, kw), sd, mx in zip(models, requests, seeds, budgets):
         m._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=sd, max_new_tokens=mx, is_llama3=is_llama3)
     rounds_cap = max_length - lead.spec_layer.total_tokens - 10  # :270
-    alive = [True, True]
+    alive = [True] * n
     final = [m.engine.state() for m in models]
-    idxs, accs = [0, 0], [[], []]
+    idxs, accs = [0] * n, [[] for _ in range(n)]
+    member_engines = [m.engine for m in models[1:]]
     for idx in range(rounds_cap):
         fa = -1 if forced_accept is None else int(forced_accept(idx))
-        lead.engine.cohort_round(memb.engine, fa)
+        lead.engine.cohort_round(member_engines, fa)
         for t, m in enumerate(models):
             if not alive[t]:
                 continue
