@@ -57,8 +57,8 @@ def log(*a):
 
 
 def build_models(device, seed, rank, world, lanes, cohort=1):
-    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2 every lane
-    also gets a cohort member (second request context on the same weight pass): returns [leader, member] lists then."""
+    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2..4 every lane
+    also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then."""
     from vispec_amd import parallel, synth_gpu
     from vispec_amd.engine import LLAVA_16_7B, DraftConfig, TargetConfig
     from vispec_amd.model import SpecModel
@@ -103,7 +103,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
         lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
-        sms.append([lead, lead.make_cohort_member()] if cohort == 2 else lead)
+        sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
 
 
@@ -321,8 +321,8 @@ def main():
     ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
     ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
-    ap.add_argument("--cohort", type=int, default=2, choices=(1, 2),
-                    help="requests per lane that run their rounds in lockstep on ONE weight pass (2 = every GEMM of a round serves two "
+    ap.add_argument("--cohort", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
@@ -365,8 +365,8 @@ def main():
     fp8 = MODEL.endswith("fp8")
     CO = args.cohort
     sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R, CO)
-    pairs = sms if CO == 2 else None
-    sms = [p[0] for p in sms] if CO == 2 else sms  # the leaders double as the single-request models of the annotation legs
+    pairs = sms if CO >= 2 else None
+    sms = [p[0] for p in sms] if CO >= 2 else sms  # the leaders double as the single-request models of the annotation legs
     sm = sms[0]
     eng = sm.engine
     K, W = args.steps, args.warmup
@@ -403,10 +403,10 @@ def main():
             with torch.cuda.stream(streams[lane]):
                 for s_ in range(lo, hi):
                     todo = list(plan[lane][s_])
-                    while CO == 2 and not ar and len(todo) >= 2:  # two requests per weight pass
-                        ia, ib = todo.pop(0), todo.pop(0)
-                        outs = specgenerate_cohort(pairs[lane], [get_req(ia), get_req(ib)], max_new_tokens=MAX_NEW,
-                                                   temperature=args.temperature, seeds=[ia, ib])
+                    while CO >= 2 and not ar and len(todo) >= 2:  # up to CO requests per weight pass
+                        now, todo = todo[:CO], todo[CO:]
+                        outs = specgenerate_cohort(pairs[lane][:len(now)], [get_req(i) for i in now], max_new_tokens=MAX_NEW,
+                                                   temperature=args.temperature, seeds=now)
                         for o, new_token, idx, acc in outs:
                             tok += int(new_token)
                             rnd += idx + 1
@@ -580,8 +580,9 @@ def main():
                     extra["cpu_baseline"]["config0_end_to_end"] = f"failed: {type(e).__name__}: {e}"[:300]
         per_step = (f"{args.requests} independent requests sharded round-robin over the {world} replica(s) and their lanes" if args.requests
                     else f"{CO} request{'s' if CO > 1 else ''} on each of {R} concurrent lanes per GPU")
-        if CO == 2:
-            per_step += " (every lane runs its two batch-1 requests in lockstep on one weight pass: each GEMM of a round is launched once for both)"
+        if CO >= 2:
+            per_step += (f" (every lane runs its {CO} batch-1 requests in lockstep on one weight pass: each GEMM of a round is launched once "
+                         f"for all of them)")
         line = {
             "metric": f"accepted output tokens/sec (ViSpec speculative decoding, {MODELS[MODEL]['name']} + ViSpec draft, T={args.temperature:g})",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,

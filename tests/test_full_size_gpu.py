@@ -93,6 +93,7 @@ def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
     got = specgenerate_cohort([sm, mb], reqs, max_new_tokens=64)
     for (toks, new_token, idx, acc), w in zip(got, want):
         assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3])
+    mb.engine.close()  # hands tile 1 back to the leader for the next test
     del mb
 
 
@@ -121,6 +122,7 @@ def test_ragged_cohort_at_full_size(model_full):
         wants = [want_long, want_short] if order == 0 else [want_short, want_long]
         for (toks, new_token, idx, acc), w in zip(got, wants):
             assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3])
+    mb.engine.close()  # hands tile 1 back to the leader for the next test
     del mb
 
 

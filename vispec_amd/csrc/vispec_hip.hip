@@ -239,7 +239,17 @@ extern "C" int vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* le
 
 extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->leader && ctx->slot >= 1 && ctx->leader->members[ctx->slot - 1] == ctx) ctx->leader->members[ctx->slot - 1] = nullptr;
+  if (ctx->leader && ctx->slot >= 1 && ctx->leader->members[ctx->slot - 1] == ctx) {
+    ctx->leader->members[ctx->slot - 1] = nullptr;
+    // the leader's cached cohort graphs bake this member's buffers in, and a later member may be allocated at this very address
+    // (the graph key compares ctx pointers): drop them with the member
+    for (auto* g : {&ctx->leader->g_cverify, &ctx->leader->g_cdraft})
+      if (g->exec) {
+        (void)hipGraphExecDestroy(g->exec);
+        g->exec = nullptr;
+        g->key = vispec_ctx::GraphKey();
+      }
+  }
   for (vispec_ctx* m : ctx->members)
     if (m) m->leader = nullptr;  // (a member must not outlive its leader's workspaces; it can no longer join a cohort)
   for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft})

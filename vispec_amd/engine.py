@@ -281,10 +281,15 @@ class Engine:
                     tw.codes8.append(cd)
                 q, s_ = quantize_fp8(tw.lm_head)
                 tw.p_lm_head8, tw.s_lm_head8, tw.c_lm_head8 = pack_weight_fp8(q), s_, q
-                tw.lm_head.copy_(q.view(torch.float8_e4m3fn).to(torch.bfloat16))
+                # a NEW tensor, never an in-place write: a tied checkpoint hands the same storage out as embed_tokens and lm_head
+                # (weights_io.py), and the embedding table must keep its real values
+                tw.lm_head = q.view(torch.float8_e4m3fn).to(torch.bfloat16)
                 tw.lm_head_scale = s_
         elif target_weight_dtype != "bf16":
             raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
+        if target_weight_dtype == "bf16" and hasattr(tw, "packed8"):
+            raise ValueError("these TargetWeights were quantised to fp8 by an earlier Engine (their row-major tensors now hold e4m3 codes + "
+                             "scales): build bf16 engines on their own TargetWeights")
         if target_weight_dtype == "bf16" and not hasattr(tw, "packed"):
             nrh = tcfg.num_heads + tcfg.num_kv_heads
             order = lambda k, w: qkv_rope_order(w, nrh) if k == "wqkv" else (swiglu_order(w) if k == "wgu" else w)
@@ -314,11 +319,16 @@ class Engine:
                                     dtype=torch.bfloat16, device=self.device)
         L.check(self.lib.vispec_set_kv(self.h, _p(self.target_kv), _p(self.draft_kv)))
 
+    def close(self):
+        """Destroy the library context now (idempotent).  A cohort member gives its activation tile back to its leader — garbage collection
+        alone is not prompt enough for that: the model objects around an engine hold reference cycles."""
+        if getattr(self, "h", None):
+            self.lib.vispec_ctx_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.vispec_ctx_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
