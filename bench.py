@@ -321,7 +321,7 @@ def main():
     ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
     ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
-    ap.add_argument("--cohort", type=int, default=2, choices=(1, 2, 3, 4),
+    ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--requests", type=int, default=0,

@@ -126,18 +126,19 @@ def test_ragged_cohort_at_full_size(model_full):
     del mb
 
 
-def test_default_bench_configuration_reproduces_single_request_tokens():
-    """The configuration bench.py's headline line runs — 4 concurrent lanes (host threads + streams, one weight copy) x cohorts of 2 at
-    the LLaVA-7B sizes — against the same 16 requests run ONE AT A TIME on one stream: every request's tokens, round count and accept
-    lengths must be identical (concurrency and weight-pass sharing change throughput, never a token)."""
+@pytest.mark.parametrize("CO", [4, 2])
+def test_default_bench_configuration_reproduces_single_request_tokens(CO):
+    """The configuration bench.py's headline line runs — 4 concurrent lanes (host threads + streams, one weight copy) x cohorts of 4 (and
+    round 2's cohorts of 2) at the LLaVA-7B sizes — against the same requests run ONE AT A TIME on one stream: every request's tokens,
+    round count and accept lengths must be identical (concurrency and weight-pass sharing change throughput, never a token)."""
     import gc
     import bench
     from vispec_amd.model.spec_model_ours import specgenerate_cohort
     bench.MODEL = "llava7b"
     dev = torch.device("cuda:0")
-    R, STEPS, NEW = 4, 2, 72
-    pairs, tcfg, _ = bench.build_models(dev, 0, 0, 1, R, 2)
-    reqs = {i: bench.make_request(tcfg, 100 + i, dev) for i in range(2 * R * STEPS)}
+    R, STEPS, NEW = 4, 2 if CO == 2 else 1, 72
+    pairs, tcfg, _ = bench.build_models(dev, 0, 0, 1, R, CO)
+    reqs = {i: bench.make_request(tcfg, 100 + i, dev) for i in range(CO * R * STEPS)}
     streams = [torch.cuda.Stream(dev) for _ in range(R)]
     torch.cuda.synchronize()
 
@@ -147,9 +148,9 @@ def test_default_bench_configuration_reproduces_single_request_tokens():
             out = {}
             with torch.cuda.stream(streams[l]):
                 for s_ in range(STEPS):
-                    ia, ib = (s_ * R + l) * 2, (s_ * R + l) * 2 + 1
-                    got = specgenerate_cohort(pairs[l], [reqs[ia], reqs[ib]], max_new_tokens=NEW, seeds=[ia, ib])
-                    out[ia], out[ib] = got
+                    mine = [(s_ * R + l) * CO + j for j in range(CO)]
+                    got = specgenerate_cohort(pairs[l], [reqs[i] for i in mine], max_new_tokens=NEW, seeds=mine)
+                    out.update(zip(mine, got))
                 streams[l].synchronize()
             return out
         return f

@@ -56,7 +56,8 @@ __device__ __forceinline__ void wide_wait_barrier() {  // own DMAs landed (N you
 
 // NL = live activation tiles (requests) — a template parameter: runtime guards around the MFMAs made hipcc branch around every
 // one of them and keep the accumulators in scratch memory.
-template <int EPI, bool W8, int NL>
+// DBG (measurement only, wrong results): 1 = no activation DMAs, 2 = no weight loads
+template <int EPI, bool W8, int NL, int DBG = 0>
 __global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                              const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                              const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,
@@ -115,9 +116,12 @@ __global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __res
     ro[t] = rrow + ((sseg ^ fsw) << 4);
   }
   u32x4_t w[LOADS];
+  constexpr int QW = DBG == 2 ? 0 : LOADS, QX = DBG == 1 ? 0 : NL;  // weight loads / activation DMAs in flight per group and wave
 #define WIDE_DMA(grp, buf)                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < NL; ++i)                                                                \
-      wide_dma16(xoff[i], xsrc + (size_t)(grp) * 128, xdst[i] + (buf) * WIDE_BUFBYTES);
+  if constexpr (DBG != 1) {                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NL; ++i)                                                              \
+        wide_dma16(xoff[i], xsrc + (size_t)(grp) * 128, xdst[i] + (buf) * WIDE_BUFBYTES);                       \
+  }
   // one k-step (one weight tile register) against the NL staged activation tiles
 #define WIDE_MFMA(u, xb)                                                                                        \
   if constexpr (!W8) {                                                                                          \
@@ -137,13 +141,13 @@ __global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __res
   }
 #define WIDE_STEP_PREF(u)                                                                                       \
   if constexpr ((u) < LOADS) {                                                                                            \
-    wide_wait_vm<LOADS - 1 + NL>(w[(u) < LOADS ? (u) : 0]);                                                     \
+    if constexpr (QW > 0) wide_wait_vm<(QW > 0 ? QW - 1 : 0) + QX>(w[(u) < LOADS ? (u) : 0]);                   \
     WIDE_MFMA((u) < LOADS ? (u) : 0, xb)                                                                        \
-    wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[(u) < LOADS ? (u) : 0], wvo, wn);                             \
+    if constexpr (QW > 0) wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[(u) < LOADS ? (u) : 0], wvo, wn);       \
   }
 #define WIDE_STEP_LAST(u)                                                                                       \
   if constexpr ((u) < LOADS) {                                                                                            \
-    wide_wait_vm<((u) < LOADS ? LOADS - 1 - (u) : 0)>(w[(u) < LOADS ? (u) : 0]);                                \
+    if constexpr (QW > 0) wide_wait_vm<((u) < LOADS ? LOADS - 1 - (u) : 0)>(w[(u) < LOADS ? (u) : 0]);          \
     WIDE_MFMA((u) < LOADS ? (u) : 0, xb)                                                                        \
   }
   if (G > 0) {
@@ -154,8 +158,9 @@ __global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __res
       wide_load_w<2048>(w[LOADS > 2 ? 2 : 0], wvo, wsrc);
       wide_load_w<3072>(w[LOADS > 2 ? 3 : 0], wvo, wsrc);
     }
+    if constexpr (DBG == 2) wide_wait_vm<QX>(w[0]);  // (the first group's tiles stay in the registers for the whole run)
   }
-  if (Gmax > 0) wide_wait_barrier<LOADS>();  // (a quarter without groups has nothing in flight: the count is harmless)
+  if (Gmax > 0) wide_wait_barrier<QW>();  // (a quarter without groups has nothing in flight: the count is harmless)
   // single-path loop body (an if / else-if / else around the two unrolled bodies made hipcc shuffle the accumulators through scratch):
   // steady-state groups, then the quarter's last group, then barrier-only rounds so that every wave of the workgroup executes the same
   // number of s_barrier whatever its quarter's group count (the quarters share nothing but the rendezvous itself)
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(1024) void gemm_w32_wide_kernel(const bf16_t* __res
     const unsigned char* wn = wsrc + (size_t)(g + 1) * (LOADS * 1024);
     WIDE_DMA(g + 1, (g + 1) & 1)  // that buffer was last read before the previous barrier
     WIDE_STEP_PREF(0) WIDE_STEP_PREF(1) WIDE_STEP_PREF(2) WIDE_STEP_PREF(3)
-    wide_wait_barrier<LOADS>();
+    wide_wait_barrier<QW>();
   }
   if (G > 0) {  // the quarter's last group: nothing left to fetch
     const unsigned char* xb = xq + ((G - 1) & 1) * WIDE_BUFBYTES;

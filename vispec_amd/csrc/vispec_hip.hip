@@ -221,7 +221,8 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_>,                   \
       (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_>,              \
       (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_>
-    const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4)};
+    const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4),
+                          (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>};
 #undef WIDE_ALL_EPI
     for (const void* f : wide)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES) != hipSuccess) (void)hipGetLastError();
@@ -860,7 +861,13 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
-    if (M > 96)
+    if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    else if (M > 96 && unc == 2)
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    else if (M > 96)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else

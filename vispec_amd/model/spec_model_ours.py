@@ -428,7 +428,7 @@ class SpecModel:
 
 @torch.no_grad()
 def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
-                        forced_accept=None):
+                        forced_accept=None, stats=None):
     """Two to four independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
 
     models   = [leader, member, ...]  (members built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
@@ -436,7 +436,8 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — exactly what
     `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` returns for that request alone, token for token: the prefills run
     per request, every decode round launches each GEMM once on all requests' rows (Engine.cohort_round), and a request that finishes
-    first is frozen on the device while the others complete."""
+    first is frozen on the device while the others complete.  `stats` (a dict, optional) receives the wall time of the round loop
+    (`decode_s`, bracketed by synchronisations like specgenerate's return_decode_time) and the number of lockstep rounds (`rounds`)."""
     n = len(models)
     if not 2 <= n <= 4 or len(requests) != n:
         raise ValueError("a cohort is 2..4 models (leader, members...) and one request per model")
@@ -453,6 +454,9 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     final = [m.engine.state() for m in models]
     idxs, accs = [0] * n, [[] for _ in range(n)]
     member_engines = [m.engine for m in models[1:]]
+    if stats is not None:
+        torch.cuda.current_stream().synchronize()
+        t_loop = time.time()
     for idx in range(rounds_cap):
         fa = -1 if forced_accept is None else int(forced_accept(idx))
         lead.engine.cohort_round(member_engines, fa)
@@ -470,6 +474,9 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
                 alive[t] = False
         if not any(alive):
             break
+    if stats is not None:
+        torch.cuda.current_stream().synchronize()
+        stats.update(decode_s=time.time() - t_loop, rounds=idx + 1)
     outs = []
     for t, m in enumerate(models):
         n_ctx = final[t]["n_ctx"]
