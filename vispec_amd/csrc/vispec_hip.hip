@@ -489,7 +489,7 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
   const int M = 32 * (n_req - 1) + o.m_tile;
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
-  PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r,   \
+  PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r,   \
           o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
 #define WIDE_D(EPI_, YPTR, LDY, SPLITS)                                                                       \
   do {                                                                                                        \
@@ -862,16 +862,16 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
     if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96 && unc == 2)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     KCHK();
     return 0;
