@@ -103,6 +103,8 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
         lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
+        if lanes == 1:
+            lead.engine.set_wide_row_blocks(0)  # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it
         sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
 

@@ -25,11 +25,15 @@ from test_loop_gpu import IMG_TOK, build  # noqa: E402
                                  (32064, 512), (22016 // 2, 4096)])
 @pytest.mark.parametrize("n_req,m_tile", [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi):
+@pytest.mark.parametrize("row_blocks", [4, 2])
+def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi, row_blocks):
     if epi == 2 and N % 16:
         pytest.skip("SwiGLU needs N % 16 == 0")
     if N * K > 2e7 and (m_tile not in (30,) or epi == 1):
         pytest.skip("large shapes: the bench configurations only")
+    if row_blocks == 2 and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1)):
+        pytest.skip("two row blocks per workgroup: the bench row counts and a one-row tile")
+    L.check(lib.vispec_set_wide_row_blocks(engine.h, row_blocks))
     rng = np.random.default_rng(N + 3 * K + 17 * n_req + m_tile + epi)
     rows = 2 * N if epi == 2 else N
     x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
@@ -47,12 +51,14 @@ def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engi
         got, want = Y[32 * t:32 * t + 32].view(torch.int16).cpu().numpy(), Y1.view(torch.int16).cpu().numpy()
         np.testing.assert_array_equal(got[:m_tile], want[:m_tile], err_msg=f"request {t}")
         assert (Y[32 * t + m_tile:32 * t + 32].float() == 7.0).all(), "padding rows of a tile must stay untouched"
+    L.check(lib.vispec_set_wide_row_blocks(engine.h, 4))
 
 
 @pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008)])
 @pytest.mark.parametrize("n_req", [3, 4])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, epi):
+@pytest.mark.parametrize("row_blocks", [4, 0])
+def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, epi, row_blocks):
     from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
     if epi == 2 and N % 16:
         pytest.skip("SwiGLU needs N % 16 == 0")
@@ -67,7 +73,9 @@ def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, 
     P8 = pack_weight_fp8(swiglu_order(q_u8) if epi == 2 else q_u8)
     X, B, R = tb(x), tb(b), tb(r)
     Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_set_wide_row_blocks(engine.h, row_blocks))
     L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+    L.check(lib.vispec_set_wide_row_blocks(engine.h, 4))
     for t in range(n_req):
         Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
         Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
@@ -83,6 +91,7 @@ def single(sm, ids, kw, **gen):
 @pytest.mark.parametrize("n_req", [3, 4])
 def test_cohort_of_three_and_four_equals_the_single_requests(golden_dir, n_req):
     sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    sm.engine.set_wide_row_blocks(0 if n_req == 3 else 4)  # both launch shapes of the wide GEMMs go through a whole request loop
     members = [sm.make_cohort_member() for _ in range(n_req - 1)]
     rng = np.random.default_rng(91)
     g = np.load(os.path.join(golden_dir, "g8_loop.npz"))

@@ -71,7 +71,7 @@ struct vispec_ctx {
   // argument or shapes the launch sequence — compared field by field (a hashed single integer could collide and replay a graph
   // with the wrong sampling parameters).
   struct GraphKey {
-    int n_req = 0, forced_accept = 0, total_token = 0;
+    int n_req = 0, forced_accept = 0, total_token = 0, wide_rb = 0;
     // per request of the (cohort) round, leader first.  `who` = the ctx itself: a captured graph bakes that request's pointers in
     // (state, tree, KV, selections ...), so the same leader with a DIFFERENT member set must not replay it.
     const void* who[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -79,7 +79,8 @@ struct vispec_ctx {
     float temperature[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned long long seed[4] = {0, 0, 0, 0};
     bool operator==(const GraphKey& o) const {
-      return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && memcmp(who, o.who, sizeof(who)) == 0 &&
+      return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && wide_rb == o.wide_rb &&
+             memcmp(who, o.who, sizeof(who)) == 0 &&
              memcmp(n_hint, o.n_hint, sizeof(n_hint)) == 0 && memcmp(sample_top_k, o.sample_top_k, sizeof(sample_top_k)) == 0 &&
              memcmp(temperature, o.temperature, sizeof(temperature)) == 0 && memcmp(seed, o.seed, sizeof(seed)) == 0;
     }
@@ -93,6 +94,7 @@ struct vispec_ctx {
   int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
   unsigned long long seed = 0;
   bool use_graphs = true;
+  int wide_rb = 4;                  // weight row blocks per workgroup of the wide-cohort GEMM: 4, 2, or 0 = two where four leave half the CUs idle
   long graph_replays = 0, graph_captures = 0, direct_runs = 0;
   std::vector<void*> allocs;
 };
@@ -217,13 +219,15 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     (void)hipGetLastError();  // a device-less build/load check must still be able to create nothing; report lazily
   }
   {  // the wide-cohort GEMM declares 132 KiB of dynamic LDS
-#define WIDE_ALL_EPI(W8_, NL_)                                                                                                      \
-  (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_>,                   \
-      (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_>,              \
-      (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_>
+#define WIDE_ALL_EPI_RB(W8_, NL_, RB_)                                                                                              \
+  (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_, 0, RB_>,   \
+      (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_, 0, RB_>, \
+      (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_, 0, RB_>
+#define WIDE_ALL_EPI(W8_, NL_) WIDE_ALL_EPI_RB(W8_, NL_, 4), WIDE_ALL_EPI_RB(W8_, NL_, 2)
     const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4),
                           (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>};
 #undef WIDE_ALL_EPI
+#undef WIDE_ALL_EPI_RB
     for (const void* f : wide)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES) != hipSuccess) (void)hipGetLastError();
   }
@@ -488,9 +492,21 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
   const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
   const int M = 32 * (n_req - 1) + o.m_tile;
+  // Row blocks per workgroup (vispec_set_wide_row_blocks): four = one byte of X per byte of W, the form for a GPU that several lanes
+  // keep full; two = twice the workgroups at twice the X traffic, which pays on a single stream where four row blocks leave half
+  // of the CUs without a workgroup (0 = two exactly there).  tools/wide_bench.py; one cohort lane 9.5 -> 8.7 ms per round with 0,
+  // four lanes 2064 -> 1980 tok/s.
+  const int rb_opt = ctx ? ctx->wide_rb : 4;
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
-  PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r,   \
-          o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
+  do {                                                                                                                                  \
+    const bool rb2_ = rb_opt == 2 || (rb_opt == 0 && ((tiles + 3) / 4) * (SPLITS) <= 128);                                              \
+    if (rb2_)                                                                                                                           \
+      PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_, 0, 2>), dim3((tiles + 1) / 2, SPLITS), dim3(512), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r, \
+              o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                                    \
+    else                                                                                                                                \
+      PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r, \
+              o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                                    \
+  } while (0)
 #define WIDE_D(EPI_, YPTR, LDY, SPLITS)                                                                       \
   do {                                                                                                        \
     if (o.wscale) { if (n_req == 3) WIDE_L(EPI_, true, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, true, 4, YPTR, LDY, SPLITS); }     \
@@ -693,7 +709,10 @@ static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int l
   if (tail < 0 || tail > 64) return fail("tree_attention: tail must be in [0,64]");
   const int MT = (M + 31) / 32, NQT = (H / H_kv) * MT;
   static const int kpw_env = getenv("VISPEC_ATT_KPW") ? atoi(getenv("VISPEC_ATT_KPW")) : 0;  // tuning experiments only
-  int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : 256;
+  // 512 keys (four 128-key chunks) per workgroup: round 2 ran 256; with the four requests of a wide cohort in one launch the 256-key
+  // grid is three rounds of workgroups per CU slot and twice the partial tiles to merge (4 lanes x cohort 4: 1980 -> 2070 tok/s; one
+  // request alone: 5.29 -> 5.21 ms per round)
+  int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : 512;
   if (max_keys < 1) max_keys = 1;
   if (max_keys > s_max) max_keys = s_max;
   // keys per workgroup from the CACHE CAPACITY, never from the requests' current lengths: the split boundaries (and with them the order in
@@ -861,17 +880,20 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
-    if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+    if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 2>), dim3((tiles + 1) / 2, S), dim3(512), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    else if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96 && unc == 2)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96)
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else
-      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(WIDE_THREADS), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     KCHK();
     return 0;
@@ -1041,6 +1063,7 @@ static vispec_ctx::GraphKey graph_key_n(vispec_ctx* const* ctxs, int n, int forc
   k.n_req = n;
   k.forced_accept = forced_accept;
   k.total_token = ctxs[0]->c.total_token;
+  k.wide_rb = ctxs[0]->wide_rb;
   for (int t = 0; t < n; ++t) {
     const vispec_ctx* ctx = ctxs[t];
     const bool sampling = ctx->temperature > 1e-5f;
@@ -1059,6 +1082,12 @@ static vispec_ctx::GraphKey graph_key(vispec_ctx* ctx, int forced_accept, bool s
 extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
   if (!ctx || !out3) return fail("null");
   out3[0] = ctx->graph_replays; out3[1] = ctx->graph_captures; out3[2] = ctx->direct_runs;
+  return 0;
+}
+extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
+  if (!ctx) return fail("null ctx");
+  if (row_blocks != 0 && row_blocks != 2 && row_blocks != 4) return fail("wide_row_blocks: 4, 2, or 0 (= two where four leave half of the CUs idle)");
+  ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
 extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {

@@ -437,6 +437,10 @@ class Engine:
     def set_graphs(self, on: bool):
         L.check(self.lib.vispec_set_graphs(self.h, int(on)))
 
+    def set_wide_row_blocks(self, row_blocks: int):
+        """Launch shape of a 3-4 request cohort's GEMMs (leader only): 4 = default (several lanes per GPU), 0 = best for ONE lane."""
+        L.check(self.lib.vispec_set_wide_row_blocks(self.h, int(row_blocks)))
+
     def graph_stats(self) -> Dict[str, int]:
         out = (C.c_longlong * 3)()
         L.check(self.lib.vispec_graph_stats(self.h, out))

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vispec_get_accept_log_host": (c_int, [P, P, P, c_int]),
     "vispec_get_tree_host": (c_int, [P, P, P, P, P, P, P, P]),
     "vispec_set_graphs": (c_int, [P, c_int]),
+    "vispec_set_wide_row_blocks": (c_int, [P, c_int]),
     "vispec_graph_stats": (c_int, [P, P]),
     "vispec_prof_enable": (c_int, [P, c_int]),
     "vispec_prof_report_host": (c_int, [P, P, P, c_int]),
