@@ -481,7 +481,47 @@ def main():
                        round_GBps=round(b_round / (ms_round * 1e-3) / 1e9, 1),
                        round_roofline_frac_of_8TBps=round(b_round / (ms_round * 1e-3) / 8e12, 4))
             extra["speedpy_comparable"] = spc
-            # ---- roofline leg: one more request with per-kernel device timestamps around every skinny-GEMM / attention launch
+            # ---- roofline legs: per-kernel device timestamps around every skinny-GEMM / attention launch (hipExtLaunchKernel events on the
+            #      launch stream), (1) of one more single request, (2) with cohorts, of one cohort of the timed region's size: the kernels the
+            #      timed region actually runs (each GEMM launch then serves CO requests with ONE pass over the weight)
+            def price(rep):
+                pf_ = rep.pop("gemm_prefill_mfma", None)
+                gemm_ = {k: v for k, v in rep.items() if k.startswith("gemm") and v["bytes"] > 0}
+                # dominant kernel = the instantiation that moves the most bytes per round (it is also the one with the largest total
+                # duration in the rocprofv3 summary under profiles/)
+                dom_ = max(gemm_, key=lambda k: gemm_[k]["bytes"])
+                return pf_, gemm_, dom_
+
+            def roofline_of(rep, gemm_, dom_, keys, note):
+                d = gemm_[dom_]
+                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                all_b = sum(v["bytes"] for v in gemm_.values())
+                all_ms = sum(v["ms"] for v in gemm_.values())
+                # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
+                # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
+                traffic = None
+                try:
+                    if MODEL != "llava7b":
+                        raise KeyError("the committed PMC pass was collected on the headline config only")
+                    import glob
+                    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")))[-1]
+                    pmc = json.load(open(pmc_file))
+                    key = keys.get(dom_)
+                    for k, v in pmc.items():
+                        if key and key in k:
+                            traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
+                except Exception:
+                    pass
+                return dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
+                            kernel=f"{dom_} ({keys.get(dom_, '?')})", what=note, launches=int(d["launches"]),
+                            avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                            algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                            timing="device begin/end timestamps of each dispatch (hipExtLaunchKernel events) on the launch stream",
+                            all_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
+                            by_kernel={k: dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                                               GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                               frac=round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4)) for k, v in rep.items() if v["bytes"] > 0})
+
             torch.cuda.synchronize()
             eng.prof_enable(True)
             out_p, new_token_p, idx_p, acc_p, t_dec = sm.specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
@@ -489,44 +529,32 @@ def main():
             rep = eng.prof_report()
             eng.prof_enable(False)
             # the draft prefill's big-M GEMM is MFMA-bound: the library records its FLOPs, reported on their own below
-            pf = rep.pop("gemm_prefill_mfma", None)
-            gemm = {k: v for k, v in rep.items() if k.startswith("gemm") and v["bytes"] > 0}
-            # dominant kernel = the instantiation that moves the most bytes per round (it is also the one with the largest total
-            # duration in the rocprofv3 summary under profiles/)
-            dom = max(gemm, key=lambda k: gemm[k]["bytes"])
-            d = gemm[dom]
-            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            all_b = sum(v["bytes"] for v in gemm.values())
-            all_ms = sum(v["ms"] for v in gemm.values())
-            # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
-            # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
-            traffic = None
-            try:
-                if MODEL != "llava7b":
-                    raise KeyError("the committed PMC pass was collected on the headline config only")
-                import glob
-                pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")))[-1]
-                pmc = json.load(open(pmc_file))
-                key = PROF_KERNEL_KEYS.get(dom)
-                for k, v in pmc.items():
-                    if key and key in k:
-                        traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
-            except Exception:
-                pass
-            extra["roofline"] = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
-                                     kernel=f"{dom} ({PROF_KERNEL_KEYS.get(dom, '?')})", launches=int(d["launches"]),
-                                     avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
-                                     algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                                     timing="device begin/end timestamps of each dispatch (hipExtLaunchKernel events) on the launch stream",
-                                     all_skinny_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
-                                     by_kernel={k: dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
-                                                        GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                                        frac=round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4)) for k, v in rep.items() if v["bytes"] > 0})
+            pf, gemm, dom = price(rep)
+            single_roof = roofline_of(rep, gemm, dom, PROF_KERNEL_KEYS, "one request per launch (the instrumented single-request leg)")
             if pf:
-                extra["roofline"]["prefill_gemm_mfma"] = dict(launches=int(pf["launches"]), avg_launch_us=round(1e3 * pf["ms"] / pf["launches"], 2),
-                                                              TFLOPs=round(pf["bytes"] / (pf["ms"] * 1e-3) / 1e12, 1), peak=2500.0,
-                                                              frac=round(pf["bytes"] / (pf["ms"] * 1e-3) / 2.5e15, 4),
-                                                              note="draft prefill (image K/V projection, text fusion GEMMs): once per request, outside the round loop")
+                single_roof["prefill_gemm_mfma"] = dict(launches=int(pf["launches"]), avg_launch_us=round(1e3 * pf["ms"] / pf["launches"], 2),
+                                                        TFLOPs=round(pf["bytes"] / (pf["ms"] * 1e-3) / 1e12, 1), peak=2500.0,
+                                                        frac=round(pf["bytes"] / (pf["ms"] * 1e-3) / 2.5e15, 4),
+                                                        note="draft prefill (image K/V projection, text fusion GEMMs): once per request, outside the round loop")
+            if CO >= 2:
+                now = list(plan[0][W])[:CO]
+                st_c = {}
+                eng.prof_enable(True)
+                with torch.cuda.stream(streams[0]):
+                    specgenerate_cohort(pairs[0][:len(now)], [get_req(i) for i in now], max_new_tokens=MAX_NEW, temperature=args.temperature,
+                                        seeds=now, stats=st_c)
+                rep_c = eng.prof_report()
+                eng.prof_enable(False)
+                rep_c.pop("gemm_prefill_mfma", None)
+                _, gemm_c, dom_c = price(rep_c)
+                keys_c = PROF_KERNEL_KEYS_WIDE if CO >= 3 else PROF_KERNEL_KEYS_PAIRED
+                extra["roofline"] = roofline_of(rep_c, gemm_c, dom_c, keys_c,
+                                                f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps): "
+                                                f"algorithmic bytes = the weight once, whatever the number of requests it serves")
+                extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
+                extra["roofline_single_request"] = single_roof
+            else:
+                extra["roofline"] = single_roof
             extra["round"] = dict(rounds_per_s=round(rounds / dt, 2), kernel_ms_per_round={k: round(v["ms"] / (idx_p + 1), 4) for k, v in rep.items()},
                                   note="kernel_ms_per_round comes from the instrumented (un-graphed) request and only splits the round by kernel; "
                                        "the round's own time and roofline fraction are speedpy_comparable.ms_per_round / round_roofline_frac_of_8TBps")
@@ -606,9 +634,15 @@ def main():
 
 
 # library profiling kinds -> the kernel instantiation they time (names as they appear in the rocprofv3 summaries under profiles/)
+PROF_KERNEL_KEYS_WIDE = {"gemm_none": "gemm_w32_wide_kernel<0,", "gemm_residual": "gemm_w32_wide_kernel<1,", "gemm_swiglu": "gemm_w32_wide_kernel<2,",
+                         "gemm_splitk_partial": "gemm_w32_wide_kernel<3,", "gemm_qkv_rope": "gemm_w32_wide_kernel<4,",
+                         "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
+PROF_KERNEL_KEYS_PAIRED = {"gemm_none": "gemm_w32_kernel<2, 0,", "gemm_residual": "gemm_w32_kernel<2, 1,", "gemm_swiglu": "gemm_w32_kernel<2, 2,",
+                           "gemm_splitk_partial": "gemm_w32_kernel<2, 3,", "gemm_qkv_rope": "gemm_w32_kernel<2, 4,",
+                           "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
 PROF_KERNEL_KEYS = {"gemm_none": "gemm_w32_kernel<1, 0,", "gemm_residual": "gemm_w32_kernel<1, 1,", "gemm_swiglu": "gemm_w32_kernel<1, 2,",
                     "gemm_splitk_partial": "gemm_w32_kernel<1, 3,", "gemm_qkv_rope": "gemm_w32_kernel<1, 4,",
-                    "attn_partial": "tree_attn_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
+                    "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
 
 
 if __name__ == "__main__":

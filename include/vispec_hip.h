@@ -230,6 +230,8 @@ int vispec_ar_step(vispec_ctx*, void* stream);
 /* Blocking read-back of the round state: out[0]=n_ctx, [1]=new_token, [2]=rounds, [3]=done(eos|max_new), [4]=last accept_len,
    [5]=next_token, [6]=draft kv len, [7]=n_leaf of current tree. */
 int vispec_get_state_host(vispec_ctx*, void* stream, int* out8_host);
+/* ... of every request of a cohort (leader first) with one synchronisation: out = n x 8 ints */
+int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void* stream, int* out8n_host);
 /* (best_candidate, accept_length) of the last accept — what evaluate_posterior returns (utils.py:451,493); blocking */
 int vispec_get_last_accept_host(vispec_ctx*, void* stream, int* out2_host);
 /* Blocking copies of device-side logs/buffers, for the API mirror and the tests. */

@@ -41,6 +41,36 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// One launch for the same small kernel of every request of a cohort (top-k, tree bookkeeping, accept, compaction, gathers: single-
+// or few-workgroup kernels whose cost is the launch itself — 72 of them per four-request round when issued request by request).
+// Each such kernel is written as a __device__ body + a functor `<name>_fn`; batch4_kernel runs the body with the argument pack of
+// request blockIdx.z.  The arithmetic is the body's, so a batched request computes exactly what its own launch would.
+// ------------------------------------------------------------------------------------------------
+template <class... Ts> struct ArgPack;
+template <> struct ArgPack<> {};
+template <class T, class... Ts> struct ArgPack<T, Ts...> { T v; ArgPack<Ts...> rest; };
+static inline ArgPack<> make_pack() { return ArgPack<>{}; }
+template <class T, class... Ts> static inline ArgPack<T, Ts...> make_pack(T a, Ts... r) {
+  ArgPack<T, Ts...> p;
+  p.v = a;
+  p.rest = make_pack(r...);
+  return p;
+}
+template <class F, class... Us> __device__ __forceinline__ void pack_apply(F f, const ArgPack<>&, Us... a) { f(a...); }
+template <class F, class T, class... Ts, class... Us>
+__device__ __forceinline__ void pack_apply(F f, const ArgPack<T, Ts...>& p, Us... a) { pack_apply(f, p.rest, a..., p.v); }
+template <class P> struct Packs4 { P p[4]; };
+template <class Fn, int TPB, class P>
+__global__ __launch_bounds__(TPB) void batch4_kernel(Packs4<P> a) {
+  const int z = blockIdx.z;  // (selected with compares: a dynamically indexed kernel argument would be copied to scratch; ONE call
+  P p = a.p[0];              //  site: a body's static __shared__ arrays must not be instantiated four times)
+  if (z == 1) p = a.p[1];
+  else if (z == 2) p = a.p[2];
+  else if (z == 3) p = a.p[3];
+  pack_apply(Fn{}, p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Device-resident round state: nothing here ever needs the host between rounds.
 // ------------------------------------------------------------------------------------------------
 struct DevState {
@@ -659,7 +689,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 
 // Token embedding rows + the first layer's input RMSNorm in one launch (modeling_llama_kv.py:985 + :104-133): X[i] = table[ids[i]],
 // Y[i] = w * bf16(X[i] * rsqrt(mean(X[i]^2) + eps)).  One workgroup per row.
-__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __restrict__ table, const int* __restrict__ ids, bf16_t* __restrict__ X,
+__device__ __forceinline__ void embed_rmsnorm_body(const bf16_t* __restrict__ table, const int* __restrict__ ids, bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ w, bf16_t* __restrict__ Y, int D, float eps) {
   __shared__ float part[4];
   const bf16_t* x = table + (size_t)ids[blockIdx.x] * D;
@@ -692,6 +722,11 @@ __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __rest
     *reinterpret_cast<uint4*>(y + d) = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
   }
 }
+__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const bf16_t* __restrict__ table, const int* __restrict__ ids, bf16_t* __restrict__ X,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ Y, int D, float eps) { embed_rmsnorm_body(table, ids, X, w, Y, D, eps); }
+struct embed_rmsnorm_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { embed_rmsnorm_body(a...); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Tree-masked attention, flash-decoding style.  hd = 128.
@@ -1020,18 +1055,22 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ table, int ld_t, c
     *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(src + d);
 }
 // out[i, :] = vec (broadcast one row) ; used for the global image feature g (cnets_ours.py:984)
-__global__ void bcast_row_kernel(const bf16_t* __restrict__ vec, bf16_t* __restrict__ out, int ld_o, int D) {
+__device__ __forceinline__ void bcast_row_body(const bf16_t* __restrict__ vec, bf16_t* __restrict__ out, int ld_o, int D) {
   bf16_t* dst = out + (size_t)blockIdx.x * ld_o;
   for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8)
     *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(vec + d);
 }
+__global__ void bcast_row_kernel(const bf16_t* __restrict__ vec, bf16_t* __restrict__ out, int ld_o, int D) { bcast_row_body(vec, out, ld_o, D); }
+struct bcast_row_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { bcast_row_body(a...); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Row-wise argmax (first max wins) and log-softmax + top-k (value desc, index asc) over bf16 logits
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-__global__ __launch_bounds__(1024) void argmax_rows_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+__device__ __forceinline__ void argmax_rows_body(const bf16_t* __restrict__ logits, int ld, int V,
                                                            int* __restrict__ out) {
   // one workgroup per row; a row of 32 064 logits is ONE pass of the block with four 16-byte loads per thread issued back to back
   // (the 256-thread form walked 16 dependent iterations: 13 us per launch)
@@ -1073,6 +1112,11 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const bf16_t* __restr
     out[blockIdx.x] = bi;
   }
 }
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+                                                           int* __restrict__ out) { argmax_rows_body(logits, ld, V, out); }
+struct argmax_rows_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { argmax_rows_body(a...); }
+};
 
 #define TOPK_MAX 16
 #define LSTK_CHUNKS 64
@@ -1136,7 +1180,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {  // fixed association: 
 }
 #define LSTK_ROW_CAND_MAX (TOPK_MAX * 8 * 20)
 template <int NV>
-__global__ __launch_bounds__(1024) void lstk_row_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k, int* __restrict__ out_idx,
+__device__ __forceinline__ void lstk_row_body(const bf16_t* __restrict__ logits, int ld, int V, int k, int* __restrict__ out_idx,
                                                         float* __restrict__ out_logp) {
   __shared__ float s_red[16];
   __shared__ unsigned long long s_lmax[1024];
@@ -1249,6 +1293,12 @@ __global__ __launch_bounds__(1024) void lstk_row_kernel(const bf16_t* __restrict
     }
   }
 }
+template <int NV>
+__global__ __launch_bounds__(1024) void lstk_row_kernel(const bf16_t* __restrict__ logits, int ld, int V, int k, int* __restrict__ out_idx,
+                                                        float* __restrict__ out_logp) { lstk_row_body<NV>(logits, ld, V, k, out_idx, out_logp); }
+template <int NV> struct lstk_row_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { lstk_row_body<NV>(a...); }
+};
 
 // ---- chunked form for LARGE vocabularies (Qwen2.5-VL: V = 152 064): the one-workgroup row kernel above walks 300 KB per row on ONE CU
 // (62-73 us per call); here a row is cut into C chunks of <= 32 768 logits, each handled by its own 1024-thread workgroup with the row
@@ -1263,7 +1313,7 @@ __device__ __forceinline__ void lstk2_load(const bf16_t* x, int lo, int hi, uint
   }
 }
 template <int NV>
-__global__ __launch_bounds__(1024) void lstk2_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, float* __restrict__ stats) {
+__device__ __forceinline__ void lstk2_stats_body(const bf16_t* __restrict__ logits, int ld, int V, int chunk, float* __restrict__ stats) {
   __shared__ float s_red[16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, C = gridDim.y, c = blockIdx.y;
   const int lo = c * chunk, hi = min(V, lo + chunk);  // chunk and V are multiples of 8
@@ -1303,7 +1353,12 @@ __global__ __launch_bounds__(1024) void lstk2_stats_kernel(const bf16_t* __restr
   }
 }
 template <int NV>
-__global__ __launch_bounds__(1024) void lstk2_select_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, int k,
+__global__ __launch_bounds__(1024) void lstk2_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, float* __restrict__ stats) { lstk2_stats_body<NV>(logits, ld, V, chunk, stats); }
+template <int NV> struct lstk2_stats_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { lstk2_stats_body<NV>(a...); }
+};
+template <int NV>
+__device__ __forceinline__ void lstk2_select_body(const bf16_t* __restrict__ logits, int ld, int V, int chunk, int k,
                                                             const float* __restrict__ stats, unsigned long long* __restrict__ cand) {
   __shared__ unsigned long long s_lmax[1024];
   __shared__ unsigned long long s_cand[TOPK_MAX * 8 * NV];
@@ -1383,7 +1438,13 @@ __global__ __launch_bounds__(1024) void lstk2_select_kernel(const bf16_t* __rest
     }
   }
 }
-__global__ __launch_bounds__(64) void lstk2_merge_kernel(const unsigned long long* __restrict__ cand, int C, int k, int* __restrict__ out_idx,
+template <int NV>
+__global__ __launch_bounds__(1024) void lstk2_select_kernel(const bf16_t* __restrict__ logits, int ld, int V, int chunk, int k,
+                                                            const float* __restrict__ stats, unsigned long long* __restrict__ cand) { lstk2_select_body<NV>(logits, ld, V, chunk, k, stats, cand); }
+template <int NV> struct lstk2_select_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { lstk2_select_body<NV>(a...); }
+};
+__device__ __forceinline__ void lstk2_merge_body(const unsigned long long* __restrict__ cand, int C, int k, int* __restrict__ out_idx,
                                                          float* __restrict__ out_logp) {
   __shared__ unsigned long long s_c[64 * TOPK_MAX];
   const int lane = threadIdx.x, n = C * k;
@@ -1401,6 +1462,11 @@ __global__ __launch_bounds__(64) void lstk2_merge_kernel(const unsigned long lon
     }
   }
 }
+__global__ __launch_bounds__(64) void lstk2_merge_kernel(const unsigned long long* __restrict__ cand, int C, int k, int* __restrict__ out_idx,
+                                                         float* __restrict__ out_logp) { lstk2_merge_body(cand, C, k, out_idx, out_logp); }
+struct lstk2_merge_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { lstk2_merge_body(a...); }
+};
 
 __global__ __launch_bounds__(256) void lstk_stats_kernel(const bf16_t* __restrict__ logits, int ld, int V, float* __restrict__ stats) {
   __shared__ float s_red[4];

@@ -40,7 +40,7 @@ __device__ __forceinline__ void tree_stage_row(const bf16_t* __restrict__ hid_sr
 }
 
 // Level 1 (cnets_ours.py:1114-1123): the k children of the root come from the last hidden state's top-k.
-__global__ __launch_bounds__(1024) void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
+__device__ __forceinline__ void tree_init_body(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
                                                          const bf16_t* __restrict__ last_hidden, const bf16_t* __restrict__ embed,
                                                          bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx2, int D) {
   const int tid = threadIdx.x;
@@ -58,9 +58,15 @@ __global__ __launch_bounds__(1024) void tree_init_kernel(TreeBufs tb, const int*
   const int r = tid / per;
   if (r < k) tree_stage_row(last_hidden, embed + (size_t)top_idx[r] * D, dx1, dx2, r, D, tid % per, per);
 }
+__global__ __launch_bounds__(1024) void tree_init_kernel(TreeBufs tb, const int* __restrict__ top_idx, const float* __restrict__ top_logp, int k,
+                                                         const bf16_t* __restrict__ last_hidden, const bf16_t* __restrict__ embed,
+                                                         bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx2, int D) { tree_init_body(tb, top_idx, top_logp, k, last_hidden, embed, dx1, dx2, D); }
+struct tree_init_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { tree_init_body(a...); }
+};
 
 // One tree level (cnets_ours.py:1139-1165) after the level forward + LM head + per-row top-k.
-__global__ __launch_bounds__(1024) void tree_level_kernel(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
+__device__ __forceinline__ void tree_level_body(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
                                                           const float* __restrict__ top_logp, const bf16_t* __restrict__ out_hidden,
                                                           const bf16_t* __restrict__ embed, bf16_t* __restrict__ dx1,
                                                           bf16_t* __restrict__ dx2, int D) {
@@ -104,9 +110,16 @@ __global__ __launch_bounds__(1024) void tree_level_kernel(TreeBufs tb, int level
   const int r = tid / per;
   if (r < k) tree_stage_row(out_hidden + (size_t)(sel[r] / k) * D, embed + (size_t)top_idx[sel[r]] * D, dx1, dx2, r, D, tid % per, per);
 }
+__global__ __launch_bounds__(1024) void tree_level_kernel(TreeBufs tb, int level, int k, const int* __restrict__ top_idx,
+                                                          const float* __restrict__ top_logp, const bf16_t* __restrict__ out_hidden,
+                                                          const bf16_t* __restrict__ embed, bf16_t* __restrict__ dx1,
+                                                          bf16_t* __restrict__ dx2, int D) { tree_level_body(tb, level, k, top_idx, top_logp, out_hidden, embed, dx1, dx2, D); }
+struct tree_level_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { tree_level_body(a...); }
+};
 
 // Global re-rank and tree construction (cnets_ours.py:1167-1213).  total = total_token-1.
-__global__ __launch_bounds__(256) void tree_finalize_kernel(TreeBufs tb, DevState* st, int k, int depth, int total,
+__device__ __forceinline__ void tree_finalize_body(TreeBufs tb, DevState* st, int k, int depth, int total,
                                                             int sampling) {
   __shared__ float sc[TREE_MAX_SCORES];
   __shared__ unsigned char keep[TREE_MAX_SCORES];
@@ -220,6 +233,11 @@ __global__ __launch_bounds__(256) void tree_finalize_kernel(TreeBufs tb, DevStat
     st->tree_T = T;
   }
 }
+__global__ __launch_bounds__(256) void tree_finalize_kernel(TreeBufs tb, DevState* st, int k, int depth, int total,
+                                                            int sampling) { tree_finalize_body(tb, st, k, depth, total, sampling); }
+struct tree_finalize_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { tree_finalize_body(a...); }
+};
 
 // A one-node "tree" = plain autoregressive decoding with the same verify kernels (baseline_forward).
 __global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
@@ -236,7 +254,7 @@ __global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
 
 // Greedy evaluate_posterior (utils.py:438-451) + the integer part of update_inference_inputs (utils.py:514-526,541,554,582)
 // am[i] = argmax of the target logits at tree node i.  sel[j] = tree node accepted at depth j (j = 0..a).
-__global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __restrict__ am, int* __restrict__ tokens,
+__device__ __forceinline__ void verify_accept_body(TreeBufs tb, DevState* st, const int* __restrict__ am, int* __restrict__ tokens,
                                      int tokens_cap, int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
                                      int forced_accept, int* __restrict__ draft_ids, int cohort) {
   __shared__ int acc[TREE_MAX_T];
@@ -297,6 +315,12 @@ __global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __res
     st->rounds += 1;
   }
 }
+__global__ void verify_accept_kernel(TreeBufs tb, DevState* st, const int* __restrict__ am, int* __restrict__ tokens,
+                                     int tokens_cap, int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
+                                     int forced_accept, int* __restrict__ draft_ids, int cohort) { verify_accept_body(tb, st, am, tokens, tokens_cap, sel, accept_log, log_cap, forced_accept, draft_ids, cohort); }
+struct verify_accept_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { verify_accept_body(a...); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Sampling path (temperature > 0): utils.py:453-493 (evaluate_posterior, sequential rejection over the tree's children),
@@ -447,7 +471,7 @@ __global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restri
 }
 
 // evaluate_posterior (sampling) + the integer half of update_inference_inputs; logits [T, V] bf16 of the verify forward
-__global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
+__device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
                                                                     int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
                                                                     int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
                                                                     int* __restrict__ draft_ids, int cohort) {
@@ -572,6 +596,13 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
     st->rounds += 1;
   }
 }
+__global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
+                                                                    int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
+                                                                    int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
+                                                                    int* __restrict__ draft_ids, int cohort) { verify_accept_sample_body(tb, st, logits, V, T, top_k, seed, tokens, tokens_cap, sel, accept_log, log_cap, draft_ids, cohort); }
+struct verify_accept_sample_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { verify_accept_sample_body(a...); }
+};
 
 // After the accept decision (one launch):
 //   blocks [0, n_kv)   KV compaction (utils.py:529-538): rows n+sel[j] -> n+j for j=1..a, for every (layer, k|v, head); one wave per
@@ -579,7 +610,7 @@ __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb,
 //   blocks n_kv + j    accept_hidden_state_new[j] = hidden_state_new[sel[j]] (utils.py:543-546), staged where the draft's catch-up forward
 //                      reads it (dx1[j, 0:D]) together with the embedding of the id it is paired with (dx2[j, 0:D] = embed(draft_ids[j]),
 //                      cnets_ours.py:1084,1093).
-__global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ kv, int s_max, int n_kv, const DevState* __restrict__ st,
+__device__ __forceinline__ void post_accept_body(bf16_t* __restrict__ kv, int s_max, int n_kv, const DevState* __restrict__ st,
                                                           const int* __restrict__ sel, const bf16_t* __restrict__ hidden_new,
                                                           bf16_t* __restrict__ accept_hidden, const int* __restrict__ draft_ids,
                                                           const bf16_t* __restrict__ draft_embed, bf16_t* __restrict__ dx1,
@@ -609,10 +640,18 @@ __global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ k
     if (es) *reinterpret_cast<uint4*>(dx2 + (size_t)j * 2 * D + d) = *reinterpret_cast<const uint4*>(es + d);
   }
 }
+__global__ __launch_bounds__(256) void post_accept_kernel(bf16_t* __restrict__ kv, int s_max, int n_kv, const DevState* __restrict__ st,
+                                                          const int* __restrict__ sel, const bf16_t* __restrict__ hidden_new,
+                                                          bf16_t* __restrict__ accept_hidden, const int* __restrict__ draft_ids,
+                                                          const bf16_t* __restrict__ draft_embed, bf16_t* __restrict__ dx1,
+                                                          bf16_t* __restrict__ dx2, int D) { post_accept_body(kv, s_max, n_kv, st, sel, hidden_new, accept_hidden, draft_ids, draft_embed, dx1, dx2, D); }
+struct post_accept_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { post_accept_body(a...); }
+};
 
 // Draft-side bookkeeping after the catch-up forward: the a+1 new rows become part of stable_kv (cnets_ours.py:1108) and the last
 // of them (out_hidden[:, -1], :1109) is what the tree grows from.
-__global__ __launch_bounds__(256) void draft_advance_kernel(DevState* st, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dlast, int D) {
+__device__ __forceinline__ void draft_advance_body(DevState* st, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dlast, int D) {
   if (st->frozen) return;
   const int a = st->accept_len;
   for (int d = threadIdx.x * 8; d < D; d += 256 * 8)
@@ -626,3 +665,7 @@ __global__ __launch_bounds__(256) void draft_advance_kernel(DevState* st, const 
     if (st->draft_real_len + TREE_MAX_DEPTH + 2 + KV_GUARD_ROWS > st->draft_rope_rows) st->done |= 4;
   }
 }
+__global__ __launch_bounds__(256) void draft_advance_kernel(DevState* st, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dlast, int D) { draft_advance_body(st, dout, dlast, D); }
+struct draft_advance_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { draft_advance_body(a...); }
+};

@@ -324,6 +324,15 @@ static void prof_end(hipStream_t) {
     if (g_prof.cur_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_prof.cur_a, g_prof.cur_b, 0, __VA_ARGS__);       \
     else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                                      \
   } while (0)
+// One launch of a small per-request kernel for ALL requests of a cohort (csrc/kernels.h: batch4_kernel runs the kernel's body with the
+// argument pack of request blockIdx.z).
+template <class Fn, int TPB, class P>
+static void launch_batch(hipStream_t s, dim3 grid, size_t lds, const P* packs, int n) {
+  Packs4<P> a;
+  for (int t = 0; t < 4; ++t) a.p[t] = packs[t < n ? t : 0];
+  grid.z = n;
+  hipLaunchKernelGGL((batch4_kernel<Fn, TPB, P>), grid, dim3(TPB), lds, s, a);
+}
 extern "C" int vispec_prof_enable(vispec_ctx*, int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;
@@ -804,6 +813,50 @@ static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int
   return 0;
 }
 
+// The same selection for every request of a cohort in ONE launch per pass (row form: one launch; chunked form: three): request t's
+// rows are x[t]->dlogits, its results x[t]->top_idx / top_logp.  Falls back to the per-request launches for shapes only the generic
+// three-pass form covers.
+struct Cohort;
+static int launch_lstopk_cohort(vispec_ctx* const* x, int n, hipStream_t s, int M, int V, int k) {
+  if (k < 1 || k > TOPK_MAX) return fail("logsoftmax_topk: k must be in [1,16]");
+  static const int chunk_min_v = getenv("VISPEC_LSTK_CHUNK_MIN_V") ? atoi(getenv("VISPEC_LSTK_CHUNK_MIN_V")) : 65536;
+  static const int row_max_v = getenv("VISPEC_LSTK_ROW_MAX_V") ? atoi(getenv("VISPEC_LSTK_ROW_MAX_V")) : 1024 * 8 * 20;
+  if (n > 1 && V % 8 == 0 && V > chunk_min_v && V <= 32768 * LSTK_CHUNKS) {
+    int C = (V + 32767) / 32768;
+    if (C < 8) C = 8;
+    const int chunk = ((V / 8 + C - 1) / C) * 8, nv = (chunk / 8 + 1023) / 1024;
+    auto p1 = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, chunk, x[t]->lstk_stats); };
+    auto p2 = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, chunk, k, (const float*)x[t]->lstk_stats, x[t]->lstk2_cand); };
+    auto p3 = [&](int t) { return make_pack((const unsigned long long*)x[t]->lstk2_cand, C, k, x[t]->top_idx, x[t]->top_logp); };
+    decltype(p1(0)) a1[4]; decltype(p2(0)) a2[4]; decltype(p3(0)) a3[4];
+    for (int t = 0; t < n; ++t) { a1[t] = p1(t); a2[t] = p2(t); a3[t] = p3(t); }
+#define LSTK2N(NV_)                                                                            \
+  do {                                                                                         \
+    launch_batch<lstk2_stats_fn<NV_>, 1024>(s, dim3(M, C), 0, a1, n);                          \
+    launch_batch<lstk2_select_fn<NV_>, 1024>(s, dim3(M, C), 0, a2, n);                         \
+  } while (0)
+    if (nv <= 1) LSTK2N(1); else if (nv == 2) LSTK2N(2); else if (nv == 3) LSTK2N(3); else LSTK2N(4);
+#undef LSTK2N
+    KCHK();
+    launch_batch<lstk2_merge_fn, 64>(s, dim3(M), 0, a3, n);
+    KCHK();
+    return 0;
+  }
+  if (n > 1 && V % 8 == 0 && V <= 1024 * 8 * 20 && V <= row_max_v && V <= chunk_min_v) {
+    auto pr = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, k, x[t]->top_idx, x[t]->top_logp); };
+    decltype(pr(0)) a[4];
+    for (int t = 0; t < n; ++t) a[t] = pr(t);
+    if (V <= 1024 * 8 * 4) launch_batch<lstk_row_fn<4>, 1024>(s, dim3(M), 0, a, n);
+    else if (V <= 1024 * 8 * 8) launch_batch<lstk_row_fn<8>, 1024>(s, dim3(M), 0, a, n);
+    else launch_batch<lstk_row_fn<20>, 1024>(s, dim3(M), 0, a, n);
+    KCHK();
+    return 0;
+  }
+  for (int t = 0; t < n; ++t)
+    if (launch_lstopk(x[t], s, x[t]->dlogits, V, M, V, k, x[t]->top_idx, x[t]->top_logp)) return -1;
+  return 0;
+}
+
 // Prefill-side GEMM (csrc/gemm_prefill.h): M rows against `n_tiles` 32-row blocks of a W32-packed weight starting at block n_tile0.
 enum { PROF_GEMM_PREFILL = 7 };
 static int launch_gemm_big(hipStream_t s, int epi, const BigA& a, int M, const void* P, int K, int n_tile0, int n_tiles, const BigEpi& e) {
@@ -1159,8 +1212,13 @@ static int draft_fuse(const Cohort& co, hipStream_t s, int rows, void* out, int 
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size;
   if (bcast_g)
-    for (int t = 0; t < co.n; ++t)
-      if (launch_bcast(s, co.c[t]->dg, co.c[t]->dx1 + D, 2 * D, rows, D)) return -1;
+    if (co.n > 1) {
+      auto pk = [&](int t) { return make_pack((const bf16_t*)co.c[t]->dg, co.c[t]->dx1 + D, 2 * D, D); };
+      decltype(pk(0)) a[4];
+      for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+      launch_batch<bcast_row_fn, 256>(s, dim3(rows), 0, a, co.n);
+      KCHK();
+    } else if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
   if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, co.M(rows), D, 2 * D, EPI_NONE, nullptr,
                   co.mt(rows)))
     return -1;
@@ -1232,33 +1290,52 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
   if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(1), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(1)))
     return -1;
-  for (int t = 0; t < co.n; ++t) {
-    vispec_ctx* x = co.c[t];
-    if (launch_lstopk(x, s, x->dlogits, V, 1, V, k, x->top_idx, x->top_logp)) return -1;
-    // the tree kernels stage the next level's inputs themselves: dx1[:, :D] = input_hidden, dx2[:, :D] = embed(input_ids)
-    hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(1024), 0, s, x->tb, x->top_idx, x->top_logp, k, x->dlast, (const bf16_t*)ctx->dw.embed,
-                       x->dx1, x->dx2, D);
-    KCHK();
+  // (a cohort's per-request kernels go out as ONE launch each: launch_batch)
+  if (launch_lstopk_cohort(co.c, co.n, s, 1, V, k)) return -1;
+  // the tree kernels stage the next level's inputs themselves: dx1[:, :D] = input_hidden, dx2[:, :D] = embed(input_ids)
+  if (co.n > 1) {
+    auto pk = [&](int t) {
+      vispec_ctx* x = co.c[t];
+      return make_pack(x->tb, (const int*)x->top_idx, (const float*)x->top_logp, k, (const bf16_t*)x->dlast, (const bf16_t*)ctx->dw.embed, x->dx1, x->dx2, D);
+    };
+    decltype(pk(0)) a[4];
+    for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+    launch_batch<tree_init_fn, 1024>(s, dim3(1), 0, a, co.n);
+  } else {
+    hipLaunchKernelGGL(tree_init_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->top_idx, ctx->top_logp, k, ctx->dlast, (const bf16_t*)ctx->dw.embed,
+                       ctx->dx1, ctx->dx2, D);
   }
+  KCHK();
   for (int lvl = 0; lvl < c.depth; ++lvl) {
     if (draft_fuse(co, s, k, ctx->dx, D, false)) return -1;
     if (draft_layer(co, s, k, lvl)) return -1;
     if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(k), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(k)))
       return -1;
-    for (int t = 0; t < co.n; ++t) {
-      vispec_ctx* x = co.c[t];
-      if (launch_lstopk(x, s, x->dlogits, V, k, V, k, x->top_idx, x->top_logp)) return -1;
-      hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(1024), 0, s, x->tb, lvl, k, x->top_idx, x->top_logp, x->dout, (const bf16_t*)ctx->dw.embed,
-                         x->dx1, x->dx2, D);
-      KCHK();
+    if (launch_lstopk_cohort(co.c, co.n, s, k, V, k)) return -1;
+    if (co.n > 1) {
+      auto pk = [&](int t) {
+        vispec_ctx* x = co.c[t];
+        return make_pack(x->tb, lvl, k, (const int*)x->top_idx, (const float*)x->top_logp, (const bf16_t*)x->dout, (const bf16_t*)ctx->dw.embed, x->dx1, x->dx2, D);
+      };
+      decltype(pk(0)) a[4];
+      for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+      launch_batch<tree_level_fn, 1024>(s, dim3(1), 0, a, co.n);
+    } else {
+      hipLaunchKernelGGL(tree_level_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, lvl, k, ctx->top_idx, ctx->top_logp, ctx->dout, (const bf16_t*)ctx->dw.embed,
+                         ctx->dx1, ctx->dx2, D);
     }
-  }
-  for (int t = 0; t < co.n; ++t) {
-    vispec_ctx* x = co.c[t];
-    hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, x->tb, x->st, k, c.depth, c.total_token - 1,
-                       x->temperature > 1e-5f ? 1 : 0);  // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
     KCHK();
   }
+  // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
+  if (co.n > 1) {
+    auto pk = [&](int t) { vispec_ctx* x = co.c[t]; return make_pack(x->tb, x->st, k, c.depth, c.total_token - 1, x->temperature > 1e-5f ? 1 : 0); };
+    decltype(pk(0)) a[4];
+    for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+    launch_batch<tree_finalize_fn, 256>(s, dim3(1), 0, a, co.n);
+  } else {
+    hipLaunchKernelGGL(tree_finalize_kernel, dim3(1), dim3(256), 0, s, ctx->tb, ctx->st, k, c.depth, c.total_token - 1, ctx->temperature > 1e-5f ? 1 : 0);
+  }
+  KCHK();
   return 0;
 }
 
@@ -1270,11 +1347,15 @@ static int draft_round_body(const Cohort& co, hipStream_t s) {
   // dx2[:, :D] = embeddings of the ids they pair with) were staged by the accept step (post_accept_kernel)
   if (draft_fuse(co, s, MC, ctx->dx, D, false)) return -1;
   if (draft_layer(co, s, MC, -1)) return -1;
-  for (int t = 0; t < co.n; ++t) {
-    vispec_ctx* x = co.c[t];
-    hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(256), 0, s, x->st, x->dout, x->dlast, D);  // + dlast = out_hidden[:, -1]
-    KCHK();
+  if (co.n > 1) {  // + dlast = out_hidden[:, -1]
+    auto pk = [&](int t) { vispec_ctx* x = co.c[t]; return make_pack(x->st, (const bf16_t*)x->dout, x->dlast, D); };
+    decltype(pk(0)) a[4];
+    for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+    launch_batch<draft_advance_fn, 256>(s, dim3(1), 0, a, co.n);
+  } else {
+    hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(256), 0, s, ctx->st, ctx->dout, ctx->dlast, D);
   }
+  KCHK();
   return draft_grow_tree(co, s);
 }
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
@@ -1454,15 +1535,27 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* x = co.c[t];
     if (!x->target_kv) return fail("target KV not set");
-    // embed the tree tokens (modeling_llama_kv.py:985) + the first layer's input_layernorm
-    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(T), dim3(256), 0, s, (const bf16_t*)ctx->tm.embed, x->tb.tree_tokens, x->xa,
-                       (const bf16_t*)ctx->layers[0].ln1, x->xn, D, c.rms_eps);
-    KCHK();
+    // embed the tree tokens (modeling_llama_kv.py:985) + the first layer's input_layernorm (a cohort's: one launch, below)
+    if (co.n == 1) {
+      hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(T), dim3(256), 0, s, (const bf16_t*)ctx->tm.embed, x->tb.tree_tokens, x->xa,
+                         (const bf16_t*)ctx->layers[0].ln1, x->xn, D, c.rms_eps);
+      KCHK();
+    }
     PosSpec& ps = rq[t].ps;  // position_ids = tree_position_ids + n (utils.py:397) ; KV rows [n, n+T)  (KVCache.cat)
     ps.base = &x->st->n_ctx;
     ps.base2 = &x->st->rope_delta;
     ps.off = x->tb.tree_pos;
     ps.kv_base = &x->st->n_ctx;
+  }
+  if (co.n > 1) {
+    auto pk = [&](int t) {
+      vispec_ctx* x = co.c[t];
+      return make_pack((const bf16_t*)ctx->tm.embed, (const int*)x->tb.tree_tokens, x->xa, (const bf16_t*)ctx->layers[0].ln1, x->xn, D, c.rms_eps);
+    };
+    decltype(pk(0)) a[4];
+    for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+    launch_batch<embed_rmsnorm_fn, 256>(s, dim3(T), 0, a, co.n);
+    KCHK();
   }
   for (int l = 0; l < c.num_layers; ++l) {
     const vispec_layer_weights& w = ctx->layers[l];
@@ -1504,16 +1597,62 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
   if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, co.M(T), V, D, EPI_NONE, ctx->tm.lm_head_scale,
                   co.mt(T)))
     return -1;
-  for (int t = 0; t < co.n; ++t) {
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(1024), 0, s, co.c[t]->logits, V, V, co.c[t]->am);
-    KCHK();
+  if (co.n > 1) {
+    auto pk = [&](int t) { return make_pack((const bf16_t*)co.c[t]->logits, V, V, co.c[t]->am); };
+    decltype(pk(0)) a[4];
+    for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+    launch_batch<argmax_rows_fn, 1024>(s, dim3(T), 0, a, co.n);
+  } else {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(1024), 0, s, ctx->logits, V, V, ctx->am);
   }
+  KCHK();
   return 0;
 }
 
 static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_accept) {
   const vispec_config& c = co.lead()->c;
   const int D = c.hidden_size, Hk = c.num_kv_heads;
+  // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
+  // for the draft's catch-up forward
+  const int n_kv = T > 1 ? 2 * c.num_layers * Hk : 0;
+  const bf16_t* dembed = (const bf16_t*)co.lead()->dw.embed;
+  bool all_sample = true, none_sample = true;
+  for (int t = 0; t < co.n; ++t) {
+    const bool smp = co.c[t]->temperature > 1e-5f && T > 1 && forced_accept < 0;
+    all_sample &= smp;
+    none_sample &= !smp;
+  }
+  if (co.n > 1 && (all_sample || none_sample)) {  // one launch per step for the whole cohort
+    if (all_sample) {
+      auto pk = [&](int t) {
+        vispec_ctx* x = co.c[t];
+        return make_pack(x->tb, x->st, (const bf16_t*)x->logits, c.vocab_size, x->temperature, x->sample_top_k, x->seed, x->tokens, x->tokens_cap, x->sel,
+                         x->accept_log, x->log_cap, x->draft_ids, 1);
+      };
+      decltype(pk(0)) a[4];
+      for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+      launch_batch<verify_accept_sample_fn, 1024>(s, dim3(1), 0, a, co.n);
+    } else {
+      auto pk = [&](int t) {
+        vispec_ctx* x = co.c[t];
+        return make_pack(x->tb, x->st, (const int*)x->am, x->tokens, x->tokens_cap, x->sel, x->accept_log, x->log_cap, forced_accept, x->draft_ids, 1);
+      };
+      decltype(pk(0)) a[4];
+      for (int t = 0; t < co.n; ++t) a[t] = pk(t);
+      launch_batch<verify_accept_fn, 64>(s, dim3(1), 0, a, co.n);
+    }
+    KCHK();
+    auto pp = [&](int t) {
+      vispec_ctx* x = co.c[t];
+      return make_pack(x->target_kv, c.max_pos, n_kv, (const DevState*)x->st, (const int*)x->sel, (const bf16_t*)x->hidden_new, x->accept_hidden,
+                       (const int*)x->draft_ids, dembed, x->dx1, x->dx2, D);
+    };
+    decltype(pp(0)) b[4];
+    for (int t = 0; t < co.n; ++t) b[t] = pp(t);
+    launch_batch<post_accept_fn, 256>(s, dim3(n_kv + TREE_RET_W), 0, b, co.n);
+    KCHK();
+    return 0;
+  }
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* ctx = co.c[t];
     if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
@@ -1523,11 +1662,8 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
       hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
                          ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids, co.n > 1 ? 1 : 0);
     KCHK();
-    // KV compaction (T > 1) + accept_hidden_state_new = hidden_state_new[:, retrieve_indices][:, best, :a+1] (utils.py:529-546), staged
-    // for the draft's catch-up forward
-    const int n_kv = T > 1 ? 2 * c.num_layers * Hk : 0;
     hipLaunchKernelGGL(post_accept_kernel, dim3(n_kv + TREE_RET_W), dim3(256), 0, s, ctx->target_kv, c.max_pos, n_kv, ctx->st, ctx->sel,
-                       ctx->hidden_new, ctx->accept_hidden, ctx->draft_ids, (const bf16_t*)co.lead()->dw.embed, ctx->dx1, ctx->dx2, D);
+                       ctx->hidden_new, ctx->accept_hidden, ctx->draft_ids, dembed, ctx->dx1, ctx->dx2, D);
     KCHK();
   }
   return 0;
@@ -1716,6 +1852,23 @@ extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   out[0] = h.n_ctx; out[1] = h.new_token; out[2] = h.rounds; out[3] = h.done; out[4] = h.accept_len;
   out[5] = h.next_token; out[6] = h.draft_len; out[7] = h.n_leaf;
+  return 0;
+}
+// The same for every request of a cohort with ONE stream synchronisation (the per-request form costs a blocking round trip each: four per
+// lockstep round): the states travel through each ctx's pinned staging buffer.  out = n x 8 ints, laid out as above.
+extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void* stream, int* out) {
+  if (!ctxs || !out || n < 1 || n > 4) return fail("cohort_get_state: 1..4 contexts");
+  for (int t = 0; t < n; ++t) {
+    if (!ctxs[t] || !ctxs[t]->h_pin) return fail("null ctx");
+    HIPCHK(hipMemcpyAsync(ctxs[t]->h_pin, ctxs[t]->st, sizeof(DevState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  }
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  for (int t = 0; t < n; ++t) {
+    const DevState& h = *reinterpret_cast<const DevState*>(ctxs[t]->h_pin);
+    int* o = out + 8 * t;
+    o[0] = h.n_ctx; o[1] = h.new_token; o[2] = h.rounds; o[3] = h.done; o[4] = h.accept_len;
+    o[5] = h.next_token; o[6] = h.draft_len; o[7] = h.n_leaf;
+  }
   return 0;
 }
 extern "C" int vispec_get_last_accept_host(vispec_ctx* ctx, void* stream, int* out2) {

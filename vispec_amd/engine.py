@@ -466,6 +466,15 @@ class Engine:
         k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
         return dict(zip(k, list(out)))
 
+    def cohort_states(self, members):
+        """state() of this engine and of its cohort members with ONE stream synchronisation."""
+        hs = [self] + list(members)
+        arr = (C.c_void_p * len(hs))(*[x.h.value for x in hs])
+        out = (C.c_int * (8 * len(hs)))()
+        L.check(self.lib.vispec_cohort_get_state_host(arr, len(hs), self._stream(), out))
+        k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
+        return [dict(zip(k, list(out[8 * t:8 * t + 8]))) for t in range(len(hs))]
+
     def last_accept(self):
         """(best_candidate, accept_length) of the last accept."""
         out = (C.c_int * 2)()

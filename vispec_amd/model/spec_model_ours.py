@@ -460,10 +460,11 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     for idx in range(rounds_cap):
         fa = -1 if forced_accept is None else int(forced_accept(idx))
         lead.engine.cohort_round(member_engines, fa)
+        states = lead.engine.cohort_states(member_engines)  # the round's ONE host synchronisation
         for t, m in enumerate(models):
             if not alive[t]:
                 continue
-            st = m.engine.state()
+            st = states[t]
             final[t], idxs[t] = st, idx
             accs[t].append(int(st["accept_len"]))
             if (st["done"] & 1) or st["new_token"] > budgets[t] or (st["done"] & 4):  # :544 / :546 / KV full
