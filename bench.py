@@ -56,6 +56,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 4)
+
+
 def build_models(device, seed, rank, world, lanes, cohort=1):
     """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2..4 every lane
     also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then."""
@@ -103,8 +106,8 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
         lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
-        if lanes == 1:
-            lead.engine.set_wide_row_blocks(0)  # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it
+        if WIDE_RB >= 0 or lanes == 1:  # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it
+            lead.engine.set_wide_row_blocks(WIDE_RB if WIDE_RB >= 0 else 0)
         sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
 
@@ -326,12 +329,15 @@ def main():
     ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
+    ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 4),
+                    help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, 4 otherwise")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
                          "replicas (request i -> GPU i mod N, then over that GPU's lanes); 0 = one request per lane per step (weak scaling)")
     args = ap.parse_args()
-    global MODEL, N_IMG
+    global MODEL, N_IMG, WIDE_RB
     MODEL = args.model
+    WIDE_RB = args.wide_row_blocks
     if args.n_img:
         N_IMG = args.n_img
         for k in ("llava7b", "llava13b"):
