@@ -97,6 +97,32 @@ def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
     del mb
 
 
+@pytest.mark.parametrize("n_req,row_blocks", [(4, 4), (3, 0)])
+def test_wide_cohort_equals_the_single_requests_at_full_size(model_full, n_req, row_blocks):
+    """Three / four requests on one weight pass (csrc/gemm_wide.h incl. its fp8 instantiations for the fp8 model, both launch shapes of
+    vispec_set_wide_row_blocks, one launch per step for the per-request kernels, four-request attention) at the real sizes of EVERY
+    BASELINE model: token for token the single-request results, with ragged budgets so that requests freeze one after the other."""
+    import bench
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    sm, tcfg, name = model_full
+    bench.MODEL = name
+    dev = torch.device("cuda:0")
+    reqs = [bench.make_request(tcfg, 20 + i, dev) for i in range(n_req)]
+    budgets = [56, 40, 64, 33][:n_req]
+    want = [sm.specgenerate(ids, max_new_tokens=b, log=True, return_acceptance_len=True, **pix) for (ids, pix), b in zip(reqs, budgets)]
+    members = [sm.make_cohort_member() for _ in range(n_req - 1)]
+    sm.engine.set_wide_row_blocks(row_blocks)
+    try:
+        got = specgenerate_cohort([sm] + members, reqs, max_new_tokens=budgets)
+        for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+            assert torch.equal(toks, w[0]) and (new_token, idx, acc) == (w[1], w[2], w[3]), f"{name}: request {t}"
+    finally:
+        sm.engine.set_wide_row_blocks(4)
+        for m in members:
+            m.engine.close()
+    del members
+
+
 def test_ragged_cohort_at_full_size(model_full):
     """A cohort whose two requests have nothing in common: the bench request (thousands of context rows, image compression) next to a
     SHORT text-only prompt — attention key splits sized for the long one run mostly empty for the short one, the draft caches differ by
