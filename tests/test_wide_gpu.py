@@ -173,3 +173,28 @@ def test_step_api_keeps_stepping_after_done_outside_cohorts():
         seen.append((st["n_ctx"], st["done"], st["rounds"]))
     assert seen[-1][1] & 2, "the budget flag must be set by now"
     assert all(b[0] > a[0] and b[2] == a[2] + 1 for a, b in zip(seen, seen[1:])), f"every step must advance the request, done or not: {seen}"
+
+
+def test_closing_a_member_frees_its_tile_and_one_sync_reads_all_states():
+    """Engine.close() destroys a member's context at once: its activation tile goes back to the leader (the next member gets the same
+    tile), the leader's cohort graphs that bake the member in are dropped, and cohort rounds keep working with the new member.
+    Engine.cohort_states() returns what state() returns for every request, with one synchronisation."""
+    sm, _, _ = build(50, 60, True)
+    m1 = sm.make_cohort_member()
+    m2 = sm.make_cohort_member()
+    rng = np.random.default_rng(94)
+    reqs = [(torch.from_numpy(rng.integers(3, T["V"], size=n))[None], {}) for n in (13, 17, 11)]
+    want = [single(sm, *r, max_new_tokens=18) for r in reqs]
+    got = specgenerate_cohort([sm, m1, m2], reqs, max_new_tokens=18)
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())
+    states = sm.engine.cohort_states([m1.engine, m2.engine])
+    assert states == [sm.engine.state(), m1.engine.state(), m2.engine.state()]
+    m1.engine.close()
+    m1.engine.close()  # idempotent
+    with pytest.raises(Exception):
+        sm.engine.cohort_round([m1.engine, m2.engine])  # a closed context cannot take part any more
+    m1b = sm.make_cohort_member()  # takes tile 1 again
+    got = specgenerate_cohort([sm, m1b, m2], reqs, max_new_tokens=18)
+    for (toks, new_token, idx, acc), w in zip(got, want):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())

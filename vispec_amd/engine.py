@@ -396,6 +396,8 @@ class Engine:
         """One draft-and-verify round of 2..4 requests (this engine's and its members', created with leader=self) on one weight pass."""
         members = [members] if isinstance(members, Engine) else list(members)
         hs = [self] + members
+        if any(e.h is None for e in hs):
+            raise L.VispecError("cohort_round: a context of this cohort was closed")
         arr = (C.c_void_p * len(hs))(*[e.h.value for e in hs])
         st = self._stream()
         L.check(self.lib.vispec_cohortn_verify_accept(arr, len(hs), st, int(forced_accept)))
@@ -469,6 +471,8 @@ class Engine:
     def cohort_states(self, members):
         """state() of this engine and of its cohort members with ONE stream synchronisation."""
         hs = [self] + list(members)
+        if any(x.h is None for x in hs):
+            raise L.VispecError("cohort_states: a context of this cohort was closed")
         arr = (C.c_void_p * len(hs))(*[x.h.value for x in hs])
         out = (C.c_int * (8 * len(hs)))()
         L.check(self.lib.vispec_cohort_get_state_host(arr, len(hs), self._stream(), out))
