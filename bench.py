@@ -4,8 +4,9 @@
 Workload (BASELINE.json configs[1]): LLaVA-v1.6-vicuna-7B-shaped target + ViSpec draft, bf16, one request =
 48 template tokens + one image run of 2144 image tokens + 512 text tokens (L = 2704), up to 512 new tokens, temperature 0,
 total_token 30 / depth 3 / top_k 8 / num_q 2.  A "step" = one whole specgenerate() request (prefill + all rounds), exactly what
-the reference harness brackets with its wall clock (gen_spec_answer_coco_caption.py:221-232).  Inputs/weights are resident in
-HBM when the timed region starts.
+the reference harness brackets with its wall clock (gen_spec_answer_coco_caption.py:221-232), on every request slot of the GPU:
+--lanes (4) concurrent streams x --cohort (4) requests per lane that share each pass over the weights (every request keeps the
+reference's batch-1 semantics and its exact tokens).  Inputs/weights are resident in HBM when the timed region starts.
 
 No checkpoints exist on the box (no network), so weights are synthetic: random N(0,0.02) layers with a successor structure on
 embed/lm_head (vispec_amd/synth_gpu.py) that makes the draft agree with the target on ~88.5 % of the tokens.  Acceptance is

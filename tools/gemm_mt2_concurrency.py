@@ -13,6 +13,7 @@ NS = 4
 engs = [mk() for _ in range(NS)]
 p = lambda t: C.c_void_p(t.data_ptr())
 M = int(os.environ.get("M", "60"))
+UNC = int(os.environ.get("UNC", "0"))  # wide kernel (M > 96) only: 1 = no activation DMAs, 2 = no weight loads, 3 = two row blocks per workgroup
 SHAPES = [("qkv", 12288, 4096, 1), ("o_proj", 4096, 4096, 4), ("gate_up", 22016, 4096, 1), ("down", 4096, 11008, 4)]
 NB = 6
 W = {n: [pack_weight((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(NB)] for n, N, K, S in SHAPES}
@@ -23,7 +24,7 @@ bytes_layer = sum(N * K * 2 for n, N, K, S in SHAPES)
 def layer(si, it, code):
     s = C.c_void_p(streams[si].cuda_stream)
     for n, N, K, S in SHAPES:
-        L.check(lib.vispec_gemm_skinny_tune(engs[si].h, code * 10000 + S * 100, s, p(X[K]), K, p(W[n][(it * NS + si) % NB]), p(Y), N, M, N, K))
+        L.check(lib.vispec_gemm_skinny_tune(engs[si].h, code * 10000 + S * 100 + UNC, s, p(X[K]), K, p(W[n][(it * NS + si) % NB]), p(Y), N, M, N, K))
 for code, name in (((8, "MT=4 NT=1"), (9, "wide (16 waves, shared staging)")) if M > 96 else ((9, "wide NL=3"),) if M > 64 else ((1, "NT=1"), (5, "NT=2"), (6, "NT=2, half the activation loads (upper bound)"))):
     for ns in (1, 2, 3, 4):
         for it in range(3):
