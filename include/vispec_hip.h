@@ -124,6 +124,12 @@ int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void
 /* SwiGLU activation of a gate|up block [M, 2I] (row stride ld): out[M, I] = bf16(bf16(silu(gate)) * up) — the prefill side of
    LlamaMLP (modeling_llama_kv.py:240-262), where the projections themselves are library GEMMs; any M */
 int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I);
+/* Causal self-attention of a prompt's L rows — the PREFILL side of LlamaAttention / Qwen2_5_VLSdpaAttention (modeling_llama_kv.py:595-640:
+   scores bf16, fp32 softmax, eager_scores = 1; modeling_qwen2_5_vl_kv.py:1073-1170: SDPA, eager_scores = 0) without the [H, L, L]
+   score tensor: q rows [L, ldq] (head h at column 128 h, rotary already applied by vispec_rope_append), K/V rows [0, L) of one layer's
+   cache slabs [H_kv, s_max, 128] as that call wrote them, out [L, ldo] bf16 (head h at column 128 h).  head_dim 128; any L <= s_max. */
+int vispec_prefill_attention(vispec_ctx*, void* stream, const void* q, int ldq, const void* k_cache, const void* v_cache, int s_max,
+                             int H, int H_kv, int L, void* out, int ldo, int eager_scores);
 /* rotary (cnets_ours.py:104-119) on fused qkv rows + append K,V to a [H_kv, S_max, hd] cache at rows
    *kv_base_dev + i ; positions = *pos_base_dev + pos_off_dev[i] (pos_off_dev may be NULL = i). Q is rotated in place. */
 int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cos, const void* sin,

@@ -265,6 +265,39 @@ def test_tree_attention(lib, engine, H, Hkv, M, prefix, tail, eager):
     assert_bf16_close(fn(O), want, min_exact=0.40, ulps=2, scale=scale)
 
 
+@pytest.mark.parametrize("H,Hkv,Lq,eager", [(2, 2, 300, 1), (2, 2, 129, 1), (4, 2, 257, 0), (2, 2, 1, 1), (14, 2, 95, 0), (2, 1, 640, 1), (1, 1, 128, 0)])
+def test_prefill_attention_against_the_oracle(lib, engine, H, Hkv, Lq, eager):
+    """vispec_prefill_attention (causal attention of a prompt's rows over the K/V rows its prefill wrote — the reference's eager
+    LlamaAttention / SDPA Qwen attention at prefill time, modeling_llama_kv.py:595-640) against the oracle's attention with a causal
+    mask: same tolerance as the decode kernel whose tile arithmetic it shares.  Row counts around the 128-row workgroup and 32-row wave
+    boundaries, one row, GQA."""
+    rng = np.random.default_rng(H * 1000 + Lq * 7 + eager)
+    hd, S = 128, 1024
+    o = vo.Ops(True)
+    q = synth.bf16_grid(rng.standard_normal((Lq, H, hd), dtype=np.float32))
+    k = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))
+    v = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))
+    allow = np.tril(np.ones((Lq, Lq), bool))
+    rep = H // Hkv
+    kk, vv = np.repeat(k[:, :Lq], rep, axis=0), np.repeat(v[:, :Lq], rep, axis=0)
+    qh = q.transpose(1, 0, 2)
+    want = (o.attn_eager if eager else o.attn_sdpa)(qh, kk, vv, allow).transpose(1, 0, 2).reshape(Lq, H * hd)
+    sc = np.einsum("hqd,hkd->hqk", qh, kk) / np.sqrt(hd)
+    sc = np.where(allow[None], sc, -np.inf)
+    pr = np.exp(sc - sc.max(-1, keepdims=True))
+    pr /= pr.sum(-1, keepdims=True)
+    scale = np.einsum("hqk,hkd->hqd", pr, np.abs(vv)).transpose(1, 0, 2).reshape(Lq, H * hd)
+    ldq = (H + 2 * Hkv) * hd  # the fused q|k|v row of the prefill: q heads first
+    Qfull = torch.zeros(Lq, ldq, dtype=torch.bfloat16, device=dev())
+    Qfull[:, : H * hd] = tb(q.reshape(Lq, H * hd))
+    Kc, Vc = tb(k), tb(v)
+    O = torch.full((Lq + 3, H * hd), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_prefill_attention(engine.h, stream(), p(Qfull), ldq, p(Kc), p(Vc), S, H, Hkv, Lq, p(O), H * hd, eager))
+    torch.cuda.synchronize()
+    assert (O[Lq:].float() == 7.0).all(), "rows past L must stay untouched"
+    assert_bf16_close(fn(O[:Lq]), want, min_exact=0.40, ulps=2, scale=scale)
+
+
 def test_argmax_rows_first_max_wins(lib):
     rng = np.random.default_rng(5)
     M, V = 30, 32064

@@ -971,6 +971,180 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
   }
 }
 
+// ---- prefill attention (round 3): causal attention of the prompt's L query rows over the K/V rows [0, L) the prefill has just written ---
+// The target prefill's GEMMs stay library calls, its attention no longer does: torch's flash SDPA runs this shape (L = 2704, 32 heads
+// of 128) at 200 TFLOP/s (296 us per layer, a quarter of the prefill), and it is not the reference's arithmetic for LLaVA (eager:
+// bf16 scores, fp32 softmax — modeling_llama_kv.py:602-623).  This kernel is the decode kernel's tile arithmetic (same MFMA operand
+// layouts, same eager score rounding, same bf16 P, K image XOR-swizzled for ds_read_b128, V through ds_read_b64_tr_b16) turned
+// around for many query rows: a workgroup = 128 query rows of one head, each of its 4 waves OWNS 32 of them (Q fragments, running
+// max / sum and the 32 x 128 output tile in registers for the whole key loop), the workgroup stages 128-key chunks of K and V once
+// for all four waves, every wave walks the chunk's four 32-key tiles with the online softmax — so there is no cross-wave merge and
+// no partial tile: the output row is normalised and stored by the wave that owns it.  Causal structure: key k is visible to row r
+// iff k <= r; a tile entirely below the diagonal takes the unmasked path, tiles above it are skipped, chunks above the
+// workgroup's last row are never staged.  grid (ceil(L / 128), H); the longest workgroups (last row blocks) are issued first.
+template <bool EAGER>
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kc,
+                                                              const bf16_t* __restrict__ Vc, int s_max, int H, int H_kv, int L,
+                                                              bf16_t* __restrict__ out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + ATT2_CHUNK * 256;
+  const int qb = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, kvh = head / (H / H_kv);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, hi = lane >> 5;
+  const int row0 = qb * 128 + wave * 32, mrow = row0 + j;  // this wave's query rows / this lane's
+  const bool qvalid = mrow < L;
+  const bf16_t* Kh = Kc + (size_t)kvh * s_max * 128;
+  const bf16_t* Vh = Vc + (size_t)kvh * s_max * 128;
+  const int n_keys = min(L, qb * 128 + 128);  // keys any row of this workgroup can see
+  const int nchunk = (n_keys + ATT2_CHUNK - 1) / ATT2_CHUNK;
+  const int last_key = n_keys - 1;
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float sqrt_hd = 11.313708498984761f;
+  const float rsqrt_hd = 1.0f / sqrt_hd;
+  uint4 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)(qvalid ? mrow : L - 1) * ldq + head * 128 + ks * 16 + hi * 8);
+  float m_run = NEG_INF, l_run = 0.f;
+  f32x16 O[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  const int srow = threadIdx.x >> 4, sc16 = threadIdx.x & 15;
+  uint4 k0r, k1r, k2r, k3r, k4r, k5r, k6r, k7r, v0r, v1r, v2r, v3r, v4r, v5r, v6r, v7r;
+#define PFA_G1(kk, vv, p, ch)                                                               \
+  {                                                                                         \
+    const int key_ = min((ch) * ATT2_CHUNK + srow + 16 * (p), last_key);                    \
+    kk = *reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8);               \
+    vv = *reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8);               \
+  }
+#define PFA_GLOAD(ch)                                                                       \
+  PFA_G1(k0r, v0r, 0, ch) PFA_G1(k1r, v1r, 1, ch) PFA_G1(k2r, v2r, 2, ch) PFA_G1(k3r, v3r, 3, ch) \
+  PFA_G1(k4r, v4r, 4, ch) PFA_G1(k5r, v5r, 5, ch) PFA_G1(k6r, v6r, 6, ch) PFA_G1(k7r, v7r, 7, ch)
+#define PFA_W1(kk, vv, p)                                                                   \
+  *reinterpret_cast<uint4*>(sK + att_swz(srow + 16 * (p), sc16 * 16)) = kk;                 \
+  *reinterpret_cast<uint4*>(sV + att_vswz(srow + 16 * (p), sc16 * 16)) = vv;
+#define PFA_LWRITE()                                                                        \
+  PFA_W1(k0r, v0r, 0) PFA_W1(k1r, v1r, 1) PFA_W1(k2r, v2r, 2) PFA_W1(k3r, v3r, 3)           \
+  PFA_W1(k4r, v4r, 4) PFA_W1(k5r, v5r, 5) PFA_W1(k6r, v6r, 6) PFA_W1(k7r, v7r, 7)
+  PFA_GLOAD(0)
+  PFA_LWRITE()
+  __syncthreads();
+  const int li = lane & 15, lg = lane >> 4;
+  const int vrow_l = 4 * hi + (li >> 2);
+  const int vcol_l = (16 * (lg & 1) + 4 * (li & 3)) * 2;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch + 1 < nchunk) { PFA_GLOAD(ch + 1) }  // in flight during the MFMA work below
+    for (int kt = 0; kt < 4; ++kt) {
+      const int kbase = ch * ATT2_CHUNK + kt * 32;
+      if (kbase > row0 + 31 || kbase >= L) break;  // wave-uniform: the tile lies above this wave's last row
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      const int krow = kt * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(sK + att_swz(krow, ks * 32 + hi * 16));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(qf[ks]), S, 0, 0, 0);
+      }
+      float mx = NEG_INF;
+      // eager scores: bf16(bf16(S) / sqrt(hd)) through one FMA-corrected reciprocal multiply (bit-identical to the division for
+      // every bf16 input, tools/div_check.hip) — the decode kernel's arithmetic
+      if (kbase + 31 <= row0) {  // wave-uniform: every key of the tile is visible to every row of the wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sc;
+          if (EAGER) {
+            const float xb = rdbf(S[r]);
+            float q = xb * rsqrt_hd;
+            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+            sc = rdbf(q);
+          } else {
+            sc = S[r] * scale;
+          }
+          S[r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      } else {  // the tile crosses the diagonal
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          float sc;
+          if (EAGER) {
+            const float xb = rdbf(S[r]);
+            float q = xb * rsqrt_hd;
+            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
+            sc = rdbf(q);
+          } else {
+            sc = S[r] * scale;
+          }
+          sc = (key <= mrow) ? sc : NEG_INF;
+          S[r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
+      float psum = 0.f;
+      unsigned pb[8];
+      const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(S[r] - m_sub);
+        const float p1 = __expf(S[r + 1] - m_sub);
+        psum += p0 + p1;
+        pb[r >> 1] = pack2(p0, p1);
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4 pB = make_uint4(pb[kk * 4 + 0], pb[kk * 4 + 1], pb[kk * 4 + 2], pb[kk * 4 + 3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int r0 = kt * 32 + vrow_l + 16 * kk;
+          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(sV + att_vswz(r0, 64 * dt + vcol_l)));
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(sV + att_vswz(r0 + 8, 64 * dt + vcol_l)));
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          const s16x8_t va = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+          O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&va), as_bf16x8(pB), O[dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with this chunk's LDS image
+    if (ch + 1 < nchunk) {
+      PFA_LWRITE()
+      __syncthreads();
+    }
+  }
+#undef PFA_GLOAD
+#undef PFA_LWRITE
+#undef PFA_G1
+#undef PFA_W1
+  if (!qvalid) return;
+  // O^T[d][q] of this wave's 32 rows: lane (j, hi) holds, for its row, d = 32 dt + 8 g + 4 hi + (0..3) in O[dt][4 g .. 4 g + 3]
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  bf16_t* orow = out + (size_t)mrow * ldo + head * 128;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<uint2*>(orow + 32 * dt + 8 * g + 4 * hi) =
+          make_uint2(pack2(O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv), pack2(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv));
+}
+
 // merge partials over splits: grid (H*MT), 256 threads
 __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, int H, int H_kv, int M, int tail,
                                                                int keys_per_wg, int nsplit, int ldo) {

@@ -1015,6 +1015,29 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 extern "C" int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps) {
   return launch_rmsnorm((hipStream_t)stream, X, w, Y, M, D, eps);
 }
+// Causal attention of a prompt's L rows over the K/V rows [0, L) its prefill has just written (csrc/kernels.h: prefill_attn_kernel).
+extern "C" int vispec_prefill_attention(vispec_ctx*, void* stream, const void* q, int ldq, const void* k_cache, const void* v_cache, int s_max,
+                                        int H, int H_kv, int L, void* out, int ldo, int eager_scores) {
+  if (!q || !k_cache || !v_cache || !out) return fail("prefill_attention: null pointer");
+  if (L < 1 || L > s_max || H < 1 || H_kv < 1 || H % H_kv || ldq % 8 || ldo % 4) return fail("prefill_attention: bad shape");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)prefill_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)prefill_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) != hipSuccess)
+      return fail("prefill_attention: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  const dim3 grid((L + 127) / 128, H), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (eager_scores)
+    hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, block, ATT2_LDS_BYTES, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
+                       s_max, H, H_kv, L, (bf16_t*)out, ldo);
+  else
+    hipLaunchKernelGGL(prefill_attn_kernel<false>, grid, block, ATT2_LDS_BYTES, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
+                       s_max, H, H_kv, L, (bf16_t*)out, ldo);
+  KCHK();
+  return 0;
+}
 extern "C" int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I) {
   if (M < 1 || I % 8 || ld % 8 || ldo % 8) return fail("silu_mul: I, ld, ldo must be multiples of 8");
   hipLaunchKernelGGL(silu_mul_kernel, dim3((I / 8 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gate_up, ld, (bf16_t*)out,

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 import ctypes as C
+import os
 
 from .. import lib as L
 from ..engine import Engine, TargetConfig, TargetWeights
@@ -152,8 +153,9 @@ class TargetLM:
         of every layer are written into the engine's KV buffer (KVCache.cat semantics, modeling_llama_kv.py:583-594).
         position_ids: None (0..L-1) or [3, L] multimodal rotary positions (Qwen2.5-VL).
 
-        The prefill is MFMA-bound: its GEMMs (hipBLASLt) and attention (SDPA) stay PyTorch ops.  The element-wise steps between
-        them — RMSNorm, rotary + KV append, SwiGLU — run as the library's kernels (one launch each instead of ~6 / ~12 / 2 torch ops,
+        The prefill is MFMA-bound: its GEMMs (hipBLASLt) stay PyTorch ops; its attention is the library's causal kernel
+        (vispec_prefill_attention, round 3: 185 us per layer at L = 2704 where torch's flash SDPA takes 296 us); the element-wise
+        steps between them — RMSNorm, rotary + KV append, SwiGLU — run as the library's kernels (one launch each instead of ~6 / ~12 / 2 torch ops,
         same rounding points as the decode path): 11 launches per layer instead of ~35, which also keeps the host thread of a lane
         from holding the interpreter while other lanes wait to issue their rounds."""
         c, eng = self.cfg, self.engine
@@ -171,6 +173,7 @@ class TargetLM:
         kv = eng.target_kv
         S = kv.shape[3]
         p = lambda t: C.c_void_p(t.data_ptr())
+        native_attn = hd == 128 and os.environ.get("VISPEC_PREFILL_SDPA", "0") != "1"  # (A/B switch: torch's SDPA instead)
 
         def rmsnorm(t, w):
             out = torch.empty_like(t)
@@ -182,9 +185,15 @@ class TargetLM:
             qkv = scaled_linear(h, lw["wqkv"], lw["bqkv"], lw.get("wqkv_scale"))  # [L, QKV]
             # rotary at position m (bf16 rounding points of the reference) on q in place; k (rotated) and v -> cache rows [0, L)
             L.check(lib.vispec_rope_append(eng.h, st, p(qkv), Ln, H, Hk, hd, p(cos), p(sin), None, None, p(kv[2 * i]), p(kv[2 * i + 1]), S, None))
-            q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
-            a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0]
-            x = x + scaled_linear(a.transpose(0, 1).reshape(Ln, H * hd), lw["wo"], None, lw.get("wo_scale"))
+            if native_attn:  # causal attention of the L rows over the cache rows just written: the library's kernel (no [H, L, L] tensor,
+                # the reference's eager score arithmetic for LLaVA — the decode kernel's — instead of a flash kernel's)
+                a = torch.empty(Ln, H * hd, dtype=self.dtype, device=x.device)
+                L.check(lib.vispec_prefill_attention(eng.h, st, p(qkv), QKV, p(kv[2 * i]), p(kv[2 * i + 1]), S, H, Hk, Ln, p(a), H * hd,
+                                                     int(c.attn_impl == "eager")))
+            else:
+                q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
+                a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0].transpose(0, 1).reshape(Ln, H * hd)
+            x = x + scaled_linear(a, lw["wo"], None, lw.get("wo_scale"))
             h = rmsnorm(x, lw["ln2"])
             gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
