@@ -265,14 +265,15 @@ def test_tree_attention(lib, engine, H, Hkv, M, prefix, tail, eager):
     assert_bf16_close(fn(O), want, min_exact=0.40, ulps=2, scale=scale)
 
 
-@pytest.mark.parametrize("H,Hkv,Lq,eager", [(2, 2, 300, 1), (2, 2, 129, 1), (4, 2, 257, 0), (2, 2, 1, 1), (14, 2, 95, 0), (2, 1, 640, 1), (1, 1, 128, 0)])
+@pytest.mark.parametrize("H,Hkv,Lq,eager", [(2, 2, 300, 1), (2, 2, 129, 1), (4, 2, 257, 0), (2, 2, 1, 1), (14, 2, 95, 0), (2, 1, 640, 1), (1, 1, 128, 0),
+                                            (32, 32, 2100, 1), (28, 4, 2590, 0)])  # the last two: paired row blocks (long + short per workgroup)
 def test_prefill_attention_against_the_oracle(lib, engine, H, Hkv, Lq, eager):
     """vispec_prefill_attention (causal attention of a prompt's rows over the K/V rows its prefill wrote — the reference's eager
     LlamaAttention / SDPA Qwen attention at prefill time, modeling_llama_kv.py:595-640) against the oracle's attention with a causal
     mask: same tolerance as the decode kernel whose tile arithmetic it shares.  Row counts around the 128-row workgroup and 32-row wave
     boundaries, one row, GQA."""
     rng = np.random.default_rng(H * 1000 + Lq * 7 + eager)
-    hd, S = 128, 1024
+    hd, S = 128, 1024 if Lq <= 1024 else 2600
     o = vo.Ops(True)
     q = synth.bf16_grid(rng.standard_normal((Lq, H, hd), dtype=np.float32))
     k = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))

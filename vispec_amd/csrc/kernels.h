@@ -981,17 +981,48 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
 // for all four waves, every wave walks the chunk's four 32-key tiles with the online softmax — so there is no cross-wave merge and
 // no partial tile: the output row is normalised and stored by the wave that owns it.  Causal structure: key k is visible to row r
 // iff k <= r; a tile entirely below the diagonal takes the unmasked path, tiles above it are skipped, chunks above the
-// workgroup's last row are never staged.  grid (ceil(L / 128), H); the longest workgroups (last row blocks) are issued first.
+// workgroup's last row are never staged.  grid (ceil(ceil(L / 128) / 2), H): a workgroup takes a long and a short row block (see the kernel).
+// Two scores at a time (the prefill kernel is VALU-bound: ~20 vector instructions per MFMA in the decode kernel's per-element form):
+// bf16 rounding of a pair is ONE v_cvt_pk_bf16_f32 + two unpack ops, the scaling runs on packed-fp32 instructions.
+typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_pk rdbf2(f32x2_pk v) {
+  const unsigned u = pack2(v.x, v.y);
+  f32x2_pk r;
+  r.x = __uint_as_float(u << 16);
+  r.y = __uint_as_float(u & 0xffff0000u);
+  return r;
+}
+template <bool EAGER>
+__device__ __forceinline__ f32x2_pk score_pair(float s0, float s1) {
+  const float sqrt_hd = 11.313708498984761f, rsqrt_hd = 1.0f / 11.313708498984761f;
+  f32x2_pk x = {s0, s1};
+  if (EAGER) {  // bf16(bf16(S) / sqrt(hd)): FMA-corrected reciprocal multiply, bit-identical to the division (tools/div_check.hip)
+    const f32x2_pk xb = rdbf2(x);
+    f32x2_pk q = xb * rsqrt_hd;
+    const f32x2_pk e = __builtin_elementwise_fma(-q, (f32x2_pk){sqrt_hd, sqrt_hd}, xb);
+    q = __builtin_elementwise_fma(e, (f32x2_pk){rsqrt_hd, rsqrt_hd}, q);
+    return rdbf2(q);
+  }
+  return x * 0.08838834764831845f;
+}
 template <bool EAGER>
 __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kc,
                                                               const bf16_t* __restrict__ Vc, int s_max, int H, int H_kv, int L,
-                                                              bf16_t* __restrict__ out, int ldo) {
+                                                              bf16_t* __restrict__ out, int ldo, int paired) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + ATT2_CHUNK * 256;
-  const int qb = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, kvh = head / (H / H_kv);
+  const int head = blockIdx.y, kvh = head / (H / H_kv);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
+  // Row block b of a causal prompt walks b + 1 key chunks: a workgroup takes the PAIR (NB-1-x, x) — long block first — so that every
+  // workgroup walks NB + 1 chunks (one block per workgroup made the last row blocks the critical path: 185 us per layer at L = 2704,
+  // the chip half idle behind 22-chunk workgroups)
+  const int NB = (L + 127) / 128;
+  // (short prompts keep one block per workgroup, longest first: pairing would leave CUs without a workgroup)
+  const int qb_long = NB - 1 - blockIdx.x, qb_short = paired ? (int)blockIdx.x : qb_long;
+  for (int pass = 0; pass < (qb_long != qb_short ? 2 : 1); ++pass) {
+  const int qb = pass == 0 ? qb_long : qb_short;
   const int row0 = qb * 128 + wave * 32, mrow = row0 + j;  // this wave's query rows / this lane's
   const bool qvalid = mrow < L;
   const bf16_t* Kh = Kc + (size_t)kvh * s_max * 128;
@@ -999,9 +1030,6 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
   const int n_keys = min(L, qb * 128 + 128);  // keys any row of this workgroup can see
   const int nchunk = (n_keys + ATT2_CHUNK - 1) / ATT2_CHUNK;
   const int last_key = n_keys - 1;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-  const float sqrt_hd = 11.313708498984761f;
-  const float rsqrt_hd = 1.0f / sqrt_hd;
   uint4 qf[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
@@ -1052,52 +1080,40 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
       float mx = NEG_INF;
       // eager scores: bf16(bf16(S) / sqrt(hd)) through one FMA-corrected reciprocal multiply (bit-identical to the division for
       // every bf16 input, tools/div_check.hip) — the decode kernel's arithmetic
-      if (kbase + 31 <= row0) {  // wave-uniform: every key of the tile is visible to every row of the wave
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float sc;
-          if (EAGER) {
-            const float xb = rdbf(S[r]);
-            float q = xb * rsqrt_hd;
-            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
-            sc = rdbf(q);
-          } else {
-            sc = S[r] * scale;
-          }
-          S[r] = sc;
-          mx = fmaxf(mx, sc);
-        }
-      } else {  // the tile crosses the diagonal
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_pk sc = score_pair<EAGER>(S[r], S[r + 1]);
+        S[r] = sc.x;
+        S[r + 1] = sc.y;
+      }
+      if (kbase + 31 > row0) {  // wave-uniform: the tile crosses the diagonal (else every key is visible to every row of the wave)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float sc;
-          if (EAGER) {
-            const float xb = rdbf(S[r]);
-            float q = xb * rsqrt_hd;
-            q = __builtin_fmaf(__builtin_fmaf(-q, sqrt_hd, xb), rsqrt_hd, q);
-            sc = rdbf(q);
-          } else {
-            sc = S[r] * scale;
-          }
-          sc = (key <= mrow) ? sc : NEG_INF;
-          S[r] = sc;
-          mx = fmaxf(mx, sc);
+          S[r] = (key <= mrow) ? S[r] : NEG_INF;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
-      float psum = 0.f;
       unsigned pb[8];
       const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;
+      // exp(s - m) = exp2(s log2e - m log2e): one packed FMA per two scores, then the two v_exp_f32
+      const float kLog2e = 1.4426950408889634f;
+      const f32x2_pk l2 = {kLog2e, kLog2e}, mneg = {-m_sub * kLog2e, -m_sub * kLog2e};
+      f32x2_pk ps = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __expf(S[r] - m_sub);
-        const float p1 = __expf(S[r + 1] - m_sub);
-        psum += p0 + p1;
-        pb[r >> 1] = pack2(p0, p1);
+        const f32x2_pk t = __builtin_elementwise_fma((f32x2_pk){S[r], S[r + 1]}, l2, mneg);
+        f32x2_pk pe;
+        pe.x = __builtin_amdgcn_exp2f(t.x);
+        pe.y = __builtin_amdgcn_exp2f(t.y);
+        ps += pe;
+        pb[r >> 1] = pack2(pe.x, pe.y);
       }
+      float psum = ps.x + ps.y;
       psum += __shfl_xor(psum, 32);
       l_run = l_run * alpha + psum;
       m_run = m_new;
@@ -1133,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
 #undef PFA_LWRITE
 #undef PFA_G1
 #undef PFA_W1
-  if (!qvalid) return;
+  if (qvalid) {
   // O^T[d][q] of this wave's 32 rows: lane (j, hi) holds, for its row, d = 32 dt + 8 g + 4 hi + (0..3) in O[dt][4 g .. 4 g + 3]
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   bf16_t* orow = out + (size_t)mrow * ldo + head * 128;
@@ -1143,6 +1159,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<uint2*>(orow + 32 * dt + 8 * g + 4 * hi) =
           make_uint2(pack2(O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv), pack2(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv));
+  }
+  __syncthreads();  // the next pass re-stages the LDS image
+  }
 }
 
 // merge partials over splits: grid (H*MT), 256 threads

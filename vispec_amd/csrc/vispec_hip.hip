@@ -1027,14 +1027,16 @@ extern "C" int vispec_prefill_attention(vispec_ctx*, void* stream, const void* q
       return fail("prefill_attention: cannot raise the dynamic LDS limit");
     attr_set = true;
   }
-  const dim3 grid((L + 127) / 128, H), block(256);
+  const int NB = (L + 127) / 128;
+  const int paired = (NB / 2) * H >= 256 ? 1 : 0;  // a workgroup = one long + one short row block when that still fills the CUs
+  const dim3 grid(paired ? (NB + 1) / 2 : NB, H), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (eager_scores)
     hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, block, ATT2_LDS_BYTES, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
-                       s_max, H, H_kv, L, (bf16_t*)out, ldo);
+                       s_max, H, H_kv, L, (bf16_t*)out, ldo, paired);
   else
     hipLaunchKernelGGL(prefill_attn_kernel<false>, grid, block, ATT2_LDS_BYTES, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
-                       s_max, H, H_kv, L, (bf16_t*)out, ldo);
+                       s_max, H, H_kv, L, (bf16_t*)out, ldo, paired);
   KCHK();
   return 0;
 }
