@@ -121,6 +121,9 @@ int vispec_gemm_skinny_tune(vispec_ctx*, int variant, void* stream, const void* 
                             int M, int N, int K);
 /* LlamaRMSNorm (cnets_ours.py:513-527, modeling_llama_kv.py:104-133) */
 int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps);
+/* Residual add + the norm that follows it in one pass (the prefill side of LlamaDecoderLayer, modeling_llama_kv.py:742-756):
+   X <- bf16(X + R) in place, Y = RMSNorm(X) * w.  any M */
+int vispec_add_rmsnorm(vispec_ctx*, void* stream, void* X, const void* R, const void* w, void* Y, int M, int D, float eps);
 /* SwiGLU activation of a gate|up block [M, 2I] (row stride ld): out[M, I] = bf16(bf16(silu(gate)) * up) — the prefill side of
    LlamaMLP (modeling_llama_kv.py:240-262), where the projections themselves are library GEMMs; any M */
 int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I);

@@ -1242,6 +1242,43 @@ __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, in
   }
 }
 
+// x <- bf16(x + r) (the residual add of the decoder layer, modeling_llama_kv.py:742-756) and y = RMSNorm(x) * w in ONE pass over the row:
+// the prefill's `x = x + o_proj(...)` / `x = x + down_proj(...)` followed by the next norm (two torch launches + one of ours before).
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* __restrict__ X, const bf16_t* __restrict__ R, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ Y, int D, float eps) {
+  __shared__ float part[4];
+  bf16_t* x = X + (size_t)blockIdx.x * D;
+  const bf16_t* r = R + (size_t)blockIdx.x * D;
+  bf16_t* y = Y + (size_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + d), rv = *reinterpret_cast<const uint4*>(r + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    const bf16_t* re = reinterpret_cast<const bf16_t*>(&rv);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = rdbf(bf2f(e[j]) + bf2f(re[j]));
+      ss += f[j] * f[j];
+    }
+    *reinterpret_cast<uint4*>(x + d) = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+  const float inv = 1.0f / sqrtf(tot / (float)D + eps);
+  for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {  // (every thread re-reads exactly the elements it has just written)
+    const uint4 v = *reinterpret_cast<const uint4*>(x + d), wv = *reinterpret_cast<const uint4*>(w + d);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f(we[j]) * rdbf(bf2f(e[j]) * inv);
+    *reinterpret_cast<uint4*>(y + d) = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row gathers / small elementwise helpers
 // ------------------------------------------------------------------------------------------------

@@ -1015,6 +1015,12 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 extern "C" int vispec_rmsnorm(vispec_ctx*, void* stream, const void* X, const void* w, void* Y, int M, int D, float eps) {
   return launch_rmsnorm((hipStream_t)stream, X, w, Y, M, D, eps);
 }
+extern "C" int vispec_add_rmsnorm(vispec_ctx*, void* stream, void* X, const void* R, const void* w, void* Y, int M, int D, float eps) {
+  if (!X || !R || !w || !Y || M < 1 || D % 8) return fail("add_rmsnorm: bad arguments (D %% 8 == 0)");
+  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16_t*)X, (const bf16_t*)R, (const bf16_t*)w, (bf16_t*)Y, D, eps);
+  KCHK();
+  return 0;
+}
 // Causal attention of a prompt's L rows over the K/V rows [0, L) its prefill has just written (csrc/kernels.h: prefill_attn_kernel).
 extern "C" int vispec_prefill_attention(vispec_ctx*, void* stream, const void* q, int ldq, const void* k_cache, const void* v_cache, int s_max,
                                         int H, int H_kv, int L, void* out, int ldo, int eager_scores) {

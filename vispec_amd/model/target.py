@@ -180,8 +180,15 @@ class TargetLM:
             L.check(lib.vispec_rmsnorm(eng.h, st, p(t), p(w), p(out), Ln, c.hidden_size, c.rms_norm_eps))
             return out
 
+        def add_rmsnorm(t, r, w):  # t <- t + r (in place), returns RMSNorm(t) * w: one launch instead of a torch add + the norm
+            out = torch.empty_like(t)
+            L.check(lib.vispec_add_rmsnorm(eng.h, st, p(t), p(r), p(w), p(out), Ln, c.hidden_size, c.rms_norm_eps))
+            return out
+
+        x = x.clone() if x.data_ptr() == inputs_embeds.data_ptr() else x  # the residual stream is updated in place
+        y = None  # the previous layer's down_proj output, added to the residual stream by the next norm's launch
         for i, lw in enumerate(self.w.layers):
-            h = rmsnorm(x, lw["ln1"])
+            h = rmsnorm(x, lw["ln1"]) if y is None else add_rmsnorm(x, y, lw["ln1"])
             qkv = scaled_linear(h, lw["wqkv"], lw["bqkv"], lw.get("wqkv_scale"))  # [L, QKV]
             # rotary at position m (bf16 rounding points of the reference) on q in place; k (rotated) and v -> cache rows [0, L)
             L.check(lib.vispec_rope_append(eng.h, st, p(qkv), Ln, H, Hk, hd, p(cos), p(sin), None, None, p(kv[2 * i]), p(kv[2 * i + 1]), S, None))
@@ -193,13 +200,12 @@ class TargetLM:
             else:
                 q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
                 a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0].transpose(0, 1).reshape(Ln, H * hd)
-            x = x + scaled_linear(a, lw["wo"], None, lw.get("wo_scale"))
-            h = rmsnorm(x, lw["ln2"])
+            h = add_rmsnorm(x, scaled_linear(a, lw["wo"], None, lw.get("wo_scale")), lw["ln2"])
             gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
             L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
-            x = x + scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))
-        hidden = rmsnorm(x, self.w.norm)
+            y = scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))
+        hidden = rmsnorm(x, self.w.norm) if y is None else add_rmsnorm(x, y, self.w.norm)
         logits = scaled_linear(hidden if all_logits else hidden[-1:], self.w.lm_head, None, getattr(self.w, "lm_head_scale", None)).float()
         return logits, hidden.contiguous()
 
