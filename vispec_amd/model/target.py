@@ -22,6 +22,49 @@ from .. import lib as L
 from ..engine import Engine, TargetConfig, TargetWeights
 
 
+_pad_lock = __import__("threading").Lock()
+
+
+def _tune_gate_up_padding(weights, Ln: int, D: int):
+    """hipBLASLt's heuristic picks a stream-K kernel for the prefill's gate|up GEMM at some row counts (LLaVA-7B: [2704 x 4096] x
+    [22016 x 4096]^T 513 us = 0.95 PFLOP/s, but 353 us = 1.4 PFLOP/s with 512 zero rows appended — tools/gateup_split_probe.py).  Once
+    per weight set, at the first prefill, the zero-row paddings {0, 256, 512} of layer 0's matrix are timed at that prompt length and
+    the best one (if it wins by more than 5 %) is applied to a prefill-only copy of every layer's matrix (`wgu_prefill`); the padded
+    output columns are never read (vispec_silu_mul takes the row stride).  bf16 weights only."""
+    if getattr(weights, "gu_pad", None) is not None:
+        return
+    with _pad_lock:
+        if getattr(weights, "gu_pad", None) is not None:
+            return
+        pad_best = 0
+        lw0 = weights.layers[0]
+        if "wgu_scale" not in lw0 and os.environ.get("VISPEC_PREFILL_PAD", "1") != "0" and Ln >= 512:
+            base = lw0["wgu"]
+            x = torch.randn(Ln, D, device=base.device, dtype=base.dtype)
+
+            def timed(w):
+                for _ in range(2):
+                    F.linear(x, w)
+                torch.cuda.synchronize(base.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    F.linear(x, w)
+                e1.record()
+                torch.cuda.synchronize(base.device)
+                return e0.elapsed_time(e1)
+
+            t_best = timed(base)
+            for pad in (256, 512):
+                tp = timed(torch.cat([base, torch.zeros(pad, D, device=base.device, dtype=base.dtype)]))
+                if tp < 0.95 * t_best:
+                    t_best, pad_best = tp, pad
+            if pad_best:
+                for lw in weights.layers:
+                    lw["wgu_prefill"] = torch.cat([lw["wgu"], torch.zeros(pad_best, D, device=base.device, dtype=base.dtype)]).contiguous()
+        weights.gu_pad = pad_best
+
+
 _sdpa_lock = __import__("threading").Lock()
 _sdpa_ready = set()
 
@@ -174,6 +217,7 @@ class TargetLM:
         S = kv.shape[3]
         p = lambda t: C.c_void_p(t.data_ptr())
         native_attn = hd == 128 and os.environ.get("VISPEC_PREFILL_SDPA", "0") != "1"  # (A/B switch: torch's SDPA instead)
+        _tune_gate_up_padding(self.w, Ln, c.hidden_size)
 
         def rmsnorm(t, w):
             out = torch.empty_like(t)
@@ -201,7 +245,7 @@ class TargetLM:
                 q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
                 a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0].transpose(0, 1).reshape(Ln, H * hd)
             h = add_rmsnorm(x, scaled_linear(a, lw["wo"], None, lw.get("wo_scale")), lw["ln2"])
-            gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))
+            gu = scaled_linear(h, lw.get("wgu_prefill", lw["wgu"]), None, lw.get("wgu_scale"))  # [L, 2I (+ padding columns)]
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
             L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
             y = scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))
