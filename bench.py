@@ -456,6 +456,8 @@ def main():
     else:
         acc_sum = float(sum(accs))
     value = tokens / dt
+    if os.environ.get("VISPEC_BENCH_DEBUG"):
+        log(f"[rank {rank}] prefill gate|up padding chosen: {getattr(sm.base_model.w, 'gu_pad', None)} rows")
 
     extra = {}
     if rank == 0:
