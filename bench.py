@@ -113,6 +113,18 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
     return sms, tcfg, t_rep
 
 
+def request_plan(n_requests, rank, world, lanes, cohort, n_steps):
+    """plan[lane][step] = ids of the requests that lane of this rank runs in that step (a lane takes them `cohort` at a time on one
+    weight pass).  n_requests > 0: BASELINE config 4's fixed batch, request i -> replica i mod world (parallel.shard_requests), then
+    lane by lane ("strong" scaling: the batch is fixed); 0: every (rank, lane) runs `cohort` requests of its own per step ("weak")."""
+    from vispec_amd import parallel
+    if n_requests > 0:
+        mine = parallel.shard_requests(n_requests, rank, world)
+        return [[[i + s * n_requests for i in mine[lane::lanes]] for s in range(n_steps)] for lane in range(lanes)], "strong"
+    return [[[((rank * lanes + lane) + s * world * lanes) * cohort + j for j in range(cohort)] for s in range(n_steps)]
+            for lane in range(lanes)], "weak"
+
+
 def run_lanes(fns):
     """Run one callable per lane concurrently (one host thread + one HIP stream per lane); returns their results."""
     import threading
@@ -382,14 +394,7 @@ def main():
     streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
     from vispec_amd.model.spec_model_ours import specgenerate_cohort
-    # plan[lane][step] = request ids that lane runs in that step
-    if args.requests > 0:  # strong scaling: the batch is fixed, request i -> replica i mod N (parallel.shard_requests), then lane
-        mine = parallel.shard_requests(args.requests, rank, world)
-        plan = [[[i + s * args.requests for i in mine[lane::R]] for s in range(W + K)] for lane in range(R)]
-        scaling = "strong"
-    else:  # weak scaling: every (rank, lane) runs one request (cohort: two) of its own per step
-        plan = [[[((rank * R + lane) + s * world * R) * CO + j for j in range(CO)] for s in range(W + K)] for lane in range(R)]
-        scaling = "weak"
+    plan, scaling = request_plan(args.requests, rank, world, R, CO, W + K)
     req_cache = {}
 
     def get_req(i):

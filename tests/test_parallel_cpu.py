@@ -43,3 +43,25 @@ def test_replicate_weights_world2(mode):
     for rank, same_before, ok, eq0, nbytes, shard in res:
         assert not same_before and ok and eq0 and nbytes > 0
     assert sorted(res[0][5] + res[1][5]) == list(range(7)) and not set(res[0][5]) & set(res[1][5])
+
+
+@pytest.mark.parametrize("world,lanes,cohort,n_requests", [(1, 4, 4, 0), (2, 4, 4, 0), (8, 4, 4, 0), (8, 4, 4, 64), (2, 3, 2, 7), (8, 4, 1, 64)])
+def test_bench_request_plan_covers_every_request_exactly_once(world, lanes, cohort, n_requests):
+    """bench.py's work split over ranks x lanes x cohorts (BASELINE config 4: 64 requests over 8 replicas): in every step each request id
+    appears on exactly one (rank, lane); weak scaling gives every lane one full cohort per step, the fixed batch is dealt i mod world."""
+    sys.path.insert(0, ROOT)
+    import bench
+    steps = 3
+    plans = [bench.request_plan(n_requests, r, world, lanes, cohort, steps) for r in range(world)]
+    assert {p[1] for p in plans} == {"strong" if n_requests else "weak"}
+    for s in range(steps):
+        ids = [i for p, _ in plans for lane in p for i in lane[s]]
+        assert len(ids) == len(set(ids))
+        if n_requests:
+            assert sorted(ids) == [i + s * n_requests for i in range(n_requests)]
+            for r, (p, _) in enumerate(plans):
+                assert all((i - s * n_requests) % world == r for lane in p for i in lane[s])
+        else:
+            assert len(ids) == world * lanes * cohort and all(len(lane[s]) == cohort for p, _ in plans for lane in p)
+    all_ids = [i for p, _ in plans for lane in p for st in lane for i in st]
+    assert len(all_ids) == len(set(all_ids)), "no request is reused across steps"
