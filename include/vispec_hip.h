@@ -253,8 +253,8 @@ int vispec_set_graphs(vispec_ctx*, int on);
 int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, direct runs} */
 /* Launch shape of the GEMMs of a three- or four-request cohort round (no reference counterpart: the reference is batch-1 only,
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that
-   several request lanes keep busy), 2 (twice the workgroups), 0 (two exactly where four would leave half of the CUs idle: a single
-   lane).  Results are bit-identical in every setting. */
+   several request lanes keep busy), 3 or 2 (more, smaller workgroups), 0 (the smallest of {2, 3, 4} whose grid still runs in one round
+   of CUs: a single lane).  Results are bit-identical in every setting. */
 int vispec_set_wide_row_blocks(vispec_ctx* leader, int row_blocks);
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
    HIP events on its own stream.  kinds 0..4 = skinny GEMM {none, residual, swiglu, split-K partial, split-K reduce(+norm)}, 9 = attention

@@ -25,13 +25,13 @@ from test_loop_gpu import IMG_TOK, build  # noqa: E402
                                  (32064, 512), (22016 // 2, 4096)])
 @pytest.mark.parametrize("n_req,m_tile", [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("row_blocks", [4, 2])
+@pytest.mark.parametrize("row_blocks", [4, 3, 2])
 def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi, row_blocks):
     if epi == 2 and N % 16:
         pytest.skip("SwiGLU needs N % 16 == 0")
     if N * K > 2e7 and (m_tile not in (30,) or epi == 1):
         pytest.skip("large shapes: the bench configurations only")
-    if row_blocks == 2 and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1)):
+    if row_blocks != 4 and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1)):
         pytest.skip("two row blocks per workgroup: the bench row counts and a one-row tile")
     L.check(lib.vispec_set_wide_row_blocks(engine.h, row_blocks))
     rng = np.random.default_rng(N + 3 * K + 17 * n_req + m_tile + epi)

@@ -1,6 +1,6 @@
 """The wide-cohort GEMM (csrc/gemm_wide.h) shape by shape at M = 120 (four requests), kernel alone, weights rotated through > 1 GB:
 variant 9SS00 = the kernel, 9SS01 = without its activation DMAs, 9SS02 = without its weight loads (wrong results on purpose: what each
-of the two streams costs), 9SS03 = two row blocks per workgroup instead of four, next to the single-request kernel (1SS00, M = 30) on the same weights.
+of the two streams costs), 9SS03 / 9SS04 = two / three row blocks per workgroup instead of four, next to the single-request kernel (1SS00, M = 30) on the same weights.
     python tools/wide_bench.py [extra variant digits ...]"""
 import ctypes as C
 import os
@@ -19,7 +19,7 @@ dcfg = DraftConfig(T["D"], T["H"], T["I"], T["V"], T["max_pos"])
 eng = Engine(tcfg, dcfg, TargetWeights.from_state_dict(tcfg, synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"]), dev),
              DraftWeightsDev.from_state_dict(dcfg, synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"]), 2, dev))
 SHAPES = [("qkv", 12288, 4096, 1), ("o_proj", 4096, 4096, 4), ("gate_up", 22016, 4096, 1), ("down", 4096, 11008, 4), ("lm_head", 32064, 4096, 1)]
-UN = [int(v) for v in sys.argv[1:]] or [0, 3]
+UN = [int(v) for v in sys.argv[1:]] or [0, 4, 3]
 p = lambda t: C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

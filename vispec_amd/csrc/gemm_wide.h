@@ -74,7 +74,8 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
   const bool tile_ok = tile_raw < tiles;
   const int tile = tile_ok ? tile_raw : 0;  // a ragged last workgroup streams tile 0 again and stores nothing
   constexpr int KSTEP = W8 ? 32 : 16;       // k per 1 KiB weight tile
-  constexpr int PPW = 4 * NL / RB;          // 1 KiB activation pieces a wave moves per 64-k group (the quarter's RB waves share 4 NL)
+  constexpr int PPW = (4 * NL + RB - 1) / RB;  // 1 KiB activation pieces a wave moves per 64-k group (the quarter's RB waves share 4 NL;
+                                               // RB = 3 with NL = 4: 18 slots for 16 pieces, the last piece is fetched three times)
   constexpr int LOADS = W8 ? 2 : 4;         // weight tiles per 64-k group
   const int KS = K / KSTEP;
   const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
   unsigned xoff[PPW], xdst[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int q = rb * PPW + i, mt = q >> 2, pc = q & 3;
+    const int q = min(rb * PPW + i, 4 * NL - 1), mt = q >> 2, pc = q & 3;
     const int row = 32 * mt + 8 * pc + (lane >> 3), g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
     xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;
     xdst[i] = lds_q + (unsigned)(mt * 4 + pc) * 1024u;

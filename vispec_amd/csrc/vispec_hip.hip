@@ -223,7 +223,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_, 0, RB_>,   \
       (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_, 0, RB_>, \
       (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_, 0, RB_>
-#define WIDE_ALL_EPI(W8_, NL_) WIDE_ALL_EPI_RB(W8_, NL_, 4), WIDE_ALL_EPI_RB(W8_, NL_, 2)
+#define WIDE_ALL_EPI(W8_, NL_) WIDE_ALL_EPI_RB(W8_, NL_, 4), WIDE_ALL_EPI_RB(W8_, NL_, 3), WIDE_ALL_EPI_RB(W8_, NL_, 2)
     const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4),
                           (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>};
 #undef WIDE_ALL_EPI
@@ -503,18 +503,19 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   const int M = 32 * (n_req - 1) + o.m_tile;
   // Row blocks per workgroup (vispec_set_wide_row_blocks): four = one byte of X per byte of W, the form for a GPU that several lanes
   // keep full; two = twice the workgroups at twice the X traffic, which pays on a single stream where four row blocks leave half
-  // of the CUs without a workgroup (0 = two exactly there).  tools/wide_bench.py; one cohort lane 9.5 -> 8.7 ms per round with 0,
-  // four lanes 2064 -> 1980 tok/s.
+  // of the CUs without a workgroup; three for gate|up (230 instead of 172 workgroups).  0 = the smallest of {2, 3, 4} whose grid still
+  // runs in one round of CUs.  tools/wide_bench.py; one cohort lane 9.5 -> 8.7 ms per round with 0, four lanes 2064 -> 1980 tok/s.
   const int rb_opt = ctx ? ctx->wide_rb : 4;
+#define WIDE_LRB(EPI_, W8_, NL_, RB_, YPTR, LDY, SPLITS)                                                                                 \
+  PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_, 0, RB_>), dim3((tiles + RB_ - 1) / RB_, SPLITS), dim3(RB_ * 256), WIDE_LDS_BYTES, s, x, ldx, w, \
+          b, YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
-    const bool rb2_ = rb_opt == 2 || (rb_opt == 0 && ((tiles + 3) / 4) * (SPLITS) <= 128);                                              \
-    if (rb2_)                                                                                                                           \
-      PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_, 0, 2>), dim3((tiles + 1) / 2, SPLITS), dim3(512), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r, \
-              o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                                    \
-    else                                                                                                                                \
-      PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_>), dim3((tiles + 3) / 4, SPLITS), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r, \
-              o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                                    \
+    int rb_ = rb_opt;                                                                                                                   \
+    if (rb_ == 0) rb_ = ((tiles + 1) / 2) * (SPLITS) <= 256 ? 2 : (((tiles + 2) / 3) * (SPLITS) <= 256 ? 3 : 4);  /* most workgroups in one round of CUs */ \
+    if (rb_ == 2) WIDE_LRB(EPI_, W8_, NL_, 2, YPTR, LDY, SPLITS);                                                                       \
+    else if (rb_ == 3) WIDE_LRB(EPI_, W8_, NL_, 3, YPTR, LDY, SPLITS);                                                                  \
+    else WIDE_LRB(EPI_, W8_, NL_, 4, YPTR, LDY, SPLITS);                                                                                \
   } while (0)
 #define WIDE_D(EPI_, YPTR, LDY, SPLITS)                                                                       \
   do {                                                                                                        \
@@ -562,6 +563,7 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   }
 #undef WIDE_D
 #undef WIDE_L
+#undef WIDE_LRB
   KCHK();
   prof_end(s);
   prof_begin(s, 4, 0.0);
@@ -943,7 +945,10 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
-    if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
+    if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
+      hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 3>), dim3((tiles + 2) / 3, S), dim3(768), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    else if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 2>), dim3((tiles + 1) / 2, S), dim3(512), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
@@ -1180,7 +1185,7 @@ extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
 }
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   if (!ctx) return fail("null ctx");
-  if (row_blocks != 0 && row_blocks != 2 && row_blocks != 4) return fail("wide_row_blocks: 4, 2, or 0 (= two where four leave half of the CUs idle)");
+  if (row_blocks != 0 && (row_blocks < 2 || row_blocks > 4)) return fail("wide_row_blocks: 4, 3, 2, or 0 (= the smallest that still runs in one round of CUs)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
