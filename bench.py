@@ -21,6 +21,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 # Four lanes need four hardware queues of their own next to the default stream's: the ROCm runtime maps streams onto
 # GPU_MAX_HW_QUEUES (default 4) queues and two lanes sharing one queue serialise (883 vs 1011 tok/s measured).  Must be in the
@@ -301,6 +302,54 @@ def cpu_config0_leg(sm, tcfg, rounds=8, ar_steps=3, budget_s=40.0):
                 seconds_per_round=round(t_dec / n_rounds, 3), tau_measured=round(float(np.mean(r["accept_lengths"])), 3),
                 tokens_per_s_decode=round(new_tok / t_dec, 3), tokens_per_s_end_to_end=round(new_tok / wall, 3),
                 ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar_decode=round(new_tok / t_dec * t_ar, 3), cores=cores)
+
+
+def vision_tower_leg(tcfg, device, n_img, iters=5):
+    """The reference harness brackets the WHOLE specgenerate call, vision tower included (gen_spec_answer_coco_caption.py:221-232), for the
+    speculative and the AR run alike.  The timed region above starts from the projected image features (no vision checkpoint exists on
+    the box), so this leg times the front-end the request would have gone through — HF's own modules at the published architecture
+    (LLaVA-1.6: CLIP ViT-L/14-336, 5 anyres tiles of a 640x427 image -> 2144 tokens (672x672 -> 2928), 2-layer projector, unpad + image_newline
+    packing; Qwen2.5-VL: its 32-layer window-attention tower + patch merger), random-initialised in bf16, on PyTorch-ROCm as the north star
+    prescribes — and `speedpy_comparable.with_vision_tower` adds that time to both walls.  -> (seconds per image set, description)"""
+    from vispec_amd.model.vision import HFVisionFrontEnd
+    dt = torch.bfloat16
+    if MODEL.startswith("qwen"):
+        from transformers import Qwen2_5_VLConfig
+        from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel as Visual
+        vc = Qwen2_5_VLConfig().vision_config
+        # the published 7B checkpoint's vision_config (HF's class defaults are not it): 32 blocks of width 1280 / MLP 3420, merger to 3584
+        vc.hidden_size, vc.intermediate_size, vc.num_heads, vc.depth, vc.out_hidden_size = 1280, 3420, 16, 32, tcfg.hidden_size
+        grids = [(1, 32, 32)] * 4 if MODEL == "qwen7b" else [(1, 68, 92)]
+        fe = HFVisionFrontEnd("Qwen2_5_VLForConditionalGeneration", SimpleNamespace(vision_config=vc), Visual._from_config(vc).to(device, dt).eval(), None, None)
+        n_patch = sum(t * h * w for t, h, w in grids)
+        pix = torch.randn(n_patch, vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2, device=device, dtype=dt)
+        call = lambda: fe.features(pix, image_grid_thw=torch.tensor(grids, device=device))
+        what = f"Qwen2.5-VL vision tower ({vc.depth} layers, hidden {vc.hidden_size}), grids {grids}"
+    else:
+        from transformers import AutoModel, LlavaNextConfig
+        from transformers.models.llava_next.modeling_llava_next import LlavaNextMultiModalProjector
+        c = LlavaNextConfig()
+        c.text_config.hidden_size = tcfg.hidden_size
+        size = {2144: (427, 640), 2928: (672, 672), 2340: (480, 640)}.get(n_img)
+        if size is None:
+            raise ValueError(f"no anyres image size known for {n_img} image tokens")
+        fe = HFVisionFrontEnd("LlavaNextForConditionalGeneration", c, AutoModel.from_config(c.vision_config).to(device, dt).eval(),
+                              LlavaNextMultiModalProjector(c).to(device, dt).eval(), torch.zeros(tcfg.hidden_size, device=device, dtype=dt))
+        pix = torch.randn(1, 5, 3, c.vision_config.image_size, c.vision_config.image_size, device=device, dtype=dt)
+        sizes = torch.tensor([list(size)])
+        call = lambda: fe.features(pix, image_sizes=sizes)
+        vc = c.vision_config
+        what = f"CLIP ViT-L/{vc.patch_size}-{vc.image_size} ({vc.num_hidden_layers} layers) on 5 anyres tiles of a {size[1]}x{size[0]} image + projector + unpad/newline packing"
+    for _ in range(2):
+        f = call()
+    if f.shape[0] != n_img:
+        raise ValueError(f"vision front-end produced {f.shape[0]} tokens, the request has {n_img}")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        call()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / iters, what
 
 
 def self_launch(n):
@@ -593,6 +642,13 @@ def main():
                 b_ar = algorithmic_bytes_per_ar_step(tcfg, n_mid, fp8)
                 spc.update(ar_tokens_per_s=round(n_ar / t_ar, 2), speedup_vs_ar=round(spc["tokens_per_s"] / (n_ar / t_ar), 3),
                            published_speedup=None, ar_roofline_frac_of_8TBps=round(b_ar * (n_ar / t_ar) / 8e12, 4))
+                try:  # the reference's wall clock also holds the vision tower, in both runs (see vision_tower_leg)
+                    t_vis, vis_what = vision_tower_leg(tcfg, device, n_img)
+                    spc["with_vision_tower"] = dict(vision_s=round(t_vis, 4), front_end=vis_what + " (random-initialised HF modules, bf16, PyTorch-ROCm)",
+                                                    tokens_per_s=round(int(new_token) / (t_req + t_vis), 2), ar_tokens_per_s=round(n_ar / (t_ar + t_vis), 2),
+                                                    speedup_vs_ar=round((int(new_token) / (t_req + t_vis)) / (n_ar / (t_ar + t_vis)), 3))
+                except Exception as e:
+                    spc["with_vision_tower"] = f"not measured: {type(e).__name__}: {e}"[:200]
                 # greedy invariance at full size: speculative tokens == AR tokens of the same target
                 if args.temperature <= 1e-5:
                     nmin = min(ar.shape[1], out.shape[1])
