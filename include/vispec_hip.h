@@ -113,7 +113,9 @@ int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, c
 /* The GEMM of a cohort round at unit level (tests): n_req = 2..4 requests of m_tile <= 32 rows each; request t's rows are rows
    32t .. 32t + m_tile - 1 of X / Y / R (which therefore span 32 n_req rows; rows beyond m_tile of a tile are neither read for results
    nor written).  Same epilogues as vispec_gemm_skinny (0 none, 1 +R, 2 SwiGLU).  Row for row bit-identical to vispec_gemm_skinny on the
-   request's own rows. */
+   request's own rows.  m_tile in [-8, -1] = the draft's slab form: the requests have -m_tile <= 8 live rows each (top_k rows of a tree
+   level, the catch-up rows, the root row: cnets_ours.py:1090-1165) and share ONE activation tile of the launch — same row placement in
+   X / Y / R, same results, the weight pass at a single request's cost. */
 int vispec_gemm_cohort(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* wscale /* fp8 image: per-row scales, else NULL */,
                        const void* bias, void* Y, int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue);
 /* tuning hook for tools/gemm_bench.py: explicit decomposition, variant = S*100 + {0:4,1:8 waves}*10 + {0:4,1:8,2:16 unroll} */

@@ -84,6 +84,66 @@ def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, 
         np.testing.assert_array_equal(Y[32 * t:32 * t + m_tile].view(torch.int16).cpu().numpy(), Y1[:m_tile].view(torch.int16).cpu().numpy())
 
 
+# The draft's GEMMs of a cohort (csrc/kernels.h, gemm_w32_kernel SLAB): the requests have at most 8 live rows each (top_k rows of a tree
+# level, depth + 2 catch-up rows, the root row) and share ONE activation tile — tile row 8 t + i is row 32 t + i of X / Y / R.  Same bar:
+# row for row bit-identical to the single-request launch; nothing outside the live rows is written.
+@pytest.mark.parametrize("N,K", [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (4096, 8192), (12288, 4096), (4096, 11008),
+                                 (64, 64), (32064, 512), (22016 // 2, 4096)])
+@pytest.mark.parametrize("n_req,rows", [(4, 8), (4, 5), (3, 8), (2, 8), (4, 1), (2, 3)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_slab_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, rows, epi):
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    if N * K > 2e7 and ((n_req, rows) not in ((4, 8), (4, 5)) or epi == 1):
+        pytest.skip("large shapes: the bench row counts only")
+    rng = np.random.default_rng(N + 3 * K + 17 * n_req + rows + epi)
+    nrows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((nrows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(nrows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    X, W, B, R = tb(x), packed(w, swiglu=(epi == 2)), tb(b), tb(r)
+    for t in range(n_req):
+        X[32 * t + rows:32 * t + 32] = float("nan")  # rows outside a request's live rows may hold anything
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(W), None, p(B), p(Y), N, p(R), N, n_req, -rows, N, K, epi))
+    for t in range(n_req):
+        Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
+        Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
+        L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(Xt), K, p(W), p(B), p(Y1), N, p(Rt), N, rows, N, K, epi))
+        torch.cuda.synchronize()
+        got, want = Y[32 * t:32 * t + 32].view(torch.int16).cpu().numpy(), Y1.view(torch.int16).cpu().numpy()
+        np.testing.assert_array_equal(got[:rows], want[:rows], err_msg=f"request {t}")
+        assert (Y[32 * t + rows:32 * t + 32].float() == 7.0).all(), "rows outside the live rows must stay untouched"
+
+
+@pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008), (152064 // 8, 512)])
+@pytest.mark.parametrize("n_req,rows", [(4, 8), (3, 1)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_slab_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, rows, epi):
+    from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    rng = np.random.default_rng(N + K + n_req + epi)
+    nrows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((nrows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(nrows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    q_u8, sc = quantize_fp8(tb(w))
+    P8 = pack_weight_fp8(swiglu_order(q_u8) if epi == 2 else q_u8)
+    X, B, R = tb(x), tb(b), tb(r)
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, n_req, -rows, N, K, epi))
+    for t in range(n_req):
+        Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
+        Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
+        L.check(lib.vispec_gemm_skinny_fp8(engine.h, stream(), p(Xt), K, p(P8), p(sc), p(B), p(Y1), N, p(Rt), N, rows, N, K, epi))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(Y[32 * t:32 * t + rows].view(torch.int16).cpu().numpy(), Y1[:rows].view(torch.int16).cpu().numpy())
+        assert (Y[32 * t + rows:32 * t + 32].float() == 7.0).all()
+
+
 def single(sm, ids, kw, **gen):
     return sm.specgenerate(ids, log=True, return_acceptance_len=True, **gen, **kw)
 

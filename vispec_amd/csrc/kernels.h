@@ -224,14 +224,21 @@ constexpr int gemm_w32_lds_bytes() {
                                                                                            : (NW * NT * MT * 4096);
 }
 
-template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
+// SLAB (MT = 1, m_tile < 0; the draft GEMMs of a cohort, whose requests have at most 8 live rows each — top_k rows of a tree level, depth + 2
+// catch-up rows, one root row): the ONE activation tile holds up to four requests, tile row m = 8 t + i is row i of request t, which lives
+// at row 32 t + i of X / Y / R (the cohort members' tile-aliased workspaces, unchanged).  The weight pass then costs what a single request's
+// costs — one 32-row activation block per workgroup instead of the 128 rows of the wide form — and a row is the same dot products in the
+// same order as in the single-request launch (split-K partials are indexed by the tile row m).
+template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1, bool SLAB = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
 __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES : 2) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
                                                            int S, const float* __restrict__ wscale, RopeEpi re, int m_tile) {
   // m_tile > 0 ("cohort"): the MT activation tiles belong to different requests, rows 32 mt .. 32 mt + m_tile - 1 of each are valid
   // (instead of the contiguous rows 0 .. M-1); the weights are still streamed once for all of them
-  auto row_ok = [&](int m) { return m_tile > 0 ? ((m & 31) < m_tile) : (m < M); };
+  static_assert(!SLAB || MT == 1, "slab mode packs the requests into one activation tile");
+  auto row_ok = [&](int m) { return SLAB ? ((m & 7) < -m_tile && m < M) : (m_tile > 0 ? ((m & 31) < m_tile) : (m < M)); };
+  auto grow = [&](int m) { return SLAB ? ((m >> 3) << 5) + (m & 7) : m; };  // row of X / Y / R that tile row m stands for
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     const int row = srow0 + i * RPI;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)  // rows >= M read row 0, never stored
-      xo[mt][i] = (unsigned)(row_ok(32 * mt + row) ? 32 * mt + row : 0) * (unsigned)ldx;
+      xo[mt][i] = (unsigned)(row_ok(32 * mt + row) ? grow(32 * mt + row) : 0) * (unsigned)ldx;
     woff[i] = (seg >> 1) * XS_STEP + (seg & 1) * XS_HALF + row * 16;
   }
   const int roff = hi * XS_HALF + j * 16;
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     const bf16_t* px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      px[mt] = X + (size_t)(row_ok(32 * mt + j) ? 32 * mt + j : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
+      px[mt] = X + (size_t)(row_ok(32 * mt + j) ? grow(32 * mt + j) : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
     for (int rstep = n_groups * LOADS; rstep < n_steps; ++rstep) {
       const uint4 av = pa0[0];
       const uint4 av1 = pa1[0];
@@ -417,8 +424,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     const int tile_b = tile + tb * tile2_off;
     for (int mt = 0; mt < MT; ++mt) {
       const int m = 32 * mt + j;
-      const int rq = m_tile > 0 ? mt : 0;        // request owning this tile
-      const int mr = m_tile > 0 ? j : m;         // row index inside the request
+      const int rq = SLAB ? (j >> 3) : (m_tile > 0 ? mt : 0);  // request owning this tile (slab mode: this tile row)
+      const int mr = SLAB ? (j & 7) : (m_tile > 0 ? j : m);    // row index inside the request
       if (wave < 2 * NT && row_ok(m)) {
         const int qq = wave & 1;
         float a[4], b[4];
@@ -435,7 +442,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
         }
         const int ncol = tile_b * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
         const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
-        const PosSpec& ps_ = re.ps[rq];
+        // slab mode: the request differs from lane to lane — select its arguments under branches (an indexed kernel argument would be
+        // copied to scratch, DESIGN.md "A compiler lesson")
+        PosSpec ps_s = re.ps[0];
+        bf16_t *kc_s = re.kc[0], *vc_s = re.vc[0];
+        if (SLAB) {
+          if (rq == 1) { ps_s = re.ps[1]; kc_s = re.kc[1]; vc_s = re.vc[1]; }
+          if (rq == 2) { ps_s = re.ps[2]; kc_s = re.kc[2]; vc_s = re.vc[2]; }
+          if (rq == 3) { ps_s = re.ps[3]; kc_s = re.kc[3]; vc_s = re.vc[3]; }
+        }
+        const PosSpec& ps_ = SLAB ? ps_s : re.ps[rq];
+        bf16_t* const kc_ = SLAB ? kc_s : re.kc[rq];
+        bf16_t* const vc_ = SLAB ? vc_s : re.vc[rq];
         const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + mr;
         if (h < re.H + re.H_kv) {
           const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of a[] / b[]
@@ -453,8 +471,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
             o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
             o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
           }
-          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
-                                   : re.kc[rq] + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)grow(m) * ldy + c1
+                                   : kc_ + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
           *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
         } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
             o1[r] = rdbf(x1);
             o2[r] = rdbf(x2);
           }
-          bf16_t* dst = re.vc[rq] + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+          bf16_t* dst = vc_ + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
           *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
         }
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
           const float act = rdbf(y / (1.0f + __expf(-y)));
           o[r] = rdbf(act * u);
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)grow(m) * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
       }
     }
     return;
@@ -542,10 +560,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
           float y = v[r];
           if (bias) y += bf2f(bias[n + r]);
           y = rdbf(y);
-          if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+          if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)grow(m) * ldr + n + r]) + y);
           o[r] = y;
         }
-        *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(Y + (size_t)grow(m) * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
       }
     }
   }
@@ -565,6 +583,8 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   __shared__ float partsum[16];
   const int m = blockIdx.x;
   if (m_tile > 0 && (m & 31) >= m_tile) return;  // cohort mode: padding rows between the requests' tiles
+  if (m_tile < 0 && (m & 7) >= -m_tile) return;  // slab mode (gemm_w32_kernel SLAB): partial row m = 8 t + i is row 32 t + i of Y / R / normed
+  const int mo = m_tile < 0 ? ((m >> 3) << 5) + (m & 7) : m;
   const int nthreads = blockDim.x;
   const bool one_pass = N <= nthreads * 4;
   float ss = 0.f;
@@ -575,7 +595,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) p[sl] = *reinterpret_cast<const float4*>(part + ((size_t)min(sl, S - 1) * Mpad + m) * N + n);
     uint2 rv = make_uint2(0, 0), bv = make_uint2(0, 0);
-    if (R) rv = *reinterpret_cast<const uint2*>(R + (size_t)m * ldr + n);
+    if (R) rv = *reinterpret_cast<const uint2*>(R + (size_t)mo * ldr + n);
     if (bias) bv = *reinterpret_cast<const uint2*>(bias + n);
     if (normed && one_pass) wkeep = *reinterpret_cast<const uint2*>(norm_w + n);
     float4 a = p[0];
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
       o[r] = y;
       ss += y * y;
     }
-    if (Y) *reinterpret_cast<uint2*>(Y + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+    if (Y) *reinterpret_cast<uint2*>(Y + (size_t)mo * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
     if (normed) {
       if (one_pass) { keep[0] = o[0]; keep[1] = o[1]; keep[2] = o[2]; keep[3] = o[3]; }
       else *reinterpret_cast<float4*>(hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
       const bf16_t* we = reinterpret_cast<const bf16_t*>(&wkeep);
       const float o0 = bf2f(we[0]) * rdbf(keep[0] * inv), o1 = bf2f(we[1]) * rdbf(keep[1] * inv);
       const float o2 = bf2f(we[2]) * rdbf(keep[2] * inv), o3 = bf2f(we[3]) * rdbf(keep[3] * inv);
-      *reinterpret_cast<uint2*>(normed + (size_t)m * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
+      *reinterpret_cast<uint2*>(normed + (size_t)mo * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
     }
     return;
   }
@@ -627,7 +647,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
     const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
     const float o0 = bf2f(we[0]) * rdbf(h.x * inv), o1 = bf2f(we[1]) * rdbf(h.y * inv);
     const float o2 = bf2f(we[2]) * rdbf(h.z * inv), o3 = bf2f(we[3]) * rdbf(h.w * inv);
-    *reinterpret_cast<uint2*>(normed + (size_t)m * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
+    *reinterpret_cast<uint2*>(normed + (size_t)mo * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
   }
 }
 

@@ -412,6 +412,8 @@ struct GemmOut {
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
   int m_tile = 0;  // > 0: cohort mode — two requests share the weight pass: tile t holds request t's rows 32t .. 32t + m_tile - 1 (M = 32 + m_tile)
+                   // < 0: slab mode — 2..4 requests of -m_tile <= 8 rows each packed into ONE activation tile (M = 8 (n - 1) - m_tile): tile row
+                   //      8t + i is row 32t + i of X / Y / R (kernels.h, gemm_w32_kernel SLAB)
 };
 // MT = number of 32-row activation tiles (M <= 32*MT): each weight tile held in registers feeds MT MFMAs, so trees of 33..64
 // nodes (and two requests sharing a launch) still stream every weight once.
@@ -419,13 +421,20 @@ template <int MT>
 static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split) {
   if (M < 1 || M > 32 * MT) return fail("gemm_skinny: M out of range");
+  if (o.m_tile < 0 && MT != 1) return fail("gemm_skinny: slab mode is a one-tile launch");
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
   const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
-  PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
-                     T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile)
+  do {                                                                                                                                    \
+    if (MT == 1 && o.m_tile < 0)                                                                                                          \
+      PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT, (MT == 1)>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
+              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile);                                            \
+    else                                                                                                                                  \
+      PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w,       \
+              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile);                                            \
+  } while (0)
   // Two activation tiles: a workgroup takes TWO row blocks (tile, tile + tiles/2) and feeds both from each staged activation
   // fragment (NT = 2) — the activation re-read from L2 is what the second tile costs (kernels.h), and with several lanes in flight
   // the halved workgroup count costs nothing (tools/gemm_mt2_concurrency.py: 4.03 -> 5.14 TB/s aggregate on 3 streams).
@@ -578,6 +587,11 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
 // m_tile > 0: cohort mode, M = 32 (n_req - 1) + m_tile with n_req in [2,4] requests of m_tile rows each (tile t = request t)
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1) {
+  if (o.m_tile < 0) {  // slab mode: the requests' <= 8 live rows share one activation tile
+    const int rows = -o.m_tile, n_req = (M - rows) / 8 + 1;
+    if (rows > 8 || (M - rows) % 8 || n_req < 2 || n_req > 4) return fail("gemm_skinny: slab mode wants M = 8 (n - 1) + rows, rows <= 8, n in [2,4]");
+    return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
+  }
   if (o.m_tile > 0) {
     const int n_req = (M - o.m_tile) / 32 + 1;
     if (o.m_tile > 32 || (M - o.m_tile) % 32 || n_req < 2 || n_req > 4) return fail("gemm_skinny: cohort mode wants M = 32 (n - 1) + m_tile, n in [2,4]");
@@ -670,9 +684,10 @@ struct QkvReq {  // per-request part of a q|k|v projection: positions and the ca
 // streamed once for all of them.
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, const QkvReq* rq, int n_req,
-                           int s_max) {
+                           int s_max, bool slab = false) {
   const int N = (H + 2 * H_kv) * 128;
-  const int m_tile = n_req >= 2 ? M : 0, Mk = n_req >= 2 ? 32 * (n_req - 1) + M : M;
+  slab = slab && n_req >= 2 && M <= 8;  // slab: the requests' rows packed into one activation tile (request t still at rows 32t .. of X / qkv)
+  const int m_tile = slab ? -M : (n_req >= 2 ? M : 0), Mk = slab ? 8 * (n_req - 1) + M : (n_req >= 2 ? 32 * (n_req - 1) + M : M);
   if (!qkv_rope_fused(N)) {
     if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, Mk, N, K, EPI_NONE, wscale, m_tile)) return -1;
     for (int t = 0; t < n_req; ++t)
@@ -685,7 +700,7 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
   for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
-  if (n_req > 2) {  // three or four requests: the wide-cohort kernel
+  if (n_req > 2 && !slab) {  // three or four requests: the wide-cohort kernel
     GemmOut o;
     o.wscale = (const float*)wscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
     return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, EPI_ROPE, o, -1, &re);
@@ -695,7 +710,14 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT_>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
                      (const float*)wscale, re, m_tile)
-  if (Mk <= 32) { if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV(true, 1, 2); else if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
+  if (slab) {
+#define VISPEC_QKV_SLAB(W8_, NT_)                                                                                                          \
+  PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, 1, true>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, 1>()), s, \
+                     (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
+                     (const float*)wscale, re, m_tile)
+    if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV_SLAB(true, 2); else if (wscale) VISPEC_QKV_SLAB(true, 1); else VISPEC_QKV_SLAB(false, 1);
+#undef VISPEC_QKV_SLAB
+  } else if (Mk <= 32) { if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV(true, 1, 2); else if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
   else if (g_mt2_single_block || (wscale && !VISPEC_W8_PAIR)) { if (wscale) VISPEC_QKV(true, 2, 1); else VISPEC_QKV(false, 2, 1); }
   else { if (wscale) VISPEC_QKV(true, 2, 2); else VISPEC_QKV(false, 2, 2); }  // N %% 128 == 0: the tile count is even
 #undef VISPEC_QKV
@@ -910,7 +932,9 @@ extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, 
 extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* wscale, const void* bias, void* Y,
                                   int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue) {
   if (epilogue < 0 || epilogue > 2) return fail("gemm_cohort: bad epilogue");
-  if (n_req < 2 || n_req > 4 || m_tile < 1 || m_tile > 32) return fail("gemm_cohort: 2..4 requests of 1..32 rows");
+  if (n_req < 2 || n_req > 4 || m_tile == 0 || m_tile > 32 || m_tile < -8) return fail("gemm_cohort: 2..4 requests of 1..32 rows (slab mode: -8..-1)");
+  if (m_tile < 0)  // slab mode: the requests' rows share one activation tile
+    return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 8 * (n_req - 1) - m_tile, N, K, epilogue, wscale, m_tile);
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 32 * (n_req - 1) + m_tile, N, K, epilogue, wscale, m_tile);
 }
 // skinny GEMM (+bias, +residual R) with the following RMSNorm fused: Y = bf16(R + bf16(X·W^T + b)), normed = norm_w * rms(Y)
@@ -1242,12 +1266,19 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
 // vispec_ctx, and the "member" ctx's activation buffers are simply the second 32-row tiles of the "leader's" (vispec_ctx_create_member).
 // Every request keeps the reference's batch-1 semantics; its tokens are bit-identical to a run on its own (the 64-row GEMM computes
 // each row with the same tiles, in the same order).  n == 1 is the ordinary single-request round.
+// A/B switch (VISPEC_DRAFT_SLAB=0): the draft GEMMs of a cohort in the tile-per-request form of the target's
+static const bool g_draft_slab = !(getenv("VISPEC_DRAFT_SLAB") && atoi(getenv("VISPEC_DRAFT_SLAB")) == 0);
 struct Cohort {
   int n;
   vispec_ctx* c[4];
   vispec_ctx* lead() const { return c[0]; }
   int mt(int rows) const { return n >= 2 ? rows : 0; }                    // m_tile argument
   int M(int rows) const { return n >= 2 ? 32 * (n - 1) + rows : rows; }  // M argument of a shared GEMM
+  // The draft's GEMMs see at most top_k / depth + 2 / 1 live rows per request: with <= 8 of them the requests share ONE activation tile
+  // (slab mode: GemmOut::m_tile < 0) and the weight pass costs what a single request's costs instead of the 128-row wide form.
+  bool slab(int rows) const { return n >= 2 && rows <= 8 && g_draft_slab; }
+  int dmt(int rows) const { return slab(rows) ? -rows : mt(rows); }
+  int dM(int rows) const { return slab(rows) ? 8 * (n - 1) + rows : M(rows); }
 };
 static Cohort solo_cohort(vispec_ctx* ctx) { return Cohort{1, {ctx, nullptr, nullptr, nullptr}}; }
 
@@ -1265,10 +1296,10 @@ static int draft_fuse(const Cohort& co, hipStream_t s, int rows, void* out, int 
       launch_batch<bcast_row_fn, 256>(s, dim3(rows), 0, a, co.n);
       KCHK();
     } else if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
-  if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, co.M(rows), D, 2 * D, EPI_NONE, nullptr,
-                  co.mt(rows)))
+  if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, co.dM(rows), D, 2 * D, EPI_NONE, nullptr,
+                  co.dmt(rows)))
     return -1;
-  return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, co.M(rows), D, 2 * D, EPI_NONE, nullptr, co.mt(rows));
+  return launch_gemm(ctx, s, ctx->dx2, 2 * D, ctx->dw.fc_w, ctx->dw.fc_b, out, ld_out, nullptr, 0, co.dM(rows), D, 2 * D, EPI_NONE, nullptr, co.dmt(rows));
 }
 
 // o_proj + residual -> post_attention_layernorm -> SwiGLU MLP -> + residual for `rows` rows per request (cnets_ours.py:575-600):
@@ -1280,11 +1311,11 @@ static int draft_layer_tail(const Cohort& co, hipStream_t s, int rows, const bf1
   {
     GemmOut o;  // o_proj + residual, post_attention_layernorm fused into the split-K reduce
     o.Y = ctx->dh; o.ldy = D; o.R = resid; o.ldr = D; o.norm_w = ctx->dw.ln2; o.normed = ctx->dn; o.ldn = D; o.eps = c.draft_rms_eps;
-    o.m_tile = co.mt(rows);
-    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, co.M(rows), D, D, EPI_RESIDUAL, o)) return -1;
+    o.m_tile = co.dmt(rows);
+    if (launch_gemm_ex(ctx, s, ctx->dattn, D, ctx->dw.wo, nullptr, co.dM(rows), D, D, EPI_RESIDUAL, o)) return -1;
   }
-  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, Id, nullptr, 0, co.M(rows), Id, D, EPI_SWIGLU, nullptr, co.mt(rows))) return -1;
-  return launch_gemm(ctx, s, ctx->dact, Id, ctx->dw.wdown, nullptr, out, D, ctx->dh, D, co.M(rows), D, Id, EPI_RESIDUAL, nullptr, co.mt(rows));
+  if (launch_gemm(ctx, s, ctx->dn, D, ctx->dw.wgu, nullptr, ctx->dact, Id, nullptr, 0, co.dM(rows), Id, D, EPI_SWIGLU, nullptr, co.dmt(rows))) return -1;
+  return launch_gemm(ctx, s, ctx->dact, Id, ctx->dw.wdown, nullptr, out, D, ctx->dh, D, co.dM(rows), D, Id, EPI_RESIDUAL, nullptr, co.dmt(rows));
 }
 
 // the draft's single decoder layer on `rows` rows per request of dx (cnets_ours.py:545-600); result in dout.
@@ -1312,7 +1343,7 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
     rq[t].vc = x->draft_kv + (size_t)Hd * c.draft_max_pos * 128;
   }
   if (launch_qkv_rope(ctx, s, ctx->dx, D, ctx->dw.wqkv, ctx->dw.bqkv, nullptr, ctx->dqkv, rows, Hd, Hd, D, ctx->dw.rope_cos, ctx->dw.rope_sin, rq,
-                      co.n, c.draft_max_pos))
+                      co.n, c.draft_max_pos, co.slab(rows)))
     return -1;
   {
     AttnCall calls[4];
@@ -1334,7 +1365,7 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
   vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, V = c.vocab_size, k = c.top_k;
-  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(1), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(1)))
+  if (launch_gemm(ctx, s, ctx->dlast, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.dM(1), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.dmt(1)))
     return -1;
   // (a cohort's per-request kernels go out as ONE launch each: launch_batch)
   if (launch_lstopk_cohort(co.c, co.n, s, 1, V, k)) return -1;
@@ -1355,7 +1386,7 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
   for (int lvl = 0; lvl < c.depth; ++lvl) {
     if (draft_fuse(co, s, k, ctx->dx, D, false)) return -1;
     if (draft_layer(co, s, k, lvl)) return -1;
-    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.M(k), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.mt(k)))
+    if (launch_gemm(ctx, s, ctx->dout, D, ctx->tm.lm_head, nullptr, ctx->dlogits, V, nullptr, 0, co.dM(k), V, D, EPI_NONE, ctx->tm.lm_head_scale, co.dmt(k)))
       return -1;
     if (launch_lstopk_cohort(co.c, co.n, s, k, V, k)) return -1;
     if (co.n > 1) {
