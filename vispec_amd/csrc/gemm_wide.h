@@ -27,6 +27,9 @@
 #define WIDE_BUFBYTES (16 * 1024)
 #define WIDE_LDS_BYTES (4 * WIDE_QBYTES)               // 128 KiB: one workgroup per CU
 #define WIDE_MPAD 128
+#ifndef VISPEC_WIDE_DEADROW_REDIRECT  // A/B switch (VISPEC_HIPCC_FLAGS=-DVISPEC_WIDE_DEADROW_REDIRECT=0)
+#define VISPEC_WIDE_DEADROW_REDIRECT 1
+#endif
 
 // Hand-counted memory pipeline.  hipcc's own s_waitcnt placement cannot express it: with an LDS-DMA in flight it waits vmcnt(0) at every use
 // of an ordinary load (MI355X guide, "three .s-level traps"), and around a loop back-edge it falls back to vmcnt(0) for the weight
@@ -105,15 +108,18 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
   // ---- staging of this K-quarter's activations: its 4 waves move [32 NL rows] x [64 k] per group as 4 NL pieces of 8 rows x 128 B (whole
-  // lines), PPW = 4 NL / RB pieces per wave, by LDS-DMA (no staging registers, no ds_write pass).  Rows past m_tile of a tile are fetched too (the
-  // workspaces hold 32 rows per tile) and only ever reach output rows that are not stored.
+  // lines), PPW = 4 NL / RB pieces per wave, by LDS-DMA (no staging registers, no ds_write pass).  Rows past m_tile of a tile hold a copy of
+  // the last live row and only ever reach output rows that are not stored.
   unsigned char* xq = smem_w + kq * WIDE_QBYTES;
   const unsigned lds_q = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xq;
   unsigned xoff[PPW], xdst[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int q = min(rb * PPW + i, 4 * NL - 1), mt = q >> 2, pc = q & 3;
-    const int row = 32 * mt + 8 * pc + (lane >> 3), g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
+    // rows past m_tile of a tile are dead (their output rows are never stored): their lanes re-read the tile's last live row — the same
+    // 128-byte line the live lanes of that row fetch, so the piece costs the TA / L2 one line less per dead row (T = 30: 2 of 32)
+    const int row = 32 * mt + (VISPEC_WIDE_DEADROW_REDIRECT ? min(8 * pc + (lane >> 3), m_tile - 1) : 8 * pc + (lane >> 3)),
+              g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
     xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;
     xdst[i] = lds_q + (unsigned)(mt * 4 + pc) * 1024u;
   }
