@@ -1288,14 +1288,17 @@ static int draft_fuse(const Cohort& co, hipStream_t s, int rows, void* out, int 
   vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size;
-  if (bcast_g)
+  if (bcast_g) {
     if (co.n > 1) {
       auto pk = [&](int t) { return make_pack((const bf16_t*)co.c[t]->dg, co.c[t]->dx1 + D, 2 * D, D); };
       decltype(pk(0)) a[4];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
       launch_batch<bcast_row_fn, 256>(s, dim3(rows), 0, a, co.n);
       KCHK();
-    } else if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) return -1;
+    } else if (launch_bcast(s, ctx->dg, ctx->dx1 + D, 2 * D, rows, D)) {
+      return -1;
+    }
+  }
   if (launch_gemm(ctx, s, ctx->dx1, 2 * D, ctx->dw.imgfc_w, ctx->dw.imgfc_b, ctx->dx2 + D, 2 * D, nullptr, 0, co.dM(rows), D, 2 * D, EPI_NONE, nullptr,
                   co.dmt(rows)))
     return -1;
