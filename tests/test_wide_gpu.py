@@ -3,6 +3,7 @@ K-quarters sharing each staged activation group).  The bar is the cohort bar of 
 the single-request kernel's, so a request in a cohort of four produces exactly the tokens it produces alone — and those are the
 oracle's / the reference fixtures'."""
 import ctypes as C
+import dataclasses
 import os
 
 import numpy as np
@@ -181,6 +182,27 @@ def test_cohort_of_three_and_four_equals_the_single_requests(golden_dir, n_req):
     np.testing.assert_array_equal(got2[1][0][0].cpu().numpy(), want[0][0][0].cpu().numpy())
     again = single(sm, *reqs[0], max_new_tokens=budgets[0])
     np.testing.assert_array_equal(again[0][0].cpu().numpy(), want[0][0][0].cpu().numpy())
+
+
+@pytest.mark.parametrize("tree", [dict(total_token=20, depth=5, top_k=4), dict(total_token=12, depth=2, top_k=3), dict(total_token=30, depth=2, top_k=10)])
+@pytest.mark.parametrize("n_req", [2, 4])
+def test_cohorts_with_other_tree_shapes_equal_the_single_requests(n_req, tree):
+    """The draft's slab GEMMs with row counts other than the default's (top_k = 4 / 3 rows per level, depth + 2 = 7 / 4 catch-up rows), and
+    a tree whose levels do not fit a slab (top_k = 10: the tile-per-request form): a cohort request == the same request alone == the oracle."""
+    sm, ot, od = build(50, 60, True, **tree)
+    models = [sm] + [sm.make_cohort_member() for _ in range(n_req - 1)]
+    rng = np.random.default_rng(93 + n_req)
+    reqs = [(torch.from_numpy(rng.integers(3, IMG_TOK, size=n))[None], {}) for n in (17, 11, 23, 14)[:n_req]]
+    budgets = [26, 19, 33, 12][:n_req]
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    got = specgenerate_cohort(models, reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    od.cfg = dataclasses.replace(od.cfg, **tree)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, reqs[0][0][0].numpy(), max_new_tokens=budgets[0], max_pos=T["max_pos"])
+    np.testing.assert_array_equal(got[0][0][0].cpu().numpy(), o_out)
+    assert got[0][3] == o_acc
 
 
 def test_cohort_of_four_on_a_side_stream_with_sampling_seeds():
