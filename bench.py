@@ -102,7 +102,8 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
             torch.cuda.empty_cache()
             tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=True, num_q=TREE["num_q"], rho=RHO[MODEL],
                                          succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
-        log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over RCCL in {t_rep:.2f} s, checksums equal")
+        log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
+            f"in {t_rep:.2f} s, checksums {'equal' if same else 'differ: weights regenerated locally'}")
     sms = []
     for _ in range(lanes):
         base = TargetLM(tcfg, tw)
