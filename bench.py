@@ -58,6 +58,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+REFILL = True  # --no-refill: cohort by cohort
 WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 4)
 
 
@@ -394,11 +395,15 @@ def main():
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 4),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, 4 otherwise")
+    ap.add_argument("--no-refill", action="store_true",
+                    help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
+                         "request's slot at once (continuous batching, the default)")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
                          "replicas (request i -> GPU i mod N, then over that GPU's lanes); 0 = one request per lane per step (weak scaling)")
     args = ap.parse_args()
-    global MODEL, N_IMG, WIDE_RB
+    global MODEL, N_IMG, WIDE_RB, REFILL
+    REFILL = not args.no_refill
     MODEL = args.model
     WIDE_RB = args.wide_row_blocks
     if args.n_img:
@@ -443,7 +448,7 @@ def main():
     K, W = args.steps, args.warmup
     streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
-    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort, specgenerate_stream
     plan, scaling = request_plan(args.requests, rank, world, R, CO, W + K)
     req_cache = {}
 
@@ -458,13 +463,28 @@ def main():
                 get_req(i)
     torch.cuda.synchronize()
 
-    def lane_fn(lane, lo, hi, ar=False):
+    lock = [0] * R  # lockstep rounds a lane executed in continuous-batching mode (slot utilisation = request-rounds / (CO x this))
+
+    def lane_fn(lane, lo_, hi, ar=False):
         def f():
+            lo = lo_
             tok = rnd = 0
             accs = []
             t_lane = time.time()
             torch.cuda.set_device(device)  # HIP's current device is per host thread; a new thread starts on device 0
             with torch.cuda.stream(streams[lane]):
+                if REFILL and CO >= 2 and not ar and sum(len(plan[lane][s_]) for s_ in range(lo, hi)) > CO:
+                    # continuous batching over the lane's CO request slots: the moment a request finishes, its slot takes the lane's next one
+                    mine = [i for s_ in range(lo, hi) for i in plan[lane][s_]]
+                    st_s = {}
+                    outs = specgenerate_stream(pairs[lane], [get_req(i) for i in mine], max_new_tokens=MAX_NEW, temperature=args.temperature,
+                                               seeds=mine, stats=st_s)
+                    for o, new_token, idx, acc in outs:
+                        tok += int(new_token)
+                        rnd += idx + 1
+                        accs += acc
+                    lock[lane] += st_s["rounds"]
+                    lo = hi  # nothing left for the step-by-step loop below
                 for s_ in range(lo, hi):
                     todo = list(plan[lane][s_])
                     while CO >= 2 and not ar and len(todo) >= 2:  # up to CO requests per weight pass
@@ -488,11 +508,12 @@ def main():
                             accs += acc
                 streams[lane].synchronize()
             if os.environ.get("VISPEC_BENCH_DEBUG"):
-                log(f"[rank {rank} lane {lane}] steps {lo}..{hi}: {time.time() - t_lane:.2f} s, {tok} tokens, {rnd} rounds")
+                log(f"[rank {rank} lane {lane}] steps {lo_}..{hi}: {time.time() - t_lane:.2f} s, {tok} tokens, {rnd} rounds")
             return tok, rnd, accs
         return f
 
     run_lanes([lane_fn(l, 0, W) for l in range(R)])
+    lock[:] = [0] * R
     barrier()
     t0 = time.time()
     res = run_lanes([lane_fn(l, W, W + K) for l in range(R)])
@@ -630,6 +651,8 @@ def main():
                                       algorithmic_GB_per_request_round=round(b_req_round / 1e9, 2),
                                       streamed_GBps_per_gpu=round(b_req_round * rounds / world / dt / 1e9, 1),
                                       frac_of_8TBps=round(b_req_round * rounds / world / dt / 8e12, 4))
+            if sum(lock):  # continuous batching: share of the (lockstep round x slot) grid that carried a live request (rank 0's lanes)
+                extra["aggregate"]["slot_utilisation"] = round(sum(r[1] for r in res) / (CO * sum(lock)), 4)
             # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
             #      once on a single lane (latency) and once with the same lane concurrency as the timed region (throughput)
             if not args.no_ar:
@@ -683,7 +706,8 @@ def main():
                     else f"{CO} request{'s' if CO > 1 else ''} on each of {R} concurrent lanes per GPU")
         if CO >= 2:
             per_step += (f" (every lane runs its {CO} batch-1 requests in lockstep on one weight pass: each GEMM of a round is launched once "
-                         f"for all of them)")
+                         f"for all of them" + ("; a lane keeps its request slots full — the slot of a finished request takes the lane's next "
+                                               "request at once (continuous batching over the K steps' requests)" if REFILL and K * CO > CO else "") + ")")
         line = {
             "metric": f"accepted output tokens/sec (ViSpec speculative decoding, {MODELS[MODEL]['name']} + ViSpec draft, T={args.temperature:g})",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -205,6 +205,49 @@ def test_cohorts_with_other_tree_shapes_equal_the_single_requests(n_req, tree):
     assert got[0][3] == o_acc
 
 
+@pytest.mark.parametrize("n_slots,temperature", [(4, 0.0), (3, 0.0), (2, 0.0), (4, 6.0)])
+def test_request_stream_through_the_slots_of_a_cohort_equals_the_single_requests(golden_dir, n_slots, temperature):
+    """Continuous batching (specgenerate_stream): nine requests of ragged lengths and budgets — text and image prompts — through 2..4 request
+    slots; a finished request's slot takes the next request while the others are mid-flight.  Every request returns what it returns alone
+    (tokens, new_token, round count, accept lengths), greedy and sampling; fewer lockstep rounds than cohort-by-cohort execution."""
+    from vispec_amd.model.spec_model_ours import specgenerate_stream
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    models = [sm] + [sm.make_cohort_member() for _ in range(n_slots - 1)]
+    rng = np.random.default_rng(97)
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    reqs = [(torch.from_numpy(g["succ0_ids"])[None], {})]
+    for i, n in enumerate((17, 9, 23, 12, 20, 7, 15, 11)):
+        if i % 3 == 1:  # an image prompt every third request
+            n_img = 11 + i
+            ids = np.concatenate([rng.integers(3, IMG_TOK, 4), np.full(n_img, IMG_TOK), rng.integers(3, IMG_TOK, n)])
+            feats = synth.bf16_grid(rng.standard_normal((n_img, T["D"]), dtype=np.float32) * 0.05)
+            reqs.append((torch.from_numpy(ids)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda())))
+        else:
+            reqs.append((torch.from_numpy(rng.integers(3, IMG_TOK, size=n))[None], {}))
+    budgets = [30, 12, 41, 8, 25, 33, 5, 19, 27]
+    seeds = list(range(40, 49))
+    gen = dict(temperature=temperature, top_k=8) if temperature > 0 else {}
+    want = [single(sm, *r, max_new_tokens=b, seed=sd, **gen) for r, b, sd in zip(reqs, budgets, seeds)]
+    st = {}
+    got = specgenerate_stream(models, reqs, max_new_tokens=budgets, seeds=seeds, stats=st, **gen)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3]), f"request {t}"
+    per_request = [w[2] + 1 for w in want]
+    assert st["request_rounds"] == sum(per_request)
+    by_cohort = sum(max(per_request[lo:lo + n_slots]) for lo in range(0, len(per_request), n_slots))
+    assert st["rounds"] <= by_cohort and st["rounds"] >= -(-sum(per_request) // n_slots)
+    if temperature == 0:  # ... and request 0 is the oracle's / the reference fixture's stream
+        o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, g["succ0_ids"], max_new_tokens=30, max_pos=T["max_pos"])
+        np.testing.assert_array_equal(got[0][0][0].cpu().numpy(), o_out)
+        assert got[0][3] == o_acc
+    # short queues fall back to the plain loops
+    two = specgenerate_stream(models, reqs[:2], max_new_tokens=budgets[:2], seeds=seeds[:2], **gen)
+    np.testing.assert_array_equal(two[1][0][0].cpu().numpy(), want[1][0][0].cpu().numpy())
+    one = specgenerate_stream(models, reqs[2:3], max_new_tokens=budgets[2:3], seeds=seeds[2:3], **gen)
+    np.testing.assert_array_equal(one[0][0][0].cpu().numpy(), want[2][0][0].cpu().numpy())
+
+
 def test_cohort_of_four_on_a_side_stream_with_sampling_seeds():
     sm, ot, od = build(50, 60, True)
     models = [sm] + [sm.make_cohort_member() for _ in range(3)]

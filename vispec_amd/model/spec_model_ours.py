@@ -485,3 +485,95 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
         toks = torch.from_numpy(m.engine.tokens(n_ctx).astype(np.int64)).to(m.engine.device)[None]
         outs.append((toks, final[t]["new_token"], idxs[t], accs[t]))
     return outs
+
+
+def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
+                        stats=None):
+    """Any number of independent requests through the request SLOTS of one cohort (continuous batching): `models` = [leader, member, ...]
+    as for specgenerate_cohort, `requests` = [(input_ids [1,L], specgenerate kwargs), ...] in arrival order.  The first len(models)
+    requests start together; every lockstep round serves all slots on one weight pass, and the moment a request finishes (EOS, its
+    token budget, a full KV cache) its slot takes the next request of the queue — prefill, first token and draft prefill of that request
+    on the same stream, then it simply joins the following rounds (the other slots' state is device-resident and waits).  A cohort run
+    request by request (specgenerate_cohort) executes max(rounds of its requests) lockstep rounds; the stream executes ≈ mean(rounds).
+    Every request keeps the reference's batch-1 semantics: it returns exactly the (input_ids, new_token, idx, acceptance_len) tuple of
+    `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` run alone (spec_model_ours.py:247-582), in request order.
+    `stats` (dict, optional): `rounds` = lockstep rounds executed, `request_rounds` = rounds summed over the requests."""
+    n, R = len(models), len(requests)
+    seeds = list(seeds) if seeds is not None else [0] * R
+    budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * R
+    if len(seeds) != R or len(budgets) != R:
+        raise ValueError("one seed and one token budget per request")
+    lead = models[0]
+    rounds_cap = max_length - lead.spec_layer.total_tokens - 10  # :270
+    if R <= n or n < 2 or rounds_cap < 1:  # nothing to refill: the plain cohort (or single-request) loops
+        outs, st_all = [], dict(rounds=0, request_rounds=0)
+        for lo in range(0, R, max(n, 1)):
+            grp = list(range(lo, min(R, lo + max(n, 1))))
+            if len(grp) >= 2 and n >= 2:
+                st = {}
+                got = specgenerate_cohort(models[:len(grp)], [requests[i] for i in grp], temperature=temperature, top_k=top_k,
+                                          max_new_tokens=[budgets[i] for i in grp], max_length=max_length, is_llama3=is_llama3,
+                                          seeds=[seeds[i] for i in grp], stats=st)
+                st_all["rounds"] += st["rounds"]
+            else:
+                got = []
+                for i in grp:
+                    ids, kw = requests[i]
+                    got.append(lead.specgenerate(ids, temperature=temperature, top_k=top_k, max_new_tokens=budgets[i], max_length=max_length,
+                                                 log=True, is_llama3=is_llama3, return_acceptance_len=True, seed=seeds[i], **kw))
+                st_all["rounds"] += sum(g[2] + 1 for g in got)
+            st_all["request_rounds"] += sum(g[2] + 1 for g in got)
+            outs += got
+        if stats is not None:
+            stats.update(st_all)
+        return outs
+    for m in models[1:]:
+        if m.engine.leader is not lead.engine:
+            raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
+    member_engines = [m.engine for m in models[1:]]
+    outs = [None] * R
+    slot = [None] * n  # request index a slot is working on
+    rnd, accs = [0] * n, [[] for _ in range(n)]
+    nxt = 0
+
+    def start(t):
+        nonlocal nxt
+        i, nxt = nxt, nxt + 1
+        ids, kw = requests[i]
+        models[t]._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=seeds[i], max_new_tokens=budgets[i],
+                                 is_llama3=is_llama3)
+        slot[t], rnd[t], accs[t] = i, 0, []
+
+    def finish(t, st):
+        m, n_ctx = models[t], st["n_ctx"]
+        m.current_length_data.fill_(n_ctx)
+        toks = torch.from_numpy(m.engine.tokens(n_ctx).astype(np.int64)).to(m.engine.device)[None]
+        outs[slot[t]] = (toks, st["new_token"], rnd[t] - 1, accs[t])
+        slot[t] = None
+
+    for t in range(n):
+        start(t)
+    lockstep = request_rounds = 0
+    while any(i is not None for i in slot):
+        lead.engine.cohort_round(member_engines, -1)
+        states = lead.engine.cohort_states(member_engines)  # the round's ONE host synchronisation
+        lockstep += 1
+        for t in range(n):
+            if slot[t] is None:
+                continue  # an idle slot (the queue is empty): its frozen rows ride along
+            st = states[t]
+            rnd[t] += 1
+            request_rounds += 1
+            accs[t].append(int(st["accept_len"]))
+            if (st["done"] & 1) or st["new_token"] > budgets[slot[t]] or (st["done"] & 4) or rnd[t] >= rounds_cap:  # :544 / :546 / KV full / :484
+                if st["done"] & 4 and not (st["done"] & 3):
+                    import warnings
+                    warnings.warn(f"request {slot[t]} stopped after {st['new_token']} new tokens: the next round would not fit a KV cache",
+                                  RuntimeWarning)
+                finish(t, st)
+        for t in range(n):
+            if slot[t] is None and nxt < R:
+                start(t)
+    if stats is not None:
+        stats.update(rounds=lockstep, request_rounds=request_rounds)
+    return outs
