@@ -123,7 +123,10 @@ def request_plan(n_requests, rank, world, lanes, cohort, n_steps):
     from vispec_amd import parallel
     if n_requests > 0:
         mine = parallel.shard_requests(n_requests, rank, world)
-        return [[[i + s * n_requests for i in mine[lane::lanes]] for s in range(n_steps)] for lane in range(lanes)], "strong"
+        # fill cohorts before opening lanes: 8 requests on a rank are 2 lanes x cohorts of 4 (one weight pass per four requests), not
+        # 4 lanes x pairs; the lanes that stay without requests do nothing
+        used = max(1, min(lanes, -(-len(mine) // max(1, cohort))))
+        return [[[i + s * n_requests for i in (mine[lane::used] if lane < used else [])] for s in range(n_steps)] for lane in range(lanes)], "strong"
     return [[[((rank * lanes + lane) + s * world * lanes) * cohort + j for j in range(cohort)] for s in range(n_steps)]
             for lane in range(lanes)], "weak"
 

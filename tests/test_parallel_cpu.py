@@ -65,3 +65,8 @@ def test_bench_request_plan_covers_every_request_exactly_once(world, lanes, coho
             assert len(ids) == world * lanes * cohort and all(len(lane[s]) == cohort for p, _ in plans for lane in p)
     all_ids = [i for p, _ in plans for lane in p for st in lane for i in st]
     assert len(all_ids) == len(set(all_ids)), "no request is reused across steps"
+    if n_requests and cohort > 1:  # cohorts are filled before lanes are opened (64 requests over 8 ranks: 2 lanes x 4, not 4 lanes x 2)
+        for p, _ in plans:
+            sizes = sorted((len(lane[0]) for lane in p), reverse=True)
+            mine = sum(sizes)
+            assert sum(1 for z in sizes if z) == max(1, min(lanes, -(-mine // cohort)))
