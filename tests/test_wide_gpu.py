@@ -229,7 +229,14 @@ def test_request_stream_through_the_slots_of_a_cohort_equals_the_single_requests
     gen = dict(temperature=temperature, top_k=8) if temperature > 0 else {}
     want = [single(sm, *r, max_new_tokens=b, seed=sd, **gen) for r, b, sd in zip(reqs, budgets, seeds)]
     st = {}
-    got = specgenerate_stream(models, reqs, max_new_tokens=budgets, seeds=seeds, stats=st, **gen)
+    g0 = sm.engine.graph_stats()
+    side = torch.cuda.Stream()  # (the legacy default stream cannot be captured: graphs are replayed on side streams only)
+    with torch.cuda.stream(side):
+        got = specgenerate_stream(models, reqs, max_new_tokens=budgets, seeds=seeds, stats=st, **gen)
+        side.synchronize()
+    g1 = sm.engine.graph_stats()
+    if temperature == 0:  # a refill does not re-capture: the requests' context hints fall in one 512-key bucket, the graph key holds their maximum
+        assert g1["captures"] - g0["captures"] <= 2 and g1["replays"] - g0["replays"] >= 2 * st["rounds"] - 2
     for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
         np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
         assert (new_token, idx, acc) == (w[1], w[2], w[3]), f"request {t}"

@@ -85,7 +85,22 @@ struct vispec_ctx {
              memcmp(temperature, o.temperature, sizeof(temperature)) == 0 && memcmp(seed, o.seed, sizeof(seed)) == 0;
     }
   };
-  struct GraphSlot { hipGraphExec_t exec = nullptr; GraphKey key; };
+  // A few graphs per round function, least recently used one replaced: a stream of requests through the slots of a cohort
+  // (specgenerate_stream) alternates between a handful of keys (context-length buckets), and a re-capture costs milliseconds.
+  struct GraphSlot {
+    static constexpr int CAP = 4;
+    hipGraphExec_t exec[CAP] = {nullptr, nullptr, nullptr, nullptr};
+    GraphKey key[CAP];
+    unsigned long stamp[CAP] = {0, 0, 0, 0}, clock = 0;
+    void clear() {
+      for (int i = 0; i < CAP; ++i) {
+        if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+        exec[i] = nullptr;
+        key[i] = GraphKey{};
+        stamp[i] = 0;
+      }
+    }
+  };
   GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft;
   vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are 32-row tile `slot` of the leader's
   int slot = 0;                  // activation tile of this request inside the leader's 128-row workspaces (leader: 0, members: 1..3)
@@ -248,17 +263,11 @@ extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
     ctx->leader->members[ctx->slot - 1] = nullptr;
     // the leader's cached cohort graphs bake this member's buffers in, and a later member may be allocated at this very address
     // (the graph key compares ctx pointers): drop them with the member
-    for (auto* g : {&ctx->leader->g_cverify, &ctx->leader->g_cdraft})
-      if (g->exec) {
-        (void)hipGraphExecDestroy(g->exec);
-        g->exec = nullptr;
-        g->key = vispec_ctx::GraphKey();
-      }
+    for (auto* g : {&ctx->leader->g_cverify, &ctx->leader->g_cdraft}) g->clear();
   }
   for (vispec_ctx* m : ctx->members)
     if (m) m->leader = nullptr;  // (a member must not outlive its leader's workspaces; it can no longer join a cohort)
-  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft})
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft}) g->clear();
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   delete ctx;
@@ -1145,15 +1154,20 @@ static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& sl
     ++ctx->direct_runs;
     return body();
   }
-  if (slot.exec && slot.key == key) {
-    HIPCHK(hipGraphLaunch(slot.exec, s));
-    ++ctx->graph_replays;
-    return 0;
+  int victim = 0;
+  for (int i = 0; i < vispec_ctx::GraphSlot::CAP; ++i) {
+    if (slot.exec[i] && slot.key[i] == key) {
+      slot.stamp[i] = ++slot.clock;
+      HIPCHK(hipGraphLaunch(slot.exec[i], s));
+      ++ctx->graph_replays;
+      return 0;
+    }
+    if (!slot.exec[i] ? slot.exec[victim] != nullptr : (slot.exec[victim] && slot.stamp[i] < slot.stamp[victim])) victim = i;  // an empty entry, else the oldest
   }
-  if (slot.exec) {
-    (void)hipGraphExecDestroy(slot.exec);
-    slot.exec = nullptr;
-    slot.key = vispec_ctx::GraphKey{};
+  if (slot.exec[victim]) {
+    (void)hipGraphExecDestroy(slot.exec[victim]);
+    slot.exec[victim] = nullptr;
+    slot.key[victim] = vispec_ctx::GraphKey{};
   }
   if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
@@ -1168,15 +1182,16 @@ static int run_graphed(vispec_ctx* ctx, hipStream_t s, vispec_ctx::GraphSlot& sl
     return rc;
   }
   if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-  const hipError_t ei = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
+  const hipError_t ei = hipGraphInstantiate(&slot.exec[victim], graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (ei != hipSuccess) {
-    slot.exec = nullptr;
+    slot.exec[victim] = nullptr;
     return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
   }
-  slot.key = key;
+  slot.key[victim] = key;
+  slot.stamp[victim] = ++slot.clock;
   ++ctx->graph_captures;
-  HIPCHK(hipGraphLaunch(slot.exec, s));
+  HIPCHK(hipGraphLaunch(slot.exec[victim], s));
   return 0;
 }
 // sampling = the launch sequence reads temperature / seed / top_k (verify's sampling accept); the draft only switches the row order
@@ -1191,7 +1206,10 @@ static vispec_ctx::GraphKey graph_key_n(vispec_ctx* const* ctxs, int n, int forc
     const vispec_ctx* ctx = ctxs[t];
     const bool sampling = ctx->temperature > 1e-5f;
     k.who[t] = ctx;
-    k.n_hint[t] = ctx->n_hint;
+    // the context hints reach the launches only as their maximum over the requests (the attention grids' split count): a stream of
+    // requests of different lengths through the slots of a cohort replays one graph per maximum, not one per combination
+    k.n_hint[0] = t == 0 ? ctx->n_hint : std::max(k.n_hint[0], ctx->n_hint);
+    if (t > 0) k.n_hint[t] = 0;
     k.temperature[t] = sampling_args ? (sampling ? ctx->temperature : 0.f) : (sampling ? 1.f : 0.f);
     k.seed[t] = sampling_args && sampling ? ctx->seed : 0;
     k.sample_top_k[t] = sampling_args && sampling ? ctx->sample_top_k : 0;
@@ -1254,6 +1272,7 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
                      c.draft_max_pos, ctx->rope_rows, c.top_k * c.depth + c.depth + 2);
   KCHK();
   long hint = (long)L + max_new_tokens + 2 * (c.depth + 2) + c.total_token + 64;
+  hint = (hint + 511) / 512 * 512;  // in steps of the attention kernels' 512 keys per workgroup: the split count is all a launch takes from it
   ctx->n_hint = (int)(hint < c.max_pos ? hint : c.max_pos);
   return 0;
 }
