@@ -16,7 +16,6 @@
 #include "kernels.h"
 #include "gemm_prefill.h"
 #include "gemm_wide.h"
-#include "gemm_wide16.h"
 #include "tree_kernels.h"
 
 static thread_local std::string g_err;
@@ -979,14 +978,7 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
-    if (M > 96 && unc == 5) {  // 9xxx5: PROTOTYPE csrc/gemm_wide16.h — sixteen row blocks of one (split, K-quarter) per workgroup; Y = caller's fp32 [4 S][128][N]
-      if (K / 16 / S / 4 < 4) return fail("tune: wide16 needs at least one 64-k group per K-quarter");
-      hipLaunchKernelGGL(gemm_w32_wide16_kernel, dim3((tiles + 15) / 16, 4 * S), dim3(1024), WIDE16_LDS_BYTES, s, x, ldx, w, (float*)Y, 30, N, K, S, tiles);
-    } else if (M > 96 && unc == 7) {  // 9xxx7: 9xxx5 without its partial stores (measurement only)
-      hipLaunchKernelGGL(gemm_w32_wide16_kernel, dim3((tiles + 15) / 16, 4 * S), dim3(1024), WIDE16_LDS_BYTES, s, x, ldx, w, (float*)Y, 30, N, K, -S, tiles);
-    } else if (M > 96 && unc == 6) {  // 9xxx6: its reduce (X = the fp32 partials, Y = bf16 [128][ldy])
-      hipLaunchKernelGGL(wide16_reduce_kernel, dim3((N + 1023) / 1024, 128), dim3(256), 0, s, (const float*)X, (bf16_t*)Y, ldy, 30, N, S);
-    } else if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
+    if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 3>), dim3((tiles + 2) / 3, S), dim3(768), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
