@@ -226,10 +226,11 @@ def _tree_mask(rng, M, tail):
 
 @pytest.mark.parametrize("H,Hkv,M,prefix,tail,eager", [
     (2, 2, 30, 300, 30, 1), (2, 2, 30, 0, 30, 1), (2, 2, 1, 777, 1, 1), (2, 2, 8, 131, 24, 0), (2, 2, 5, 1, 5, 0),
-    (2, 2, 2, 600, 0, 0), (4, 2, 30, 257, 30, 1), (14, 2, 3, 90, 3, 1), (2, 2, 64, 500, 64, 1), (2, 2, 30, 1500, 30, 1)])
+    (2, 2, 2, 600, 0, 0), (4, 2, 30, 257, 30, 1), (14, 2, 3, 90, 3, 1), (2, 2, 64, 500, 64, 1), (2, 2, 30, 1500, 30, 1),
+    (2, 1, 30, 9000, 30, 0), (2, 2, 30, 33000, 30, 1)])  # the last two: 18 key splits; a 40 960-row cache (key range per workgroup doubled to 1024)
 def test_tree_attention(lib, engine, H, Hkv, M, prefix, tail, eager):
     rng = np.random.default_rng(H * 1000 + M * 10 + prefix + tail)
-    hd, S = 128, 2048
+    hd, S = 128, 2048 if prefix + tail <= 2048 else (10240 if prefix + tail <= 10240 else 40960)
     o = vo.Ops(True)
     q = synth.bf16_grid(rng.standard_normal((M, H, hd), dtype=np.float32))
     k = synth.bf16_grid(rng.standard_normal((Hkv, S, hd), dtype=np.float32))
