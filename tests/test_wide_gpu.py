@@ -330,3 +330,33 @@ def test_closing_a_member_frees_its_tile_and_one_sync_reads_all_states():
     got = specgenerate_cohort([sm, m1b, m2], reqs, max_new_tokens=18)
     for (toks, new_token, idx, acc), w in zip(got, want):
         np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy())
+
+
+def test_cohort_at_long_context_equals_the_single_requests():
+    """Contexts of 9 000 - 33 000 keys in 40 960-row caches (more than 64 x 512 rows: the attention's key range per workgroup doubles to
+    1024; 9 - 33 key splits per request): the split boundaries come from the cache capacity, never from the requests of a launch, so a
+    cohort request stays bit-identical to the same request alone at every context length — and the speculative stream is still the
+    greedy stream of the same target."""
+    from vispec_amd.engine import DraftConfig, TargetConfig
+    from vispec_amd.model import SpecModel
+    max_pos = 40960
+    tw = synth.make_target_weights(T["D"], T["H"], T["I"], T["V"], T["NL"], seed=50, structured=True)
+    dw = synth.make_draft_weights(T["D"], T["H"], T["I"], T["V"], num_q=2, seed=60, structured=True, target_embed=tw["model.embed_tokens.weight"], rho=0.25)
+    tcfg = TargetConfig(hidden_size=T["D"], num_heads=T["H"], num_kv_heads=T["H"], intermediate_size=T["I"], vocab_size=T["V"],
+                        num_layers=T["NL"], max_position_embeddings=max_pos, architectures=("LlamaForCausalLM",), image_token_index=IMG_TOK)
+    dcfg = DraftConfig(hidden_size=T["D"], num_heads=T["H"], intermediate_size=T["I"], vocab_size=T["V"], max_position_embeddings=max_pos)
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, num_q=2)
+    models = [sm] + [sm.make_cohort_member() for _ in range(2)]
+    rng = np.random.default_rng(97)
+    reqs = [(torch.from_numpy(rng.integers(3, IMG_TOK, size=n))[None], {}) for n in (33000, 9000, 17000)]
+    budgets = [24, 31, 18]
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    got = specgenerate_cohort(models, reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    ar = sm.baseline_generate(reqs[1][0], max_new_tokens=budgets[1])[0].cpu().numpy()
+    out = want[1][0][0].cpu().numpy()
+    n = min(len(ar), len(out))
+    assert n > 9000 + 20
+    np.testing.assert_array_equal(ar[:n], out[:n])
