@@ -401,11 +401,14 @@ def main():
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
+    ap.add_argument("--max-new-tokens", type=int, default=512,
+                    help="experiments only (what the prompt prefill costs the line): the BASELINE workload is 512 new tokens per request")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
                          "replicas (request i -> GPU i mod N, then over that GPU's lanes); 0 = one request per lane per step (weak scaling)")
     args = ap.parse_args()
-    global MODEL, N_IMG, WIDE_RB, REFILL
+    global MODEL, N_IMG, WIDE_RB, REFILL, MAX_NEW
+    MAX_NEW = args.max_new_tokens
     REFILL = not args.no_refill
     MODEL = args.model
     WIDE_RB = args.wide_row_blocks
@@ -717,7 +720,7 @@ def main():
             "ms_per_step": round(1e3 * dt / K, 2), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "fp8-w8a16" if fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"{MODELS[MODEL]['name']}-shaped target + ViSpec draft, {MODELS[MODEL]['desc']}, "
-                                   f"max_new_tokens=512, temperature={args.temperature:g}, total_token=30 depth=3 top_k=8 num_q=2; "
+                                   f"max_new_tokens={MAX_NEW}, temperature={args.temperature:g}, total_token=30 depth=3 top_k=8 num_q=2; "
                                    f"a step = {per_step} (replicas share one weight copy per GPU)",
                        "weights": f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
                                   f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)",
