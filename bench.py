@@ -396,7 +396,7 @@ def main():
     ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
-    ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 4),
+    ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, 4 otherwise")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "

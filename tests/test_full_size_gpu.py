@@ -97,7 +97,7 @@ def test_cohort_of_two_equals_the_single_requests_at_full_size(model_full):
     del mb
 
 
-@pytest.mark.parametrize("n_req,row_blocks", [(4, 4), (3, 0)])
+@pytest.mark.parametrize("n_req,row_blocks", [(4, 4), (3, 0), (4, 8), (3, 8)])
 def test_wide_cohort_equals_the_single_requests_at_full_size(model_full, n_req, row_blocks):
     """Three / four requests on one weight pass (csrc/gemm_wide.h incl. its fp8 instantiations for the fp8 model, both launch shapes of
     vispec_set_wide_row_blocks, one launch per step for the per-request kernels, four-request attention) at the real sizes of EVERY

@@ -26,7 +26,7 @@ from test_loop_gpu import IMG_TOK, build  # noqa: E402
                                  (32064, 512), (22016 // 2, 4096)])
 @pytest.mark.parametrize("n_req,m_tile", [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("row_blocks", [4, 3, 2])
+@pytest.mark.parametrize("row_blocks", [4, 3, 2, 8])
 def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi, row_blocks):
     if epi == 2 and N % 16:
         pytest.skip("SwiGLU needs N % 16 == 0")
@@ -58,7 +58,7 @@ def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engi
 @pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008)])
 @pytest.mark.parametrize("n_req", [3, 4])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("row_blocks", [4, 0])
+@pytest.mark.parametrize("row_blocks", [4, 0, 8])
 def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, epi, row_blocks):
     from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
     if epi == 2 and N % 16:

@@ -22,7 +22,7 @@ SHAPE_SETS = {"llava7b": [("qkv", 12288, 4096, 1), ("o_proj", 4096, 4096, 4), ("
               # Qwen2.5-VL-7B (BASELINE configs 3 / 5): GQA 28/4 -> 4608 q|k|v rows, I = 18944, V = 152064; split factors = choose_split's
               "qwen7b": [("qkv", 4608, 3584, 1), ("o_proj", 3584, 3584, 4), ("gate_up", 37888, 3584, 1), ("down", 3584, 18944, 4), ("lm_head_131072_of_152064", 131072, 3584, 1)]}  # (the tune entry point's partial workspace holds 128 x 131072 floats)
 SHAPES = SHAPE_SETS[os.environ.get("SHAPES", "llava7b")]
-UN = [int(v) for v in sys.argv[1:]] or [0, 4, 3]
+UN = [int(v) for v in sys.argv[1:]] or [0, 4, 3, 5]
 p = lambda t: C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

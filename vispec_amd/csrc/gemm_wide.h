@@ -57,6 +57,106 @@ __device__ __forceinline__ void wide_wait_barrier() {  // own DMAs landed (N you
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "i"(N) : "memory");
 }
 
+// ---- epilogues (the arithmetic of gemm_w32_kernel's, on the sums held in registers) — shared by the two wide kernels.  D[i = n][j = m]:
+// register 4q + r of a lane is column 8q + 4hi + r of the tile for row j of the activation tile.
+template <int EPI, bool W8, int NL>
+__device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int split, int j, int hi, int m_tile, int N, const bf16_t* __restrict__ bias,
+                                              void* __restrict__ Yv, int ldy, const bf16_t* __restrict__ R, int ldr, const float* __restrict__ wscale,
+                                              const RopeEpi& re) {
+#pragma unroll
+  for (int mt = 0; mt < NL; ++mt) {
+    if (j >= m_tile) continue;
+    const int m = 32 * mt + j;
+    if (EPI == EPI_ROPE) {
+      const PosSpec& ps_ = re.ps[mt];
+      const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + j;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
+        const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
+        if (h < re.H + re.H_kv) {
+          const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of the pair
+          const int pos = (ps_.base ? *ps_.base : 0) + (ps_.base2 ? *ps_.base2 : 0) + ps_.add + (ps_.off ? ps_.off[j] : (ps_.row ? j : 0));
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
+            if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+            if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
+            x1 = rdbf(x1);
+            x2 = rdbf(x2);
+            const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
+            o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
+            o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
+          }
+          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
+                                   : re.kc[mt] + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
+            if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+            if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
+            o1[r] = rdbf(x1);
+            o2[r] = rdbf(x2);
+          }
+          bf16_t* dst = re.vc[mt] + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
+        }
+      }
+    } else if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int n = tile * 16 + 8 * qq + 4 * hi;  // output column; gate row n, up row N + n of the natural weight
+        if (n >= N) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = acc[mt][4 * qq + r], u = acc[mt][4 * (qq + 2) + r];
+          if (W8) { y *= wscale[n + r]; u *= wscale[N + n + r]; }
+          if (bias) { y += bf2f(bias[n + r]); u += bf2f(bias[N + n + r]); }
+          y = rdbf(y);
+          u = rdbf(u);
+          const float act = rdbf(y / (1.0f + __expf(-y)));
+          o[r] = rdbf(act * u);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = tile * 32 + 8 * q + 4 * hi;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[mt][4 * q + r];
+          if (W8) v[r] *= wscale[n + r];  // per-output-channel dequantisation scale on the fp32 accumulator
+        }
+        if (EPI == EPI_PARTIAL) {
+          float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * WIDE_MPAD + m) * N + n;
+          *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float y = v[r];
+            if (bias) y += bf2f(bias[n + r]);
+            y = rdbf(y);
+            if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
+            o[r] = y;
+          }
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        }
+      }
+    }
+  }
+}
+
 // NL = live activation tiles (requests) — a template parameter: runtime guards around the MFMAs made hipcc branch around every
 // one of them and keep the accumulators in scratch memory.
 // DBG (measurement only, wrong results): 1 = no activation DMAs, 2 = no weight loads
@@ -257,98 +357,190 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     }
   }
   if (kq != 0 || !tile_ok) return;
-  // ---- epilogues (the arithmetic of gemm_w32_kernel's, on the sums held in registers).  D[i = n][j = m]: register 4q + r of a
-  // lane is column 8q + 4hi + r of the tile for row j of the activation tile.
+  wide_epilogue<EPI, W8, NL>(acc, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re);
+}
+
+// =====================================================================================================================================
+// Wide-8 (round 4): EIGHT weight row blocks per workgroup — the form for a GPU that several lanes keep busy, where a launch costs CU-time in
+// proportion to the bytes its workgroups ingest (W + X per workgroup, <= ~55 GB/s per CU whatever the source: tools/probe/cu_ingest_probe.hip).
+// The 4 x 4 kernel above re-reads the whole [32 NL, K] activation block once per FOUR row blocks (bf16: one byte of X per byte of W; fp8
+// weights: two); here a workgroup is 8 waves, wave w owns row block 8 blockIdx.x + w over the split's WHOLE K range, and the eight waves
+// walk k in lockstep through ONE staged X ring (LDS-DMA, LA groups of lookahead) — half the X traffic per weight byte.
+//
+// Bit-identity with the single-request kernel is kept by accumulating the K range quarter by quarter: `cur` runs over the k-steps of
+// quarter q (the steps wave q of gemm_w32_kernel<1, ..., NW = 4> owns, ascending, one MFMA per step with the same operands) and is folded
+// into `tot` at the quarter's end — tot = q0, then (q0 + q1), ((q0 + q1) + q2), (((q0 + q1) + q2) + q3): the order of the skinny kernel's
+// LDS reduction.  Two accumulator sets (2 x 16 NL registers) are what limits a wave to one row block at 8 waves per CU.
+//
+// Groups of 64 k are aligned to the QUARTER starts (a quarter of n steps = n / LOADS whole groups + a tail group that re-reads the last
+// 64 k with its already-used steps pointed at a zero buffer — acc + W x 0 changes no bit), so every group is LOADS weight tiles and
+// 4 NL activation pieces and the memory pipeline is one steady state with hand-counted vmcnt from the first group to the last:
+//   per group and wave: [PPW activation DMAs of group g + LA] then, after step u's MFMAs, [weight tile u of group g + LA]
+//   in flight at the top of a group: LA x (LOADS + PPW) operations; step u waits vmcnt(LA (LOADS + PPW) - 1), the barrier that publishes
+//   group g + 1's activations waits vmcnt(LA (LOADS + PPW) - PPW).  The last LA groups fetch stand-ins (the last group again).
+// Needs every quarter of the split to hold at least one whole group (the host falls back to the 4 x 4 kernel otherwise: tiny models).
+#define WIDE8_BUFBYTES (16 * 1024)
+template <bool W8> constexpr int wide8_la() { return W8 ? 4 : 2; }                                   // groups of lookahead (8 KiB of W per wave in flight)
+template <bool W8> constexpr int wide8_lds_bytes() { return (wide8_la<W8>() + 2) * WIDE8_BUFBYTES; }  // ring of LA + 1 buffers + the zero buffer
+
+template <int EPI, bool W8, int NL>
+__global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+                                                             const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
+                                                             const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,
+                                                             const float* __restrict__ wscale, RopeEpi re, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  constexpr int LA = wide8_la<W8>(), NB = LA + 1;
+  constexpr int KSTEP = W8 ? 32 : 16, LOADS = W8 ? 2 : 4;
+  constexpr int PPW = (4 * NL + 7) / 8;  // 1 KiB activation pieces a wave moves per group (NL = 3: 16 slots for 12 pieces, the last one fetched five times)
+  constexpr int QIN = LA * (LOADS + PPW);  // memory operations in flight per wave in steady state
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, hi = lane >> 5;
+  const int split = blockIdx.y;
+  const int tile_raw = blockIdx.x * 8 + wave;
+  const bool tile_ok = tile_raw < tiles;
+  const int tile = tile_ok ? tile_raw : 0;  // a ragged last workgroup streams tile 0 again and stores nothing
+  const int KS = K / KSTEP;
+  const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
+  const int len = ks_hi - ks_lo;
+  // total number of groups of the split (all quarters)
+  int Gtot = 0;
 #pragma unroll
-  for (int mt = 0; mt < NL; ++mt) {
-    if (j >= m_tile) continue;
-    const int m = 32 * mt + j;
-    if (EPI == EPI_ROPE) {
-      const PosSpec& ps_ = re.ps[mt];
-      const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + j;
+  for (int q = 0; q < 4; ++q) {
+    const int a = ks_lo + (int)((long)len * q / 4), b = ks_lo + (int)((long)len * (q + 1) / 4);
+    Gtot += (b - a + LOADS - 1) / LOADS;
+  }
+  f32x16 cur[NL], tot[NL];
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int ncol = tile * 32 + 8 * qq + 4 * hi;  // packed column of a[0]
-        const int h = ncol >> 7, t4 = (ncol & 127) >> 5, c = ncol & 31;
-        if (h < re.H + re.H_kv) {
-          const int d = 16 * t4 + c, c1 = h * 128 + d, c2 = c1 + 64;  // natural columns of the pair
-          const int pos = (ps_.base ? *ps_.base : 0) + (ps_.base2 ? *ps_.base2 : 0) + ps_.add + (ps_.off ? ps_.off[j] : (ps_.row ? j : 0));
-          float o1[4], o2[4];
+  for (int mt = 0; mt < NL; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
-            if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
-            if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
-            x1 = rdbf(x1);
-            x2 = rdbf(x2);
-            const float cs = bf2f(re.cosT[(size_t)pos * 128 + d + r]), sn = bf2f(re.sinT[(size_t)pos * 128 + d + r]);
-            o1[r] = rdbf(rdbf(x1 * cs) + rdbf(-x2 * sn));
-            o2[r] = rdbf(rdbf(x2 * cs) + rdbf(x1 * sn));
-          }
-          bf16_t* dst = (h < re.H) ? reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + c1
-                                   : re.kc[mt] + ((size_t)(h - re.H) * re.s_max + kvrow) * 128 + d;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
-        } else {  // v head: natural order, columns ncol + r and ncol + 16 + r
-          float o1[4], o2[4];
+    for (int r = 0; r < 16; ++r) { cur[mt][r] = 0.f; tot[mt][r] = 0.f; }
+
+  // ---- activation staging: the workgroup's 8 waves move [32 NL rows] x [64 k] per group as 4 NL pieces of 8 rows x 128 B (LDS image and
+  // source-side swizzle of the 4 x 4 kernel above)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_w;
+  unsigned xoff[PPW], xdst[PPW];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
-            if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
-            if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
-            o1[r] = rdbf(x1);
-            o2[r] = rdbf(x2);
-          }
-          bf16_t* dst = re.vc[mt] + ((size_t)(h - re.H - re.H_kv) * re.s_max + kvrow) * 128 + (ncol & 127);
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-          *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2(o2[0], o2[1]), pack2(o2[2], o2[3]));
-        }
-      }
-    } else if (EPI == EPI_SWIGLU) {
+  for (int i = 0; i < PPW; ++i) {
+    const int q = min(wave * PPW + i, 4 * NL - 1), mt = q >> 2, pc = q & 3;
+    const int row = 32 * mt + min(8 * pc + (lane >> 3), m_tile - 1), g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
+    xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;
+    xdst[i] = lds0 + (unsigned)(mt * 4 + pc) * 1024u;
+  }
+  {  // the zero buffer (slot NB): 16 KiB, 32 B per thread
+    uint4* z = reinterpret_cast<uint4*>(smem_w + NB * WIDE8_BUFBYTES);
+    z[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    z[threadIdx.x + 512] = make_uint4(0, 0, 0, 0);
+  }
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X);                                     // + step * KSTEP * 2 bytes
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + (size_t)tile * KS * 1024;           // + step KiB
+  const unsigned wvo = lane * 16;
+  const unsigned rrow = (unsigned)(j >> 3) * 1024u + (unsigned)(j & 7) * 128u, fsw = (unsigned)(j >> 1) & 7u;
+  unsigned ro[4];
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int n = tile * 16 + 8 * qq + 4 * hi;  // output column; gate row n, up row N + n of the natural weight
-        if (n >= N) continue;
-        float o[4];
+  for (int t = 0; t < 4; ++t) {
+    const unsigned sseg = W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi);
+    ro[t] = rrow + ((sseg ^ fsw) << 4);
+  }
+  // ---- group iterators (wave-uniform scalars): (quarter, index in quarter) -> first k-step, zeroed leading steps, last-of-quarter
+  struct It { int q, i, a, n; };
+  auto it_begin = [&]() { It t; t.q = 0; t.i = 0; t.a = ks_lo; t.n = ks_lo + (int)((long)len * 1 / 4) - ks_lo; return t; };
+  auto it_step0 = [&](const It& t) { return t.i < t.n / LOADS ? t.a + t.i * LOADS : t.a + t.n - LOADS; };
+  auto it_skip = [&](const It& t) { return t.i < t.n / LOADS ? 0 : LOADS - t.n % LOADS; };
+  auto it_last = [&](const It& t) { return t.i == (t.n + LOADS - 1) / LOADS - 1; };
+  auto it_next = [&](It& t) {  // never moves past the split's last group (stand-in fetches repeat it)
+    if (t.i + 1 < (t.n + LOADS - 1) / LOADS) { ++t.i; return; }
+    if (t.q == 3) return;
+    ++t.q; t.i = 0; t.a += t.n;
+    t.n = ks_lo + (int)((long)len * (t.q + 1) / 4) - t.a;
+  };
+  u32x4_t w[LA][LOADS];
+#define W8_DMA(step0, slot)                                                                                   \
+  {                                                                                                             \
+    const unsigned char* xs_ = xsrc + (size_t)(step0) * (KSTEP * 2);                                            \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) wide_dma16(xoff[i], xs_, xdst[i] + (unsigned)(slot) * WIDE8_BUFBYTES); \
+  }
+  // one k-step (one weight tile register) against the NL staged activation tiles; a step below `sk` reads the zero buffer instead
+#define W8_MFMA(SL, u, xb_live, sk)                                                                           \
+  {                                                                                                             \
+    const unsigned char* xb_ = (u) < (sk) ? smem_w + NB * WIDE8_BUFBYTES : (xb_live);                           \
+    if constexpr (!W8) {                                                                                        \
+      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                       \
+        const uint4 bv = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[u]);                              \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[SL][u]), as_bf16x8(bv), cur[mt], 0, 0, 0); \
+      }                                                                                                         \
+    } else {                                                                                                    \
+      uint4 a_lo, a_hi;                                                                                         \
+      fp8x16_to_bf16(make_uint4(w[SL][u].x, w[SL][u].y, w[SL][u].z, w[SL][u].w), a_lo, a_hi);                   \
+      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                       \
+        const uint4 b0 = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u)) & 3]);                  \
+        const uint4 b1 = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u) + 1) & 3]);              \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), cur[mt], 0, 0, 0);    \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), cur[mt], 0, 0, 0);    \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+#define W8_STEP(SL, u)                                                                                        \
+  if constexpr ((u) < LOADS) {                                                                                  \
+    wide_wait_vm<QIN - 1>(w[SL][(u) < LOADS ? (u) : 0]);                                                        \
+    W8_MFMA(SL, (u) < LOADS ? (u) : 0, xb, skip)                                                                \
+    wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[SL][(u) < LOADS ? (u) : 0], wvo, wn);                         \
+  }
+  // one group: SL = its weight-register slot (g % LA, compile time), `c` = its iterator, `pf` = the iterator LA groups ahead
+#define W8_GROUP(SL)                                                                                          \
+  {                                                                                                             \
+    const bool live = g + (SL) < Gtot;                                                                          \
+    const int skip = live ? it_skip(c) : LOADS;                                                                 \
+    const int s0p = it_step0(pf);                                                                               \
+    const unsigned char* wn = wsrc + (size_t)s0p * 1024;                                                        \
+    const unsigned char* xb = smem_w + rd * WIDE8_BUFBYTES;                                                     \
+    W8_DMA(s0p, wr)                                                                                             \
+    W8_STEP(SL, 0) W8_STEP(SL, 1) W8_STEP(SL, 2) W8_STEP(SL, 3)                                                 \
+    if (live && it_last(c)) { /* the quarter is complete: fold it (uniform branch, three or four times per launch) */ \
+      if (c.q == 0) {                                                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) tot[mt] = cur[mt];                                    \
+      } else {                                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < NL; ++mt)                                                       \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) tot[mt][r] += cur[mt][r];                              \
+      }                                                                                                         \
+      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt)                                                         \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) cur[mt][r] = 0.f;                                        \
+    }                                                                                                           \
+    wide_wait_barrier<QIN - PPW>();                                                                             \
+    it_next(c); it_next(pf);                                                                                    \
+    rd = rd + 1 == NB ? 0 : rd + 1;                                                                             \
+    wr = wr + 1 == NB ? 0 : wr + 1;                                                                             \
+  }
+  // ---- prologue: groups 0 .. LA-1 in the steady-state order [D(0), W(0,*), D(1), W(1,*), ...]
+  It c = it_begin(), pf = it_begin();
+  __syncthreads();  // (the zero buffer is written; nothing else touches LDS before the first DMA lands)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float y = acc[mt][4 * qq + r], u = acc[mt][4 * (qq + 2) + r];
-          if (W8) { y *= wscale[n + r]; u *= wscale[N + n + r]; }
-          if (bias) { y += bf2f(bias[n + r]); u += bf2f(bias[N + n + r]); }
-          y = rdbf(y);
-          u = rdbf(u);
-          const float act = rdbf(y / (1.0f + __expf(-y)));
-          o[r] = rdbf(act * u);
-        }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = tile * 32 + 8 * q + 4 * hi;
-        if (n >= N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[mt][4 * q + r];
-          if (W8) v[r] *= wscale[n + r];  // per-output-channel dequantisation scale on the fp32 accumulator
-        }
-        if (EPI == EPI_PARTIAL) {
-          float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * WIDE_MPAD + m) * N + n;
-          *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float y = v[r];
-            if (bias) y += bf2f(bias[n + r]);
-            y = rdbf(y);
-            if (EPI == EPI_RESIDUAL) y = rdbf(bf2f(R[(size_t)m * ldr + n + r]) + y);
-            o[r] = y;
-          }
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-        }
-      }
+  for (int p = 0; p < LA; ++p) {
+    const int s0 = it_step0(pf);
+    const unsigned char* wp = wsrc + (size_t)s0 * 1024;
+    W8_DMA(s0, p)
+    wide_load_w<0>(w[p][0], wvo, wp);
+    wide_load_w<1024>(w[p][1], wvo, wp);
+    if constexpr (LOADS > 2) {
+      wide_load_w<2048>(w[p][LOADS > 2 ? 2 : 0], wvo, wp);
+      wide_load_w<3072>(w[p][LOADS > 2 ? 3 : 0], wvo, wp);
+    }
+    it_next(pf);
+  }
+  wide_wait_barrier<QIN - PPW>();  // group 0's activations are staged
+  int rd = 0, wr = LA;             // ring slot read by the current group / written by the prefetch (LA ahead, mod NB)
+  for (int g = 0; g < Gtot; g += LA) {
+    W8_GROUP(0)
+    W8_GROUP(1)
+    if constexpr (LA > 2) {
+      W8_GROUP(LA > 2 ? 2 : 0)
+      W8_GROUP(LA > 2 ? 3 : 0)
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stand-in fetches of the last groups (their LDS-DMAs must not outlive the workgroup)
+#undef W8_GROUP
+#undef W8_STEP
+#undef W8_MFMA
+#undef W8_DMA
+  if (!tile_ok) return;
+  wide_epilogue<EPI, W8, NL>(tot, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re);
 }

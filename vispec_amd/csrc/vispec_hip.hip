@@ -245,6 +245,18 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
 #undef WIDE_ALL_EPI_RB
     for (const void* f : wide)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES) != hipSuccess) (void)hipGetLastError();
+    // the eight-row-block form (gemm_w32_wide8_kernel): 64 KiB (bf16) / 96 KiB (fp8 weights) of dynamic LDS
+#define WIDE8_ALL_EPI(W8_, NL_)                                                                                                      \
+  (const void*)gemm_w32_wide8_kernel<EPI_NONE, W8_, NL_>, (const void*)gemm_w32_wide8_kernel<EPI_RESIDUAL, W8_, NL_>,                  \
+      (const void*)gemm_w32_wide8_kernel<EPI_SWIGLU, W8_, NL_>, (const void*)gemm_w32_wide8_kernel<EPI_PARTIAL, W8_, NL_>,             \
+      (const void*)gemm_w32_wide8_kernel<EPI_ROPE, W8_, NL_>
+    const void* wide8_bf16[] = {WIDE8_ALL_EPI(false, 3), WIDE8_ALL_EPI(false, 4)};
+    const void* wide8_fp8[] = {WIDE8_ALL_EPI(true, 3), WIDE8_ALL_EPI(true, 4)};
+#undef WIDE8_ALL_EPI
+    for (const void* f : wide8_bf16)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<false>()) != hipSuccess) (void)hipGetLastError();
+    for (const void* f : wide8_fp8)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<true>()) != hipSuccess) (void)hipGetLastError();
   }
   if (leader) leader->members[slot - 1] = ctx;
   *out = ctx;
@@ -508,6 +520,17 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   return 0;
 }
 
+// gemm_w32_wide8_kernel walks every K-quarter of every split in whole 64-k groups (plus a tail group that re-reads the quarter's last
+// 64 k): each quarter must hold at least one group
+static bool wide8_ok(int KS, int S, int loads) {
+  for (int sp = 0; sp < S; ++sp) {
+    const int lo = (int)((long)KS * sp / S), hi = (int)((long)KS * (sp + 1) / S), len = hi - lo;
+    for (int q = 0; q < 4; ++q)
+      if ((int)((long)len * (q + 1) / 4) - (int)((long)len * q / 4) < loads) return false;
+  }
+  return true;
+}
+
 // Three or four requests per weight pass (csrc/gemm_wide.h): tile t of X / Y / R (rows 32t ..) belongs to request t, rows
 // 32t .. 32t + m_tile - 1 are live.  Same decomposition rules as launch_gemm_mt — in particular the SAME split-K factor as the
 // single-request launch of the same GEMM, so every row's partial sums group the same k ranges.
@@ -530,6 +553,12 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
     int rb_ = rb_opt;                                                                                                                   \
+    if (rb_ == 8 && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup, K walked quarter by quarter */            \
+      PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
+              YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
+      break;                                                                                                                            \
+    }                                                                                                                                   \
+    if (rb_ == 8) rb_ = 4;                                                                                                              \
     if (rb_ == 0) rb_ = ((tiles + 1) / 2) * (SPLITS) <= 256 ? 2 : (((tiles + 2) / 3) * (SPLITS) <= 256 ? 3 : 4);  /* most workgroups in one round of CUs */ \
     if (rb_ == 2) WIDE_LRB(EPI_, W8_, NL_, 2, YPTR, LDY, SPLITS);                                                                       \
     else if (rb_ == 3) WIDE_LRB(EPI_, W8_, NL_, 3, YPTR, LDY, SPLITS);                                                                  \
@@ -978,7 +1007,11 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
-    if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
+    if (M > 96 && unc == 5) {  // 9xxx5: EIGHT row blocks per workgroup, K walked quarter by quarter (gemm_w32_wide8_kernel)
+      if (!wide8_ok(K / 16, S, 4)) return fail("tune: wide8 needs a whole 64-k group in every K-quarter");
+      hipLaunchKernelGGL((gemm_w32_wide8_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 7) / 8, S), dim3(512), wide8_lds_bytes<false>(), s, x, ldx, w, nullptr,
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+    } else if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 3>), dim3((tiles + 2) / 3, S), dim3(768), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     else if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
@@ -1227,7 +1260,8 @@ extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
 }
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   if (!ctx) return fail("null ctx");
-  if (row_blocks != 0 && (row_blocks < 2 || row_blocks > 4)) return fail("wide_row_blocks: 4, 3, 2, or 0 (= the smallest that still runs in one round of CUs)");
+  if (row_blocks != 0 && row_blocks != 8 && (row_blocks < 2 || row_blocks > 4))
+    return fail("wide_row_blocks: 8, 4, 3, 2, or 0 (= the smallest of 2..4 that still runs in one round of CUs)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
