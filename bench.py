@@ -58,6 +58,34 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# Real checkpoints: when $VISPEC_WEIGHTS (or --weights-dir) holds the published pair under its hub names — or
+# --base-model-path / --spec-model-path (the reference harness's own flags, gen_spec_answer_coco_caption.py:292-300) name the directories —
+# the weights come from SpecModel.from_pretrained (spec_model_ours.py:147-166) and tau is what those weights accept on the synthetic prompts.
+HUB_NAMES = {"llava7b": ("llava-hf/llava-v1.6-vicuna-7b-hf", "JLKang/ViSpec-llava-v1.6-vicuna-7b-hf"),
+             "llava13b": ("llava-hf/llava-v1.6-vicuna-13b-hf", "JLKang/ViSpec-llava-v1.6-vicuna-13b-hf"),
+             "qwen7b": ("Qwen/Qwen2.5-VL-7B-Instruct", "JLKang/ViSpec-Qwen2.5-VL-7B-Instruct")}
+REAL_WEIGHTS = None  # (base_model_path, spec_model_path) once resolved
+
+
+def resolve_weights(args):
+    base, spec = args.base_model_path, args.spec_model_path
+    root = args.weights_dir or os.environ.get("VISPEC_WEIGHTS")
+    if not (base and spec) and root:
+        names = HUB_NAMES.get(MODEL.replace("-hires", "").replace("-fp8", ""))
+        if names:
+            cand = [os.path.join(root, n) for n in names]
+            cand_flat = [os.path.join(root, n.split("/")[-1]) for n in names]
+            for b_, s_ in (cand, cand_flat):
+                if os.path.isdir(b_) and os.path.isdir(s_):
+                    base, spec = base or b_, spec or s_
+                    break
+    if bool(base) != bool(spec):
+        raise SystemExit("error: --base-model-path and --spec-model-path go together")
+    if base and not (os.path.isdir(base) and os.path.isdir(spec)):
+        raise SystemExit(f"error: checkpoint directories not found: {base} / {spec}")
+    return (base, spec) if base else None
+
+
 REFILL = True  # --no-refill: cohort by cohort
 WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 4)
 
@@ -81,11 +109,18 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
     else:
         tcfg = TargetConfig(**LLAVA_16_7B)
         dcfg = DraftConfig(hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32064, max_position_embeddings=4096)
-    # rank 0 creates the weights; the others allocate same-shaped buffers (different seed) and receive rank 0's over RCCL
-    tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=True, num_q=TREE["num_q"],
-                                 rho=RHO[MODEL], succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
+    real = REAL_WEIGHTS is not None
+    if real:  # every rank reads the checkpoint itself (no collective needed); the lanes share that one copy
+        first = SpecModel.from_pretrained(base_model_path=REAL_WEIGHTS[0], spec_model_path=REAL_WEIGHTS[1], device=str(device), **TREE)
+        tcfg, dcfg = first.base_model.cfg, first.spec_layer.config
+        tw, dw = first.engine.tw, first.engine.dw
+        first.engine.close()
+        del first
+    else:  # rank 0 creates the weights; the others allocate same-shaped buffers (different seed) and receive rank 0's over RCCL
+        tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=True, num_q=TREE["num_q"],
+                                     rho=RHO[MODEL], succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
     t_rep = 0.0
-    if world > 1:
+    if world > 1 and not real:
         import torch.distributed as dist
         torch.cuda.synchronize()
         dist.barrier()
@@ -208,15 +243,10 @@ CPU_THREADS = 16  # torch's CPU GEMMs at M <= 30 are memory-bound and get SLOWER
                   # (tools/cpu_probe.py, [30,4096]x[11008,4096]: 6.0 ms at 16 threads, 26 ms at 64, 261 ms at 256)
 
 
-def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
-    """The reference's CPU path in spirit (SURVEY.md §8d, BASELINE.md §3): the oracle's restatement on its PyTorch-CPU back end
-    (oracle/torch_cpu.py: torch ops, fp32, torch.set_num_threads) runs the decode part of ONE request of the bench workload on the
-    host — the very weights the GPU streams (copied to the host, de-fused to the reference's state-dict names), the same prompt at its
-    real length: the draft prefill with image-token compression, then a bounded number (and a bounded time) of draft-and-verify rounds
-    with MEASURED accept lengths and of plain AR steps on the same cores.  The 2704-token TARGET prefill (36 TFLOP: minutes on host
-    cores) is not repeated on the CPU: its outputs — KV rows, hidden states, last logits — are copied from the GPU's prefill, which is
-    how the CPU rounds start from the real context.  tokens/s = (tau + 1) / seconds per round, steady state.  Checker-side code only:
-    nothing here is on the product path."""
+def cpu_models(sm, tcfg):
+    """The oracle's PyTorch-CPU restatement (oracle/torch_cpu.py) over the GPU's own weight pair, copied to the host and de-fused to the
+    reference's state-dict names — built once, used by both CPU legs.  Checker-side code only.  -> (target, draft, cores, seconds) or a string
+    saying why not."""
     from oracle import torch_cpu as tc
     from oracle import vispec_oracle as vo
     avail_gb = 0.0
@@ -229,7 +259,7 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
     n_par = sum(t.numel() for t in sm.engine.tw.tensors()) + sum(t.numel() for t in sm.engine.dw.tensors())
     need_gb = n_par * 4 * 1.6 / 1e9  # fp32 copies + transients
     if avail_gb and avail_gb < need_gb + 16:
-        return dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"skipped: {avail_gb:.0f} GB of host memory available, {need_gb:.0f} GB needed")
+        return f"skipped: {avail_gb:.0f} GB of host memory available, {need_gb:.0f} GB needed"
     cores = min(CPU_THREADS, os.cpu_count())
     torch.set_num_threads(cores)
     eng = sm.engine
@@ -242,7 +272,23 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
                                       rms_norm_eps=dcfg.rms_norm_eps, rope_theta=dcfg.rope_theta, num_q=eng.num_q, total_token=eng.total_token,
                                       depth=eng.depth, top_k=eng.top_k), tc.split_fused_draft(eng.dw))
     ot.ops, od.ops = tc.TorchOps(), tc.TorchOps()
-    t_copy = time.time() - t0
+    return ot, od, cores, time.time() - t0
+
+
+def cpu_baseline_leg(sm, tcfg, req, host, rounds=6, ar_steps=4, budget_s=20.0):
+    """The reference's CPU path in spirit (SURVEY.md §8d, BASELINE.md §3): the oracle's restatement on its PyTorch-CPU back end
+    (oracle/torch_cpu.py: torch ops, fp32, torch.set_num_threads) runs the decode part of ONE request of the bench workload on the
+    host — the very weights the GPU streams (copied to the host, de-fused to the reference's state-dict names), the same prompt at its
+    real length: the draft prefill with image-token compression, then a bounded number (and a bounded time) of draft-and-verify rounds
+    with MEASURED accept lengths and of plain AR steps on the same cores.  The 2704-token TARGET prefill (36 TFLOP: minutes on host
+    cores) is not repeated on the CPU: its outputs — KV rows, hidden states, last logits — are copied from the GPU's prefill, which is
+    how the CPU rounds start from the real context.  tokens/s = (tau + 1) / seconds per round, steady state.  Checker-side code only:
+    nothing here is on the product path."""
+    from oracle import torch_cpu as tc
+    if isinstance(host, str):
+        return dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=host)
+    ot, od, cores, t_copy = host
+    eng = sm.engine
     ids, pix = req
     emb_in, mask, _, pos3, rope_delta = sm._merge_vision(ids.clone(), None, dict(pix))
     emb = emb_in.reshape(-1, emb_in.shape[-1]).float().cpu().numpy()
@@ -272,24 +318,16 @@ def cpu_baseline_leg(sm, tcfg, req, rounds=6, ar_steps=4, budget_s=20.0):
                         f"de-fusing of the weights {t_copy:.0f}s (not timed)"))
 
 
-def cpu_config0_leg(sm, tcfg, rounds=8, ar_steps=3, budget_s=40.0):
+def cpu_config0_leg(sm, tcfg, host, rounds=6, ar_steps=2, budget_s=8.0):
     """BASELINE.json configs[0] — "the reference's own CPU-runnable case" (SURVEY.md §8d cfg 1): one LLaVA-1.5-7B-shaped request END TO
     END on the host cores, target prefill included: L = 576 image + 32 + 35 text tokens, LLaVA-1.5 semantics (the draft sees token ids, no
     image-token compression: SURVEY.md fact 0.7), the oracle on its PyTorch-CPU back end with the weight pair the GPU benchmark uses
-    (LLaVA-1.5-7B and v1.6-vicuna-7B share every dimension).  Opt-in (--cpu-config0): ~1 minute of host time.  Checker-side code only."""
+    (LLaVA-1.5-7B and v1.6-vicuna-7B share every dimension).  In the default line in a bounded form (~7 s of prefill + <= 8 s of rounds +
+    2 AR steps, the host models shared with cpu_baseline_leg); --no-cpu-config0 drops it.  Checker-side code only."""
     from oracle import torch_cpu as tc
-    from oracle import vispec_oracle as vo
-    cores = min(CPU_THREADS, os.cpu_count())
-    torch.set_num_threads(cores)
-    eng = sm.engine
-    ot = vo.TargetLlama(vo.TargetConfig(tcfg.hidden_size, tcfg.num_heads, tcfg.num_kv_heads, tcfg.intermediate_size, tcfg.vocab_size, tcfg.num_layers,
-                                        tcfg.max_position_embeddings, rms_norm_eps=tcfg.rms_norm_eps, rope_theta=tcfg.rope_theta,
-                                        attn_impl=tcfg.attn_impl, mrope_section=tcfg.mrope_section), tc.split_fused_target(eng.tw, tcfg))
-    dcfg = eng.dcfg
-    od = vo.DraftModel(vo.DraftConfig(dcfg.hidden_size, dcfg.num_heads, dcfg.intermediate_size, dcfg.vocab_size, max(eng.kv_max_pos, eng.draft_max_pos),
-                                      rms_norm_eps=dcfg.rms_norm_eps, rope_theta=dcfg.rope_theta, num_q=eng.num_q, total_token=eng.total_token,
-                                      depth=eng.depth, top_k=eng.top_k), tc.split_fused_draft(eng.dw))
-    ot.ops, od.ops = tc.TorchOps(), tc.TorchOps()
+    if isinstance(host, str):
+        return host
+    ot, od, cores, _ = host
     n_pre, n_img, n_post = 35, 576, 32
     from vispec_amd import synth
     ids, emb, mask = synth.make_request(tcfg.vocab_size, tcfg.hidden_size, n_pre, n_img, n_post, seed=9000, image_token_id=tcfg.image_token_index,
@@ -386,7 +424,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-config0", action="store_true", help="also run BASELINE configs[0] (LLaVA-1.5-7B shape, L=643) end to end on the host cores (~1 min)")
+    ap.add_argument("--no-cpu-config0", action="store_true",
+                    help="drop BASELINE configs[0] (one LLaVA-1.5-7B-shaped request, L=643, end to end on the host cores, ~20 s) from the cpu_baseline object")
+    ap.add_argument("--cpu-config0", action="store_true", help=argparse.SUPPRESS)  # (round 2-3 spelling: the leg is on by default now)
     ap.add_argument("--no-ar", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
@@ -406,8 +446,11 @@ def main():
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE config 4 mode: a step = this many independent (image, prompt) requests sharded round-robin over the "
                          "replicas (request i -> GPU i mod N, then over that GPU's lanes); 0 = one request per lane per step (weak scaling)")
+    ap.add_argument("--weights-dir", default=None, help="directory holding the published checkpoints under their hub names (default: $VISPEC_WEIGHTS)")
+    ap.add_argument("--base-model-path", default=None, help="target checkpoint directory (the reference harness's flag)")
+    ap.add_argument("--spec-model-path", default=None, help="ViSpec draft checkpoint directory (the reference harness's flag)")
     args = ap.parse_args()
-    global MODEL, N_IMG, WIDE_RB, REFILL, MAX_NEW
+    global MODEL, N_IMG, WIDE_RB, REFILL, MAX_NEW, REAL_WEIGHTS
     MAX_NEW = args.max_new_tokens
     REFILL = not args.no_refill
     MODEL = args.model
@@ -416,6 +459,7 @@ def main():
         N_IMG = args.n_img
         for k in ("llava7b", "llava13b"):
             MODELS[k]["desc"] = f"1 image ({N_IMG} image tokens) + 512 text + 48 template tokens per request (L={N_PRE + N_IMG + N_POST})"
+    REAL_WEIGHTS = resolve_weights(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", 0))
@@ -454,7 +498,7 @@ def main():
     K, W = args.steps, args.warmup
     streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
-    from vispec_amd.model.spec_model_ours import specgenerate_cohort, specgenerate_stream
+    from vispec_amd.model.spec_model_ours import baseline_generate_cohort, specgenerate_cohort, specgenerate_stream
     plan, scaling = request_plan(args.requests, rank, world, R, CO, W + K)
     req_cache = {}
 
@@ -501,6 +545,11 @@ def main():
                             tok += int(new_token)
                             rnd += idx + 1
                             accs += acc
+                    while CO >= 2 and ar == "cohort" and len(todo) >= 2:  # the AR baseline at the same batching: CO requests per weight pass
+                        now, todo = todo[:CO], todo[CO:]
+                        outs = baseline_generate_cohort(pairs[lane][:len(now)], [get_req(i) for i in now], max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1)
+                        for o, i in zip(outs, now):
+                            tok += o.shape[1] - get_req(i)[0].shape[1]
                     for i in todo:
                         ids, pix = get_req(i)
                         if ar:
@@ -590,7 +639,7 @@ def main():
                 all_ms = sum(v["ms"] for v in gemm_.values())
                 # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
                 # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
-                traffic = None
+                traffic = traffic_source = None
                 try:
                     if MODEL != "llava7b":
                         raise KeyError("the committed PMC pass was collected on the headline config only")
@@ -601,9 +650,12 @@ def main():
                     for k, v in pmc.items():
                         if key and key in k:
                             traffic = int(2 * 1024 * v["fetch_size_kb_per_launch"])
+                            traffic_source = (f"profiles/{os.path.basename(pmc_file)} (a separate `rocprofv3 --pmc FETCH_SIZE` pass of this kernel, committed with "
+                                              f"the tree: NOT measured by this run; x2 = the guide's gfx950 correction)")
                 except Exception:
                     pass
                 return dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
+                            traffic_source=traffic_source,
                             kernel=f"{dom_} ({keys.get(dom_, '?')})", what=note, launches=int(d["launches"]),
                             avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                             algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
@@ -683,15 +735,30 @@ def main():
                 if args.temperature <= 1e-5:
                     nmin = min(ar.shape[1], out.shape[1])
                     extra["spec_equals_ar_prefix"] = int((ar[0, :nmin] == out[0, :nmin]).long().cumprod(0).sum().item()) - ids.shape[1]
-                torch.cuda.synchronize()
-                t1 = time.time()
-                ar_plan = [lane_fn(l, W, W + 1, ar=True) for l in range(R)]
-                res_ar = run_lanes(ar_plan)
-                torch.cuda.synchronize()
-                t_arR = time.time() - t1
-                ar_rate = sum(r[0] for r in res_ar) / t_arR
-                extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, new_tokens=int(sum(r[0] for r in res_ar)), wall_s=round(t_arR, 3))
-                extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
+                # the speed-up of the LINE divides like by like (speed.py:56-97): the same lanes x cohorts, the requests of one timed step,
+                # decoded autoregressively with CO requests per weight pass (vispec_cohortn_ar_step)
+                def ar_leg(mode):
+                    torch.cuda.synchronize()
+                    t1_ = time.time()
+                    res_ = run_lanes([lane_fn(l, W, W + 1, ar=mode) for l in range(R)])
+                    torch.cuda.synchronize()
+                    dt_ = time.time() - t1_
+                    n_ = sum(r[0] for r in res_)
+                    return n_ / dt_, n_, dt_
+                if CO >= 2:
+                    ar_leg("cohort")  # (captures the AR cohort graphs outside the timed leg)
+                    ar_rate, ar_n, ar_dt = ar_leg("cohort")
+                    extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, cohort=CO, new_tokens=int(ar_n), wall_s=round(ar_dt, 3),
+                                                what=f"greedy AR of the same requests at the SAME batching as the timed region: {R} lanes x {CO} requests per weight pass")
+                    extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
+                    b1_rate, b1_n, b1_dt = ar_leg(True)
+                    extra["ar_baseline_batch1_lanes"] = dict(tokens_per_s=round(b1_rate, 2), lanes=R, cohort=1, new_tokens=int(b1_n), wall_s=round(b1_dt, 3),
+                                                             what=f"{R} lanes of batch-1 AR requests (one request per weight pass): NOT the denominator of speedup_vs_ar — "
+                                                                  f"against it the line is {round((tokens / world / dt) / b1_rate, 3)}x, most of which is batching, not speculation")
+                else:
+                    ar_rate, ar_n, ar_dt = ar_leg(True)
+                    extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, cohort=1, new_tokens=int(ar_n), wall_s=round(ar_dt, 3))
+                    extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
         except Exception as e:
             extra["extra_legs_error"] = f"{type(e).__name__}: {e}"[:300]
             try:
@@ -700,12 +767,14 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             try:
-                extra["cpu_baseline"] = cpu_baseline_leg(sm, tcfg, get_req(plan[0][W][0]))
+                host = cpu_models(sm, tcfg)
+                extra["cpu_baseline"] = cpu_baseline_leg(sm, tcfg, get_req(plan[0][W][0]), host)
             except Exception as e:  # never lose the GPU line to the CPU leg
-                extra["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(e).__name__}: {e}"[:300])
-            if args.cpu_config0 and MODEL == "llava7b":
+                host = f"failed: {type(e).__name__}: {e}"[:300]
+                extra["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=os.cpu_count(), kind="port", sample=host)
+            if not args.no_cpu_config0 and MODEL == "llava7b" and not REAL_WEIGHTS:  # BASELINE configs[0]: LLaVA-1.5-7B shares LLaVA-v1.6-7B's dimensions
                 try:
-                    extra["cpu_baseline"]["config0_end_to_end"] = cpu_config0_leg(sm, tcfg)
+                    extra["cpu_baseline"]["config0_end_to_end"] = cpu_config0_leg(sm, tcfg, host)
                 except Exception as e:
                     extra["cpu_baseline"]["config0_end_to_end"] = f"failed: {type(e).__name__}: {e}"[:300]
         per_step = (f"{args.requests} independent requests sharded round-robin over the {world} replica(s) and their lanes" if args.requests
@@ -722,8 +791,11 @@ def main():
             "config": {"workload": f"{MODELS[MODEL]['name']}-shaped target + ViSpec draft, {MODELS[MODEL]['desc']}, "
                                    f"max_new_tokens={MAX_NEW}, temperature={args.temperature:g}, total_token=30 depth=3 top_k=8 num_q=2; "
                                    f"a step = {per_step} (replicas share one weight copy per GPU)",
-                       "weights": f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
-                                  f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)",
+                       "weights": (f"real checkpoints: {REAL_WEIGHTS[0]} + {REAL_WEIGHTS[1]} (SpecModel.from_pretrained); prompts and image features "
+                                   f"are synthetic, so tau is what these weights accept on random prompts (published on COCO captions etc.: {TAU_PUBLISHED[MODEL]})"
+                                   if REAL_WEIGHTS else
+                                   f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
+                                   f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)"),
                        "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)"},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }

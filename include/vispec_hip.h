@@ -237,6 +237,10 @@ int vispec_sample_row(vispec_ctx*, void* stream, const void* logits_row_bf16, in
 int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
 /* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */
 int vispec_ar_step(vispec_ctx*, void* stream);
+/* The same for the n = 2..4 requests of a cohort (ctxs as for vispec_cohortn_verify_accept) on ONE weight pass: the AR baseline at the
+   batching of the speculative run it is compared with (speed.py:56-97 divides like by like).  Row for row vispec_ar_step's arithmetic:
+   a request's AR tokens do not depend on its cohort; a finished request (done != 0) freezes while the others go on. */
+int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stream);
 
 /* Blocking read-back of the round state: out[0]=n_ctx, [1]=new_token, [2]=rounds, [3]=done(eos|max_new), [4]=last accept_len,
    [5]=next_token, [6]=draft kv len, [7]=n_leaf of current tree. */

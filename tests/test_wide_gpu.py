@@ -360,3 +360,60 @@ def test_cohort_at_long_context_equals_the_single_requests():
     n = min(len(ar), len(out))
     assert n > 9000 + 20
     np.testing.assert_array_equal(ar[:n], out[:n])
+
+
+@pytest.mark.parametrize("n_req", [2, 3, 4])
+def test_cohort_ar_baseline_equals_the_single_request_ar_runs(golden_dir, n_req):
+    """vispec_cohortn_ar_step (bench.py's AR denominator at the cohort's batching): every request's greedy AR tokens are the tokens of
+    SpecModel.baseline_generate for that request alone — and, greedy decoding being what speculative decoding preserves, the tokens of its
+    speculative run (gen_baseline_answer_coco_caption.py:34-133 vs spec_model_ours.py:247-582).  Ragged budgets: requests freeze one by one."""
+    from vispec_amd.model.spec_model_ours import baseline_generate_cohort
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    members = [sm.make_cohort_member() for _ in range(n_req - 1)]
+    rng = np.random.default_rng(191)
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    n_img = 23
+    ids_img = np.concatenate([rng.integers(3, IMG_TOK, 5), np.full(n_img, IMG_TOK), rng.integers(3, IMG_TOK, 9)])
+    feats = synth.bf16_grid(rng.standard_normal((n_img, T["D"]), dtype=np.float32) * 0.05)
+    reqs = [(torch.from_numpy(g["succ0_ids"])[None], {}),
+            (torch.from_numpy(ids_img)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda())),
+            (torch.from_numpy(g["succ1_ids"])[None], {}),
+            (torch.from_numpy(rng.integers(3, IMG_TOK, 21))[None], {})][:n_req]
+    budgets = [30, 22, 41, 17][:n_req]
+    want = [sm.baseline_generate(ids, max_new_tokens=b, max_steps=b + 1, **kw) for (ids, kw), b in zip(reqs, budgets)]
+    st = {}
+    got = baseline_generate_cohort([sm] + members, reqs, max_new_tokens=budgets, stats=st)
+    assert st["steps"] >= max(budgets)
+    for t, (a, w, b) in enumerate(zip(got, want, budgets)):
+        np.testing.assert_array_equal(a[0].cpu().numpy(), w[0].cpu().numpy(), err_msg=f"request {t}")
+        assert a.shape[1] == reqs[t][0].shape[1] + b + 1  # no EOS in these streams: budget + the token that crossed it
+    spec = specgenerate_cohort([sm] + members, reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), a) in enumerate(zip(spec, got)):
+        n = min(toks.shape[1], a.shape[1])
+        np.testing.assert_array_equal(toks[0, :n].cpu().numpy(), a[0, :n].cpu().numpy(), err_msg=f"request {t}: speculative != AR")
+    # a second AR cohort on the same contexts replays the captured graph; the leader alone afterwards is still itself
+    got2 = baseline_generate_cohort([sm] + members, reqs, max_new_tokens=budgets)
+    for a, b in zip(got, got2):
+        assert torch.equal(a, b)
+    again = sm.baseline_generate(reqs[0][0], max_new_tokens=budgets[0], max_steps=budgets[0] + 1)
+    assert torch.equal(again, want[0])
+
+
+def test_destroying_a_leader_keeps_its_workspaces_until_the_last_member_is_gone():
+    """Round-3 advice: a member's GEMM workspaces are rows of its leader's.  Closing the leader first must not leave the members with dangling
+    pointers: the leader's allocations live on until its last member is closed, the members keep working as single requests, and a cohort
+    round on the destroyed leader is refused."""
+    sm, _, _ = build(50, 60, True)
+    m1, m2 = sm.make_cohort_member(), sm.make_cohort_member()
+    rng = np.random.default_rng(17)
+    ids = torch.from_numpy(rng.integers(3, T["V"], size=14))[None]
+    want = m1.specgenerate(ids, max_new_tokens=12)
+    lead_engine = sm.engine
+    lead_engine.close()
+    got = m1.specgenerate(ids, max_new_tokens=12)  # runs on rows of the (kept) leader workspaces
+    assert torch.equal(got, want)
+    got2 = m2.specgenerate(ids, max_new_tokens=12)
+    assert torch.equal(got2, want)
+    m1.engine.close()
+    assert torch.equal(m2.specgenerate(ids, max_new_tokens=12), want)
+    m2.engine.close()  # the last member frees the leader's allocations too

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
+bench.MODEL = os.environ.get("MODEL", "llava7b")  # llava7b | llava13b | qwen7b | qwen7b-hires | qwen7b-fp8
 dev = torch.device("cuda:0")
 sms, tcfg, _ = bench.build_models(dev, 0, 0, 1, 1)
 sm = sms[0]

@@ -240,7 +240,7 @@ struct tree_finalize_fn {
 };
 
 // A one-node "tree" = plain autoregressive decoding with the same verify kernels (baseline_forward).
-__global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
+__device__ __forceinline__ void tree_single_body(TreeBufs tb, DevState* st) {
   if (threadIdx.x == 0) {
     tb.tree_tokens[0] = st->next_token;
     tb.tree_pos[0] = 0;
@@ -251,6 +251,10 @@ __global__ void tree_single_kernel(TreeBufs tb, DevState* st) {
     st->tree_T = 1;
   }
 }
+__global__ void tree_single_kernel(TreeBufs tb, DevState* st) { tree_single_body(tb, st); }
+struct tree_single_fn {
+  template <class... A> __device__ __forceinline__ void operator()(A... a) const { tree_single_body(a...); }
+};
 
 // Greedy evaluate_posterior (utils.py:438-451) + the integer part of update_inference_inputs (utils.py:514-526,541,554,582)
 // am[i] = argmax of the target logits at tree node i.  sel[j] = tree node accepted at depth j (j = 0..a).
@@ -260,8 +264,9 @@ __device__ __forceinline__ void verify_accept_body(TreeBufs tb, DevState* st, co
   __shared__ int acc[TREE_MAX_T];
   const int tid = threadIdx.x;
   // cohort rounds only: a finished request (its partners are still running) freezes.  The single-request entry points keep
-  // stepping whatever `done` says — a caller driving the step API past EOS with its own stop rule gets fresh results every step.
-  if (cohort && st->done) {
+  // stepping past the EOS / budget flags — a caller driving the step API with its own stop rule gets fresh results every step — but
+  // NOT past bit 2 (the KV cache is full): the next tree's rows would be written beyond the cache slab, so that flag freezes always.
+  if ((cohort && st->done) || (st->done & 4)) {
     __syncthreads();
     if (tid == 0) st->frozen = 1;
     return;
@@ -485,7 +490,7 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
   __shared__ int s_i[2];
   __shared__ int s_hist[258];
   const int tid = threadIdx.x;
-  if (cohort && st->done) {  // finished request of a cohort (its partners are still running): freeze
+  if ((cohort && st->done) || (st->done & 4)) {  // finished request of a cohort (its partners are still running), or a full KV cache: freeze
     __syncthreads();
     if (tid == 0) st->frozen = 1;
     return;

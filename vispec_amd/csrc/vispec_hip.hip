@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "gemm_prefill.h"
+#include <mutex>
 #include "gemm_wide.h"
 #include "tree_kernels.h"
 
@@ -101,7 +102,8 @@ struct vispec_ctx {
       }
     }
   };
-  GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft;
+  GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft, g_car;
+  bool zombie = false;  // a leader destroyed while members were alive: its workspaces (which the members alias) are freed with the last member
   vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are 32-row tile `slot` of the leader's
   int slot = 0;                  // activation tile of this request inside the leader's 128-row workspaces (leader: 0, members: 1..3)
   vispec_ctx* members[3] = {nullptr, nullptr, nullptr};  // (leader) the member that owns tile 1, 2, 3
@@ -233,7 +235,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
           hipSuccess) {
     (void)hipGetLastError();  // a device-less build/load check must still be able to create nothing; report lazily
   }
-  {  // the wide-cohort GEMM declares 132 KiB of dynamic LDS
+  {  // the wide-cohort GEMM declares 128 KiB of dynamic LDS (WIDE_LDS_BYTES)
 #define WIDE_ALL_EPI_RB(W8_, NL_, RB_)                                                                                              \
   (const void*)gemm_w32_wide_kernel<EPI_NONE, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_RESIDUAL, W8_, NL_, 0, RB_>,   \
       (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_, 0, RB_>, \
@@ -269,20 +271,30 @@ extern "C" int vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* le
   return ctx_create_impl(cfg, leader, out);
 }
 
-extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
-  if (!ctx) return;
-  if (ctx->leader && ctx->slot >= 1 && ctx->leader->members[ctx->slot - 1] == ctx) {
-    ctx->leader->members[ctx->slot - 1] = nullptr;
-    // the leader's cached cohort graphs bake this member's buffers in, and a later member may be allocated at this very address
-    // (the graph key compares ctx pointers): drop them with the member
-    for (auto* g : {&ctx->leader->g_cverify, &ctx->leader->g_cdraft}) g->clear();
-  }
-  for (vispec_ctx* m : ctx->members)
-    if (m) m->leader = nullptr;  // (a member must not outlive its leader's workspaces; it can no longer join a cohort)
-  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft}) g->clear();
+static void ctx_free(vispec_ctx* ctx) {
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   delete ctx;
+}
+extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
+  if (!ctx || ctx->zombie) return;
+  if (ctx->leader && ctx->slot >= 1 && ctx->leader->members[ctx->slot - 1] == ctx) {
+    vispec_ctx* ld = ctx->leader;
+    ld->members[ctx->slot - 1] = nullptr;
+    // the leader's cached cohort graphs bake this member's buffers in, and a later member may be allocated at this very address
+    // (the graph key compares ctx pointers): drop them with the member
+    for (auto* g : {&ld->g_cverify, &ld->g_cdraft, &ld->g_car}) g->clear();
+    if (ld->zombie && !ld->members[0] && !ld->members[1] && !ld->members[2]) ctx_free(ld);  // the last member of a destroyed leader
+  }
+  // A member's GEMM workspaces ARE rows of its leader's (ctx_create_impl, AL): a leader destroyed while members are alive keeps its
+  // allocations until the last of them is gone (the members stay usable as single requests; the destroyed leader handle must not be used)
+  if (ctx->members[0] || ctx->members[1] || ctx->members[2]) {
+    for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
+    ctx->zombie = true;
+    return;
+  }
+  ctx_free(ctx);
 }
 
 extern "C" int vispec_set_target_layer(vispec_ctx* ctx, int layer, const vispec_layer_weights* w) {
@@ -547,13 +559,16 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   // of the CUs without a workgroup; three for gate|up (230 instead of 172 workgroups).  0 = the smallest of {2, 3, 4} whose grid still
   // runs in one round of CUs.  tools/wide_bench.py; one cohort lane 9.5 -> 8.7 ms per round with 0, four lanes 2064 -> 1980 tok/s.
   const int rb_opt = ctx ? ctx->wide_rb : 4;
+  // (experiments: restrict the eight-row-block form to GEMMs of a given size, in 32-row tiles)
+  static const int w8_tiles_min = getenv("VISPEC_WIDE8_TILES_MIN") ? atoi(getenv("VISPEC_WIDE8_TILES_MIN")) : 0;
+  static const int w8_tiles_max = getenv("VISPEC_WIDE8_TILES_MAX") ? atoi(getenv("VISPEC_WIDE8_TILES_MAX")) : 1 << 30;
 #define WIDE_LRB(EPI_, W8_, NL_, RB_, YPTR, LDY, SPLITS)                                                                                 \
   PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_, 0, RB_>), dim3((tiles + RB_ - 1) / RB_, SPLITS), dim3(RB_ * 256), WIDE_LDS_BYTES, s, x, ldx, w, \
           b, YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
     int rb_ = rb_opt;                                                                                                                   \
-    if (rb_ == 8 && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup, K walked quarter by quarter */            \
+    if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
       PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
               YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
       break;                                                                                                                            \
@@ -1107,12 +1122,17 @@ extern "C" int vispec_prefill_attention(vispec_ctx*, void* stream, const void* q
                                         int H, int H_kv, int L, void* out, int ldo, int eager_scores) {
   if (!q || !k_cache || !v_cache || !out) return fail("prefill_attention: null pointer");
   if (L < 1 || L > s_max || H < 1 || H_kv < 1 || H % H_kv || ldq % 8 || ldo % 4) return fail("prefill_attention: bad shape");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)prefill_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)prefill_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) != hipSuccess)
-      return fail("prefill_attention: cannot raise the dynamic LDS limit");
-    attr_set = true;
+  {  // the dynamic-LDS limit is a per-DEVICE attribute and lanes call from several host threads: once per device, under a flag of its own
+    static std::once_flag once[64];
+    static bool ok[64];
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail("prefill_attention: device index out of range");
+    std::call_once(once[dev], [dev]() {
+      ok[dev] = hipFuncSetAttribute((const void*)prefill_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) == hipSuccess &&
+                hipFuncSetAttribute((const void*)prefill_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES) == hipSuccess;
+    });
+    if (!ok[dev]) return fail("prefill_attention: cannot raise the dynamic LDS limit");
   }
   const int NB = (L + 127) / 128;
   const int paired = (NB / 2) * H >= 256 ? 1 : 0;  // a workgroup = one long + one short row block when that still fills the CUs
@@ -1827,6 +1847,7 @@ static int cohort_check(vispec_ctx* const* ctxs, int n, Cohort* co) {
     if (!ctxs[t]) return fail("null ctx");
   vispec_ctx* a = ctxs[0];
   if (a->leader) return fail("cohort: the first ctx must be the leader (an ordinary ctx)");
+  if (a->zombie) return fail("cohort: the leader was destroyed (vispec_ctx_destroy); its members can only run as single requests");
   if (a->c.total_token > 32) return fail("cohort: every request needs a tree of <= 32 nodes (one activation tile each)");
   co->n = n;
   for (int t = 0; t < 4; ++t) co->c[t] = nullptr;
@@ -1972,6 +1993,26 @@ extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
     KCHK();
     const Cohort co = solo_cohort(ctx);
+    if (target_forward(co, s, 1)) return -1;
+    return target_accept(co, s, 1, -1);
+  });
+}
+
+// The AR baseline at the cohort's batching (gen_baseline_answer_coco_caption.py:34-133 is batch 1 per request, like everything in the
+// reference; the speed-up bench.py prints divides like by like: n speculative requests per weight pass by n AR requests per weight pass):
+// one greedy token for each of the n requests, the target's GEMMs launched ONCE for all of them (m_tile = 1).  Row for row the
+// arithmetic of vispec_ar_step, so a request's AR tokens do not depend on its cohort; a finished request freezes like in a cohort round.
+extern "C" int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stream) {
+  Cohort co;
+  if (cohort_check(ctxs, n, &co)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  vispec_ctx* a = co.c[0];
+  return run_graphed(a, s, a->g_car, graph_key_n(co.c, n, -1, false), [&]() {
+    auto pk = [&](int t) { return make_pack(co.c[t]->tb, co.c[t]->st); };
+    decltype(pk(0)) b[4];
+    for (int t = 0; t < co.n; ++t) b[t] = pk(t);
+    launch_batch<tree_single_fn, 64>(s, dim3(1), 0, b, co.n);
+    KCHK();
     if (target_forward(co, s, 1)) return -1;
     return target_accept(co, s, 1, -1);
   });

@@ -433,6 +433,14 @@ class Engine:
     def ar_step(self):
         L.check(self.lib.vispec_ar_step(self.h, self._stream()))
 
+    def cohort_ar_step(self, members):
+        """One greedy AR token for each request of the cohort (this engine's and its members') on one weight pass."""
+        hs = [self] + list(members)
+        if any(e.h is None for e in hs):
+            raise L.VispecError("cohort_ar_step: a context of this cohort was closed")
+        arr = (C.c_void_p * len(hs))(*[e.h.value for e in hs])
+        L.check(self.lib.vispec_cohortn_ar_step(arr, len(hs), self._stream()))
+
     PROF_KINDS = ["gemm_none", "gemm_residual", "gemm_swiglu", "gemm_splitk_partial", "gemm_splitk_reduce", "gemm_qkv_rope", "k6", "gemm_prefill_mfma", "k8",
                   "attn_partial", "attn_reduce", "k11", "attn_partial_sdpa", "attn_reduce_sdpa"]
 

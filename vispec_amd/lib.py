@@ -86,6 +86,7 @@ SIGNATURES = {
     "vispec_sample_row": (c_int, [P, P, P, c_int, P]),
     "vispec_set_next_token": (c_int, [P, P, P]),
     "vispec_ar_step": (c_int, [P, P]),
+    "vispec_cohortn_ar_step": (c_int, [P, c_int, P]),
     "vispec_get_state_host": (c_int, [P, P, P]),
     "vispec_cohort_get_state_host": (c_int, [P, c_int, P, P]),
     "vispec_get_last_accept_host": (c_int, [P, P, P]),

@@ -390,12 +390,11 @@ class SpecModel:
 
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def baseline_generate(self, input_ids, inputs_embeds=None, max_new_tokens=512, max_steps=2048, **kwargs):
-        """Greedy AR with the same KV cache and kernels — evaluation/gen_baseline_answer_coco_caption.py:34-133."""
+    def _start_baseline(self, input_ids, inputs_embeds, kwargs, max_new_tokens):
+        """Prefill + first token of an AR request (gen_baseline_answer_coco_caption.py:60-110); -> the prompt ids on the device."""
         eng = self.engine
-        dev = eng.device
         eng.set_sampling(0.0, 0)
-        input_ids = input_ids.clone().to(dev)
+        input_ids = input_ids.clone().to(eng.device)
         inputs_embeds, _, _, position_ids, rope_delta = self._merge_vision(input_ids, inputs_embeds, kwargs)
         if inputs_embeds is None:
             inputs_embeds = self.base_model.get_input_embeddings()(input_ids)
@@ -406,7 +405,24 @@ class SpecModel:
         if rope_delta:
             eng.set_rope_delta(rope_delta)
         eng.set_next_token(first)
-        n = 0
+        return input_ids
+
+    def _finish_baseline(self, input_ids, n_ctx, max_new_tokens):
+        toks = self.engine.tokens(n_ctx).astype(np.int64)
+        eos = self.base_model.cfg.eos_token_id
+        gen = toks[input_ids.shape[1]:]
+        cut = np.nonzero(gen == eos)[0]
+        if cut.size:
+            toks = toks[: input_ids.shape[1] + int(cut[0]) + 1]
+        elif len(gen) > max_new_tokens + 1:
+            toks = toks[: input_ids.shape[1] + max_new_tokens + 1]
+        return torch.from_numpy(toks).to(self.engine.device)[None]
+
+    @torch.no_grad()
+    def baseline_generate(self, input_ids, inputs_embeds=None, max_new_tokens=512, max_steps=2048, **kwargs):
+        """Greedy AR with the same KV cache and kernels — evaluation/gen_baseline_answer_coco_caption.py:34-133."""
+        eng = self.engine
+        input_ids = self._start_baseline(input_ids, inputs_embeds, kwargs, max_new_tokens)
         sync_every = 16
         for n in range(1, max_steps + 1):
             eng.ar_step()
@@ -415,15 +431,40 @@ class SpecModel:
                 if st["done"]:
                     break
         st = eng.state()
-        toks = eng.tokens(st["n_ctx"]).astype(np.int64)
-        eos = self.base_model.cfg.eos_token_id
-        gen = toks[input_ids.shape[1]:]
-        cut = np.nonzero(gen == eos)[0]
-        if cut.size:
-            toks = toks[: input_ids.shape[1] + int(cut[0]) + 1]
-        elif len(gen) > max_new_tokens + 1:
-            toks = toks[: input_ids.shape[1] + max_new_tokens + 1]
-        return torch.from_numpy(toks).to(dev)[None]
+        return self._finish_baseline(input_ids, st["n_ctx"], max_new_tokens)
+
+
+@torch.no_grad()
+def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=2048, stats=None):
+    """The AR baseline (gen_baseline_answer_coco_caption.py:34-133) for two to four requests in LOCKSTEP on one weight pass: what
+    specgenerate_cohort is to specgenerate.  models / requests as there; max_new_tokens may be a list.  Returns one [1, L + new] id tensor
+    per request — the tokens `m.baseline_generate(ids, ...)` returns for that request alone (every row keeps the single-request
+    arithmetic; a request that reaches EOS or its budget freezes on the device while the others go on).  The speed-up bench.py prints
+    divides a cohort's speculative tokens/s by THIS rate: like by like (speed.py:56-97)."""
+    n = len(models)
+    if not 2 <= n <= 4 or len(requests) != n:
+        raise ValueError("a cohort is 2..4 models (leader, members...) and one request per model")
+    lead = models[0]
+    for m in models[1:]:
+        if m.engine.leader is not lead.engine:
+            raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
+    budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * n
+    prompts = [m._start_baseline(ids, None, dict(kw), mx) for m, (ids, kw), mx in zip(models, requests, budgets)]
+    members = [m.engine for m in models[1:]]
+    if stats is not None:
+        torch.cuda.current_stream().synchronize()
+        t_loop = time.time()
+    sync_every, steps = 16, 0
+    for steps in range(1, max_steps + 1):
+        lead.engine.cohort_ar_step(members)
+        if steps % sync_every == 0 or steps == max_steps:
+            states = lead.engine.cohort_states(members)
+            if all(st["done"] for st in states):
+                break
+    states = lead.engine.cohort_states(members)
+    if stats is not None:
+        stats.update(decode_s=time.time() - t_loop, steps=steps)
+    return [m._finish_baseline(p, st["n_ctx"], mx) for m, p, st, mx in zip(models, prompts, states, budgets)]
 
 
 @torch.no_grad()
