@@ -87,7 +87,7 @@ def resolve_weights(args):
 
 
 REFILL = True  # --no-refill: cohort by cohort
-WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 4)
+WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight where it pays)
 
 
 def build_models(device, seed, rank, world, lanes, cohort=1):
@@ -145,8 +145,10 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
         lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
-        if WIDE_RB >= 0 or lanes == 1:  # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it
-            lead.engine.set_wide_row_blocks(WIDE_RB if WIDE_RB >= 0 else 0)
+        # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it; several lanes: every launch costs CU-time
+        # in proportion to the bytes its workgroups ingest, so the GEMMs take eight row blocks per workgroup where that pays (same-box A/B
+        # in profiles/README.md, round 4: +3-4 % on the LLaVA / Qwen bf16 lines)
+        lead.engine.set_wide_row_blocks(WIDE_RB if WIDE_RB >= 0 else (0 if lanes == 1 else 84))
         sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
 
@@ -436,8 +438,9 @@ def main():
     ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
-    ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8),
-                    help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, 4 otherwise")
+    ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
+                    help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, "
+                         "84 (eight where it pays, else four) with several")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -577,6 +580,15 @@ def main():
     tokens = sum(r[0] for r in res)
     rounds = sum(r[1] for r in res)
     accs = [a for r in res for a in r[2]]
+    if os.environ.get("VISPEC_BENCH_RANKLOG"):  # what THIS rank did (tools/dryrun_world2.sh, tests/test_world2_gpu.py check the N > 1 control flow with it)
+        os.makedirs(os.environ["VISPEC_BENCH_RANKLOG"], exist_ok=True)
+        ck = parallel.checksum(list(eng.tw.tensors()) + list(eng.dw.tensors()))
+        with open(os.path.join(os.environ["VISPEC_BENCH_RANKLOG"], f"rank{rank}.json"), "w") as f:
+            json.dump(dict(rank=rank, world=world, device=str(device), weights_checksum=int(ck.item()), replicate_s=round(t_rep, 3),
+                           replicate_mode=os.environ.get("VISPEC_REPLICATE", "broadcast"),
+                           backend=None if dist is None else dist.get_backend(), timed_request_ids=sorted(i for lane in plan for st_ in lane[W:W + K] for i in st_),
+                           warmup_request_ids=sorted(i for lane in plan for st_ in lane[:W] for i in st_), tokens=int(tokens), rounds=int(rounds),
+                           wall_s=round(dt, 4)), f)
     stats = torch.tensor([dt, tokens, rounds, sum(accs)], dtype=torch.float64, device=device)
     if dist is not None:
         mx = stats.clone()
@@ -587,8 +599,6 @@ def main():
     else:
         acc_sum = float(sum(accs))
     value = tokens / dt
-    if os.environ.get("VISPEC_BENCH_DEBUG"):
-        log(f"[rank {rank}] prefill gate|up padding chosen: {getattr(sm.base_model.w, 'gu_pad', None)} rows")
 
     extra = {}
     if rank == 0:

@@ -233,6 +233,10 @@ int vispec_set_top_k(vispec_ctx*, int top_k);
    equivalent to the reference's torch RNG, bit-reproducible against the oracle).  temperature <= 1e-5 restores greedy. */
 int vispec_set_sampling(vispec_ctx*, float temperature, unsigned long long seed);
 int vispec_sample_row(vispec_ctx*, void* stream, const void* logits_row_bf16, int V, int* out_token_dev);
+/* Tests only: take the uniforms of the sampling accept — one per (candidate row, level): the reference's torch.rand_like (utils.py:461),
+   and one for the final multinomial (utils.py:488-493 / :551) — from a host table [n_leaf, max_depth] instead of the counter-based generator,
+   so that the reference's RECORDED draws (tests/golden g7, g11) can be replayed through vispec_accept.  u = NULL: off.  Blocking. */
+int vispec_set_uniform_override_host(vispec_ctx*, void* stream, const float* u, int n_leaf, int max_depth, float u_final);
 /* Seed the next token to decode (the prefill's argmax) when no draft is used (AR baseline). */
 int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
 /* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */
@@ -260,7 +264,10 @@ int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, di
 /* Launch shape of the GEMMs of a three- or four-request cohort round (no reference counterpart: the reference is batch-1 only,
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that
    several request lanes keep busy), 3 or 2 (more, smaller workgroups), 0 (the smallest of {2, 3, 4} whose grid still runs in one round
-   of CUs: a single lane).  Results are bit-identical in every setting. */
+   of CUs: a single lane), 8 (round 4: eight row blocks per workgroup, the K range walked quarter by quarter by every wave — half the
+   activation traffic per weight byte, half the workgroups: gemm_w32_wide8_kernel), 84 (eight for the bf16 GEMMs whose four-row-block
+   grid leaves a third of the CUs idle or spills into a second round of CUs, four elsewhere: what bench.py runs with several lanes).
+   Results are bit-identical in every setting. */
 int vispec_set_wide_row_blocks(vispec_ctx* leader, int row_blocks);
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
    HIP events on its own stream.  kinds 0..4 = skinny GEMM {none, residual, swiglu, split-K partial, split-K reduce(+norm)}, 9 = attention

@@ -84,7 +84,7 @@ def replay_levels(od, head_w, last, kv, len_posi, eng, worst):
             in_h = out[out_ids]
             tmask = np.concatenate([tmask[out_ids], np.eye(k, dtype=bool)], axis=1)  # a node inherits its PARENT'S row (cnets_ours.py:1163-1165)
     dout = eng.buffer("draft_out", (64, eng.dcfg.hidden_size))[:k].float().cpu().numpy()
-    np.testing.assert_allclose(dout, out, rtol=0, atol=2.0 ** -5 * np.abs(out).max())
+    np.testing.assert_allclose(dout, out, rtol=0, atol=2.0 ** -6 * np.abs(out).max())
 
 
 def run_case(sm, ot, od, ids, head_w, feats=None, grids=None, mask=None):
@@ -105,7 +105,7 @@ def run_case(sm, ot, od, ids, head_w, feats=None, grids=None, mask=None):
     out_c, kv, _ = od.forward_prefill(h_np, e_shift, None if mask_np is None else mask_np.astype(bool))
     last = out_c[-1:]
     dlast = eng.buffer("draft_last", (16, D))[:1].float().cpu().numpy()
-    np.testing.assert_allclose(dlast, last, rtol=0, atol=2.0 ** -5 * np.abs(last).max())
+    np.testing.assert_allclose(dlast, last, rtol=0, atol=2.0 ** -6 * np.abs(last).max())
     worst = [0.0]
     replay_levels(od, head_w, last, kv, L, eng, worst)
     check_tree_exact(eng)
@@ -120,7 +120,7 @@ def run_case(sm, ot, od, ids, head_w, feats=None, grids=None, mask=None):
     assert kv2[2] == n and kv2[0].shape[1] == kv[0].shape[1] + a + 1  # real length / compressed length after the catch-up
     last2 = out2[-1:]
     dlast2 = eng.buffer("draft_last", (16, D))[:1].float().cpu().numpy()
-    np.testing.assert_allclose(dlast2, last2, rtol=0, atol=2.0 ** -5 * np.abs(last2).max())
+    np.testing.assert_allclose(dlast2, last2, rtol=0, atol=2.0 ** -6 * np.abs(last2).max())
     replay_levels(od, head_w, last2, kv2, n, eng, worst)
     check_tree_exact(eng)
     assert eng.state()["draft_len"] == kv2[0].shape[1]

@@ -156,7 +156,7 @@ def test_multi_image_draft_prefill_against_the_repaired_reference_fixture(golden
     tol(kv[1][:, :Lc], want_v)
     tol(eng.buffer("draft_g", (1, T["D"])).float().cpu().numpy(), g[f"{tag}_g"])
     dlast = eng.buffer("draft_last", (16, T["D"]))[:1].float().cpu().numpy()
-    np.testing.assert_allclose(dlast[0], g[f"{tag}_out_last"], rtol=0, atol=2.0 ** -5 * np.abs(g[f"{tag}_out_last"]).max())
+    np.testing.assert_allclose(dlast[0], g[f"{tag}_out_last"], rtol=0, atol=2.0 ** -6 * np.abs(g[f"{tag}_out_last"]).max())
 
 
 def test_draft_prefill_stage_on_the_prefill_gemm():
@@ -231,8 +231,8 @@ def test_round_stages_against_oracle():
     ot.tree_mask = tmask
     want_logits, want_hidden = ot.forward(pkv, input_ids=tok, position_ids=pos + len(ids))
     # 2 target layers of bf16 with different accumulation orders: a few ulp at the activations' scale
-    np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=2.0 ** -5 * np.abs(want_hidden).max())
-    np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=2.0 ** -5 * np.abs(want_logits).max())
+    np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=2.0 ** -6 * np.abs(want_hidden).max())
+    np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=2.0 ** -6 * np.abs(want_logits).max())
     # BASELINE.json asks for "logits within 1e-3".  The logits are bf16 tensors in the reference too (one ulp = 3.9e-3 of the value),
     # so 1e-3 can only hold on average: measured 1.4e-3 of the logit scale in the mean, 8e-3 (two ulps) at worst, a quarter of the
     # entries bit-equal.  Asserted with a 2x margin; the token decisions built on them are compared exactly below.
@@ -254,7 +254,7 @@ def test_round_stages_against_oracle():
     kvd = e2.target_kv.float().cpu().numpy()
     for j in range(a + 1):
         np.testing.assert_allclose(kvd[:, 0, :, n + j], pkv_data[0][:, 0, :, n + ret[best, j]], rtol=0,
-                                   atol=2.0 ** -5 * np.abs(pkv_data[0]).max())
+                                   atol=2.0 ** -6 * np.abs(pkv_data[0]).max())
     # --- next draft round: tree logic exact on the device's own candidate lists
     e2.draft_round()
     check_tree_exact(e2)
@@ -401,6 +401,24 @@ def test_qwen25vl_target_loop_matches_oracle():
     np.testing.assert_array_equal(ar[0, :n].cpu().numpy(), o_out[:n])
 
 
+def fp8_codes_of(sm, D, H, Hkv, I, NL):
+    """The product's own e4m3 codes and per-output-channel scales, split back per projection: name -> (values fp32, scales) for the oracle
+    (handing it the very codes the kernels stream means exact .5 ties of w / scale cannot differ between the two quantisers)."""
+    etw = sm.engine.tw
+    f8 = lambda t: t.view(torch.float8_e4m3fn).float().cpu().numpy()
+    hd, codes = D // H, {}
+    for i in range(NL):
+        p_ = f"model.layers.{i}."
+        c8, s8 = etw.codes8[i], etw.scales8[i]
+        nq, nk = H * hd, Hkv * hd
+        for nm, key, lo, hi in (("self_attn.q_proj", "wqkv", 0, nq), ("self_attn.k_proj", "wqkv", nq, nq + nk), ("self_attn.v_proj", "wqkv", nq + nk, nq + 2 * nk),
+                                ("self_attn.o_proj", "wo", 0, D), ("mlp.gate_proj", "wgu", 0, I), ("mlp.up_proj", "wgu", I, 2 * I),
+                                ("mlp.down_proj", "wdown", 0, D)):
+            codes[p_ + nm + ".weight"] = (f8(c8[key][lo:hi]), s8[key][lo:hi].cpu().numpy())
+    codes["lm_head.weight"] = (f8(etw.c_lm_head8), etw.s_lm_head8.cpu().numpy())
+    return codes
+
+
 def build_qwen_fp8():
     """Qwen2.5-VL-tiny with fp8 (e4m3, per-output-channel) target weights + the oracle built on the product's own codes and scales."""
     Q = synth.QWEN_TINY
@@ -415,19 +433,7 @@ def build_qwen_fp8():
     dcfg = DraftConfig(hidden_size=Q["D"], num_heads=Q["H"], intermediate_size=Q["I"], vocab_size=Q["V"], max_position_embeddings=Q["max_pos"],
                        rms_norm_eps=Q["eps"], rope_theta=Q["theta"], qkv_bias=True)
     sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, target_weight_dtype="fp8")
-    # hand the oracle the product's own e4m3 codes and scales (split back per projection)
-    etw = sm.engine.tw
-    f8 = lambda t: t.view(torch.float8_e4m3fn).float().cpu().numpy()
-    hd, codes = Q["D"] // Q["H"], {}
-    for i in range(Q["NL"]):
-        p_ = f"model.layers.{i}."
-        c8, s8 = etw.codes8[i], etw.scales8[i]
-        nq, nk = Q["H"] * hd, Q["Hkv"] * hd
-        for nm, key, lo, hi in (("self_attn.q_proj", "wqkv", 0, nq), ("self_attn.k_proj", "wqkv", nq, nq + nk), ("self_attn.v_proj", "wqkv", nq + nk, nq + 2 * nk),
-                                ("self_attn.o_proj", "wo", 0, Q["D"]), ("mlp.gate_proj", "wgu", 0, Q["I"]), ("mlp.up_proj", "wgu", Q["I"], 2 * Q["I"]),
-                                ("mlp.down_proj", "wdown", 0, Q["D"])):
-            codes[p_ + nm + ".weight"] = (f8(c8[key][lo:hi]), s8[key][lo:hi].cpu().numpy())
-    codes["lm_head.weight"] = (f8(etw.c_lm_head8), etw.s_lm_head8.cpu().numpy())
+    codes = fp8_codes_of(sm, Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["NL"])
     ot = vo.TargetLlama(vo.TargetConfig(Q["D"], Q["H"], Q["Hkv"], Q["I"], Q["V"], Q["NL"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"],
                                         attn_impl="sdpa", mrope_section=Q["mrope_section"]), tw, bf16=True, fp8=codes)
     od = vo.DraftModel(vo.DraftConfig(Q["D"], Q["H"], Q["I"], Q["V"], Q["max_pos"], rms_norm_eps=Q["eps"], rope_theta=Q["theta"]), dw, bf16=True)

@@ -21,19 +21,36 @@ from test_loop_gpu import IMG_TOK, build  # noqa: E402
 
 
 # shapes: whole groups only / leftover k-steps (704 = 44 steps: quarters of 11) / split-K with uneven quarters (11008) / a ragged last
-# workgroup (1008 rows = 31.5 tiles; 96 rows = 3 tiles) / one k-step per quarter (K = 64) / the real layer shapes
-@pytest.mark.parametrize("N,K", [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (12288, 4096), (4096, 11008), (64, 64),
-                                 (32064, 512), (22016 // 2, 4096)])
-@pytest.mark.parametrize("n_req,m_tile", [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("row_blocks", [4, 3, 2, 8])
+# workgroup (1008 rows = 31.5 tiles; 96 rows = 3 tiles) / one k-step per quarter (K = 64) / the real layer shapes (LLaVA-7B, Qwen2.5-VL-7B)
+WIDE_SHAPES = [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (12288, 4096), (4096, 11008), (64, 64), (32064, 512),
+               (22016 // 2, 4096), (4608, 3584), (3584, 18944)]
+
+
+def wide_cases():
+    """(N, K, n_req, m_tile, epi, row_blocks): every launch shape of vispec_set_wide_row_blocks (8 = csrc/gemm_wide.h's eight-row-block kernel;
+    shapes whose K-quarters hold less than one 64-k group fall back to four row blocks inside the library) — small shapes with every row
+    count and epilogue, the large (bench) shapes at the bench row count, 2 / 3 row blocks at the bench row counts and a one-row tile."""
+    out = []
+    for N, K in WIDE_SHAPES:
+        for n_req, m_tile in [(3, 30), (4, 30), (4, 8), (3, 1), (4, 32)]:
+            for epi in (0, 1, 2):
+                for rb in (4, 3, 2, 8, 84):
+                    if epi == 2 and N % 16:
+                        continue
+                    if N * K > 2e7 and (m_tile != 30 or epi == 1):
+                        continue
+                    if rb in (2, 3) and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1)):
+                        continue
+                    if rb == 8 and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1), (4, 32)):
+                        continue
+                    if rb == 84 and ((n_req, m_tile) != (4, 30) or epi == 1):  # the per-shape policy: the bench row count only
+                        continue
+                    out.append((N, K, n_req, m_tile, epi, rb))
+    return out
+
+
+@pytest.mark.parametrize("N,K,n_req,m_tile,epi,row_blocks", wide_cases())
 def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, m_tile, epi, row_blocks):
-    if epi == 2 and N % 16:
-        pytest.skip("SwiGLU needs N % 16 == 0")
-    if N * K > 2e7 and (m_tile not in (30,) or epi == 1):
-        pytest.skip("large shapes: the bench configurations only")
-    if row_blocks != 4 and (n_req, m_tile) not in ((4, 30), (3, 30), (3, 1)):
-        pytest.skip("two row blocks per workgroup: the bench row counts and a one-row tile")
     L.check(lib.vispec_set_wide_row_blocks(engine.h, row_blocks))
     rng = np.random.default_rng(N + 3 * K + 17 * n_req + m_tile + epi)
     rows = 2 * N if epi == 2 else N
@@ -55,14 +72,12 @@ def test_wide_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engi
     L.check(lib.vispec_set_wide_row_blocks(engine.h, 4))
 
 
-@pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008)])
+@pytest.mark.parametrize("N,K,epi", [(N, K, e) for N, K in [(256, 704), (4096, 3584), (1024, 18944), (96, 11008), (4608, 3584), (256, 256)]
+                                     for e in (0, 1, 2) if not (e == 2 and N % 16)])
 @pytest.mark.parametrize("n_req", [3, 4])
-@pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("row_blocks", [4, 0, 8])
+@pytest.mark.parametrize("row_blocks", [4, 0, 8, 84])
 def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, epi, row_blocks):
     from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
-    if epi == 2 and N % 16:
-        pytest.skip("SwiGLU needs N % 16 == 0")
     m_tile = 30
     rng = np.random.default_rng(N + K + n_req + epi)
     rows = 2 * N if epi == 2 else N
@@ -88,15 +103,22 @@ def test_wide_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, 
 # The draft's GEMMs of a cohort (csrc/kernels.h, gemm_w32_kernel SLAB): the requests have at most 8 live rows each (top_k rows of a tree
 # level, depth + 2 catch-up rows, the root row) and share ONE activation tile — tile row 8 t + i is row 32 t + i of X / Y / R.  Same bar:
 # row for row bit-identical to the single-request launch; nothing outside the live rows is written.
-@pytest.mark.parametrize("N,K", [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (4096, 8192), (12288, 4096), (4096, 11008),
-                                 (64, 64), (32064, 512), (22016 // 2, 4096)])
-@pytest.mark.parametrize("n_req,rows", [(4, 8), (4, 5), (3, 8), (2, 8), (4, 1), (2, 3)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
+def slab_cases():
+    out = []
+    for N, K in [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (4096, 8192), (12288, 4096), (4096, 11008), (64, 64), (32064, 512),
+                 (22016 // 2, 4096)]:
+        for n_req, rows in [(4, 8), (4, 5), (3, 8), (2, 8), (4, 1), (2, 3)]:
+            for epi in (0, 1, 2):
+                if epi == 2 and N % 16:
+                    continue
+                if N * K > 2e7 and ((n_req, rows) not in ((4, 8), (4, 5)) or epi == 1):  # large shapes: the bench row counts only
+                    continue
+                out.append((N, K, n_req, rows, epi))
+    return out
+
+
+@pytest.mark.parametrize("N,K,n_req,rows,epi", slab_cases())
 def test_slab_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, rows, epi):
-    if epi == 2 and N % 16:
-        pytest.skip("SwiGLU needs N % 16 == 0")
-    if N * K > 2e7 and ((n_req, rows) not in ((4, 8), (4, 5)) or epi == 1):
-        pytest.skip("large shapes: the bench row counts only")
     rng = np.random.default_rng(N + 3 * K + 17 * n_req + rows + epi)
     nrows = 2 * N if epi == 2 else N
     x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
@@ -118,13 +140,11 @@ def test_slab_gemm_rows_are_bit_identical_to_the_single_request_kernel(lib, engi
         assert (Y[32 * t + rows:32 * t + 32].float() == 7.0).all(), "rows outside the live rows must stay untouched"
 
 
-@pytest.mark.parametrize("N,K", [(256, 704), (4096, 3584), (1024, 18944), (96, 11008), (152064 // 8, 512)])
+@pytest.mark.parametrize("N,K,epi", [(N, K, e) for N, K in [(256, 704), (4096, 3584), (1024, 18944), (96, 11008), (152064 // 8, 512)]
+                                     for e in (0, 1, 2) if not (e == 2 and N % 16)])
 @pytest.mark.parametrize("n_req,rows", [(4, 8), (3, 1)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
 def test_slab_gemm_fp8_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, rows, epi):
     from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
-    if epi == 2 and N % 16:
-        pytest.skip("SwiGLU needs N % 16 == 0")
     rng = np.random.default_rng(N + K + n_req + epi)
     nrows = 2 * N if epi == 2 else N
     x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
   constexpr int KSTEP = W8 ? 32 : 16, LOADS = W8 ? 2 : 4;
   constexpr int PPW = (4 * NL + 7) / 8;  // 1 KiB activation pieces a wave moves per group (NL = 3: 16 slots for 12 pieces, the last one fetched five times)
   constexpr int QIN = LA * (LOADS + PPW);  // memory operations in flight per wave in steady state
+  constexpr int XAHEAD = W8 ? 1 : 2;       // k-steps whose activation fragments are read from LDS ahead of their MFMAs (8 NL... 2 NL x 16 B per lane either way)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
   const int split = blockIdx.y;
@@ -459,30 +460,44 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
     const unsigned char* xs_ = xsrc + (size_t)(step0) * (KSTEP * 2);                                            \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) wide_dma16(xoff[i], xs_, xdst[i] + (unsigned)(slot) * WIDE8_BUFBYTES); \
   }
-  // one k-step (one weight tile register) against the NL staged activation tiles; a step below `sk` reads the zero buffer instead
-#define W8_MFMA(SL, u, xb_live, sk)                                                                           \
+  // The activation fragments of a group are read from LDS AHEAD of the MFMAs that consume them (two k-steps = 8 NL... 2 x NL x 16 B per lane in
+  // flight): the whole group is staged before its barrier, so the reads need not wait for the weight tile — with two waves per SIMD an
+  // LDS round trip in front of every MFMA quartet is what kept the matrix pipe at 44 % in the first form of this kernel (fp8: 29 GB/s
+  // per CU instead of the ~55 the CU can ingest).  A step below `sk` reads the zero buffer instead of the ring slot.
+  uint4 xf[LOADS][NL][W8 ? 2 : 1];
+#define W8_XREAD(u, xb_live, sk)                                                                              \
   {                                                                                                             \
     const unsigned char* xb_ = (u) < (sk) ? smem_w + NB * WIDE8_BUFBYTES : (xb_live);                           \
-    if constexpr (!W8) {                                                                                        \
-      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                       \
-        const uint4 bv = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[u]);                              \
-        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[SL][u]), as_bf16x8(bv), cur[mt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
+      if constexpr (!W8) {                                                                                      \
+        xf[u][mt][0] = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[u]);                                \
+      } else {                                                                                                  \
+        xf[u][mt][0] = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u)) & 3]);                    \
+        xf[u][mt][W8 ? 1 : 0] = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u) + 1) & 3]);       \
       }                                                                                                         \
+    }                                                                                                           \
+  }
+  // one k-step (one weight tile register) against the NL staged activation tiles
+#define W8_MFMA(SL, u)                                                                                        \
+  {                                                                                                             \
+    if constexpr (!W8) {                                                                                        \
+      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt)                                                         \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[SL][u]), as_bf16x8(xf[u][mt][0]), cur[mt], 0, 0, 0); \
     } else {                                                                                                    \
       uint4 a_lo, a_hi;                                                                                         \
       fp8x16_to_bf16(make_uint4(w[SL][u].x, w[SL][u].y, w[SL][u].z, w[SL][u].w), a_lo, a_hi);                   \
       _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                       \
-        const uint4 b0 = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u)) & 3]);                  \
-        const uint4 b1 = *reinterpret_cast<const uint4*>(xb_ + mt * 4096 + ro[(2 * (u) + 1) & 3]);              \
-        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(b0), cur[mt], 0, 0, 0);    \
-        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), cur[mt], 0, 0, 0);    \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_lo), as_bf16x8(xf[u][mt][0]), cur[mt], 0, 0, 0);           \
+        cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(xf[u][mt][W8 ? 1 : 0]), cur[mt], 0, 0, 0);  \
       }                                                                                                         \
     }                                                                                                           \
   }
+  // step u: its weight tile has landed -> (the fragment reads of the step after next go out) -> its MFMAs -> its register is re-issued
 #define W8_STEP(SL, u)                                                                                        \
   if constexpr ((u) < LOADS) {                                                                                  \
     wide_wait_vm<QIN - 1>(w[SL][(u) < LOADS ? (u) : 0]);                                                        \
-    W8_MFMA(SL, (u) < LOADS ? (u) : 0, xb, skip)                                                                \
+    if constexpr ((u) + XAHEAD < LOADS) W8_XREAD(((u) + XAHEAD < LOADS ? (u) + XAHEAD : 0), xb, skip)           \
+    W8_MFMA(SL, (u) < LOADS ? (u) : 0)                                                                          \
     wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[SL][(u) < LOADS ? (u) : 0], wvo, wn);                         \
   }
   // one group: SL = its weight-register slot (g % LA, compile time), `c` = its iterator, `pf` = the iterator LA groups ahead
@@ -493,6 +508,8 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
     const int s0p = it_step0(pf);                                                                               \
     const unsigned char* wn = wsrc + (size_t)s0p * 1024;                                                        \
     const unsigned char* xb = smem_w + rd * WIDE8_BUFBYTES;                                                     \
+    W8_XREAD(0, xb, skip)                                                                                       \
+    if constexpr (XAHEAD > 1) W8_XREAD((XAHEAD > 1 ? 1 : 0), xb, skip)                                          \
     W8_DMA(s0p, wr)                                                                                             \
     W8_STEP(SL, 0) W8_STEP(SL, 1) W8_STEP(SL, 2) W8_STEP(SL, 3)                                                 \
     if (live && it_last(c)) { /* the quarter is complete: fold it (uniform branch, three or four times per launch) */ \
@@ -540,6 +557,7 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
 #undef W8_GROUP
 #undef W8_STEP
 #undef W8_MFMA
+#undef W8_XREAD
 #undef W8_DMA
   if (!tile_ok) return;
   wide_epilogue<EPI, W8, NL>(tot, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re);

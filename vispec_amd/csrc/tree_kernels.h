@@ -479,7 +479,10 @@ __global__ __launch_bounds__(1024) void sample_row_kernel(const bf16_t* __restri
 __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
                                                                     int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
                                                                     int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
-                                                                    int* __restrict__ draft_ids, int cohort) {
+                                                                    int* __restrict__ draft_ids, const float* __restrict__ u_over, int cohort) {
+  // u_over (tests only, vispec_set_uniform_override_host): the uniforms of the rejection steps come from this table — [row j][level i] at
+  // j * TREE_RET_W + i, the final multinomial's at TREE_MAX_T * TREE_RET_W — instead of the counter-based generator: how the reference's
+  // recorded torch.rand_like draws (tests/golden g7) reach this kernel
   __shared__ int cand[TREE_MAX_T][TREE_RET_W];
   __shared__ int s_eq[TREE_MAX_T];
   __shared__ int accept_cand[TREE_RET_W];
@@ -546,7 +549,7 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
         seen[nseen++] = x;
         const float p = bf2f(row[x]) >= thr ? expf(bf2f(row[x]) / T - m) / Z : 0.f;
         const float px = p / (1.0f - rm);
-        if (vs_uniform(seed, (unsigned)round, (unsigned)j, (unsigned)i) <= px) {
+        if ((u_over ? u_over[j * TREE_RET_W + i] : vs_uniform(seed, (unsigned)round, (unsigned)j, (unsigned)i)) <= px) {
           accept_cand[al] = x;
           sh[0] = al + 1;
           sh[1] = j;
@@ -574,7 +577,8 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
     vs_row_stats(logits + (size_t)node * V, V, T, thr, s_f, m, Z);
     nrem = 0;
   }
-  const int next = vs_multinomial(logits + (size_t)node * V, V, T, m, thr, removed, nrem, vs_uniform(seed, (unsigned)round, 255u, 255u), s_d, s_i);
+  const int next = vs_multinomial(logits + (size_t)node * V, V, T, m, thr, removed, nrem,
+                                  u_over ? u_over[TREE_MAX_T * TREE_RET_W] : vs_uniform(seed, (unsigned)round, 255u, 255u), s_d, s_i);
   if (tid == 0) {
     const int* rowp = tb.retrieve + best * TREE_RET_W;
     const int n = st->n_ctx;
@@ -604,7 +608,7 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
 __global__ __launch_bounds__(1024) void verify_accept_sample_kernel(TreeBufs tb, DevState* st, const bf16_t* __restrict__ logits, int V, float T,
                                                                     int top_k, unsigned long long seed, int* __restrict__ tokens, int tokens_cap,
                                                                     int* __restrict__ sel, int* __restrict__ accept_log, int log_cap,
-                                                                    int* __restrict__ draft_ids, int cohort) { verify_accept_sample_body(tb, st, logits, V, T, top_k, seed, tokens, tokens_cap, sel, accept_log, log_cap, draft_ids, cohort); }
+                                                                    int* __restrict__ draft_ids, const float* __restrict__ u_over, int cohort) { verify_accept_sample_body(tb, st, logits, V, T, top_k, seed, tokens, tokens_cap, sel, accept_log, log_cap, draft_ids, u_over, cohort); }
 struct verify_accept_sample_fn {
   template <class... A> __device__ __forceinline__ void operator()(A... a) const { verify_accept_sample_body(a...); }
 };

@@ -72,7 +72,7 @@ struct vispec_ctx {
   // argument or shapes the launch sequence — compared field by field (a hashed single integer could collide and replay a graph
   // with the wrong sampling parameters).
   struct GraphKey {
-    int n_req = 0, forced_accept = 0, total_token = 0, wide_rb = 0;
+    int n_req = 0, forced_accept = 0, total_token = 0, wide_rb = 0, u_over = 0;
     // per request of the (cohort) round, leader first.  `who` = the ctx itself: a captured graph bakes that request's pointers in
     // (state, tree, KV, selections ...), so the same leader with a DIFFERENT member set must not replay it.
     const void* who[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -80,7 +80,7 @@ struct vispec_ctx {
     float temperature[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned long long seed[4] = {0, 0, 0, 0};
     bool operator==(const GraphKey& o) const {
-      return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && wide_rb == o.wide_rb &&
+      return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && wide_rb == o.wide_rb && u_over == o.u_over &&
              memcmp(who, o.who, sizeof(who)) == 0 &&
              memcmp(n_hint, o.n_hint, sizeof(n_hint)) == 0 && memcmp(sample_top_k, o.sample_top_k, sizeof(sample_top_k)) == 0 &&
              memcmp(temperature, o.temperature, sizeof(temperature)) == 0 && memcmp(seed, o.seed, sizeof(seed)) == 0;
@@ -103,6 +103,8 @@ struct vispec_ctx {
     }
   };
   GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft, g_car;
+  float* u_over = nullptr;  // tests only: uniforms of the sampling accept taken from here (vispec_set_uniform_override_host)
+  bool u_over_on = false;
   bool zombie = false;  // a leader destroyed while members were alive: its workspaces (which the members alias) are freed with the last member
   vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are 32-row tile `slot` of the leader's
   int slot = 0;                  // activation tile of this request inside the leader's 128-row workspaces (leader: 0, members: 1..3)
@@ -177,7 +179,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   A(accept_log, ctx->log_cap);
   AL(xa, D); AL(xn, D); AL(qkv, QKV); AL(attn_o, (size_t)c.num_heads * c.head_dim);
   AL(act, I); AL(hidden_new, D); AL(logits, V);
-  AL(am, 1); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D);
+  AL(am, 1); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D); A(u_over, TREE_MAX_T * TREE_RET_W + 1);
   AL(dx1, 2 * D); AL(dx2, 2 * D); AL(dx, D); AL(dqkv, 3 * D); AL(dattn, D);
   AL(dh, D); AL(dn, D); AL(dact, Id); AL(dout, D); AL(dlast, D);
   AL(dlogits, V); A(dg, D);
@@ -568,6 +570,11 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
     int rb_ = rb_opt;                                                                                                                   \
+    /* 84 = "eight where it pays, else four" (several lanes per GPU): the eight-row-block form for bf16 GEMMs whose four-row-block grid  \
+       leaves more than a third of the CUs without a workgroup (q|k|v, o_proj, down: <= 160 workgroups) or needs a second round of CUs    \
+       (Qwen's gate|up: 296, lm_head) — measured per shape in tools/wide_bench.py and on the bench lines (profiles/README.md, round 4);    \
+       fp8 weights stay on four (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte, two waves per SIMD) */ \
+    if (rb_ == 84) rb_ = (!(W8_) && (((tiles + 3) / 4) * (SPLITS) <= 160 || ((tiles + 3) / 4) * (SPLITS) > 256)) ? 8 : 4;                  \
     if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
       PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
               YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
@@ -1259,6 +1266,7 @@ static vispec_ctx::GraphKey graph_key_n(vispec_ctx* const* ctxs, int n, int forc
     const vispec_ctx* ctx = ctxs[t];
     const bool sampling = ctx->temperature > 1e-5f;
     k.who[t] = ctx;
+    k.u_over |= ctx->u_over_on ? 1 << t : 0;
     // the context hints reach the launches only as their maximum over the requests (the attention grids' split count): a stream of
     // requests of different lengths through the slots of a cohort replays one graph per maximum, not one per combination
     k.n_hint[0] = t == 0 ? ctx->n_hint : std::max(k.n_hint[0], ctx->n_hint);
@@ -1280,8 +1288,8 @@ extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
 }
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   if (!ctx) return fail("null ctx");
-  if (row_blocks != 0 && row_blocks != 8 && (row_blocks < 2 || row_blocks > 4))
-    return fail("wide_row_blocks: 8, 4, 3, 2, or 0 (= the smallest of 2..4 that still runs in one round of CUs)");
+  if (row_blocks != 0 && row_blocks != 8 && row_blocks != 84 && (row_blocks < 2 || row_blocks > 4))
+    return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 where it pays, else 4: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
@@ -1780,7 +1788,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
       auto pk = [&](int t) {
         vispec_ctx* x = co.c[t];
         return make_pack(x->tb, x->st, (const bf16_t*)x->logits, c.vocab_size, x->temperature, x->sample_top_k, x->seed, x->tokens, x->tokens_cap, x->sel,
-                         x->accept_log, x->log_cap, x->draft_ids, 1);
+                         x->accept_log, x->log_cap, x->draft_ids, (const float*)(x->u_over_on ? x->u_over : nullptr), 1);
       };
       decltype(pk(0)) a[4];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
@@ -1810,7 +1818,8 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
     vispec_ctx* ctx = co.c[t];
     if (ctx->temperature > 1e-5f && T > 1 && forced_accept < 0)
       hipLaunchKernelGGL(verify_accept_sample_kernel, dim3(1), dim3(1024), 0, s, ctx->tb, ctx->st, ctx->logits, c.vocab_size, ctx->temperature,
-                         ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids, co.n > 1 ? 1 : 0);
+                         ctx->sample_top_k, ctx->seed, ctx->tokens, ctx->tokens_cap, ctx->sel, ctx->accept_log, ctx->log_cap, ctx->draft_ids,
+                         (const float*)(ctx->u_over_on ? ctx->u_over : nullptr), co.n > 1 ? 1 : 0);
     else
       hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st, ctx->am, ctx->tokens, ctx->tokens_cap,
                          ctx->sel, ctx->accept_log, ctx->log_cap, forced_accept, ctx->draft_ids, co.n > 1 ? 1 : 0);
@@ -1920,6 +1929,23 @@ extern "C" int vispec_set_tree_host(vispec_ctx* ctx, void* stream, const int* to
 extern "C" int vispec_set_retrieve_host(vispec_ctx* ctx, void* stream, const int* retrieve, int n_leaf, int max_depth) {
   if (!ctx || !retrieve) return fail("null");
   return upload_retrieve(ctx, (hipStream_t)stream, retrieve, n_leaf, max_depth, ctx->c.total_token);
+}
+
+// Tests only: the uniforms of the sampling accept (utils.py:453-493: torch.rand_like per candidate row and level; one more for the final
+// multinomial) from a host table instead of the counter-based generator — the way the reference's RECORDED draws (tests/golden g7) are fed
+// to verify_accept_sample_kernel.  u = [n_leaf, max_depth] row-major; u == NULL switches the override off.  Blocking.
+extern "C" int vispec_set_uniform_override_host(vispec_ctx* ctx, void* stream, const float* u, int n_leaf, int max_depth, float u_final) {
+  if (!ctx) return fail("null ctx");
+  if (!u) { ctx->u_over_on = false; return 0; }
+  if (n_leaf < 1 || n_leaf > TREE_MAX_T || max_depth < 1 || max_depth > TREE_RET_W) return fail("uniform_override: bad shape");
+  std::vector<float> tab(TREE_MAX_T * TREE_RET_W + 1, 2.0f);  // (2 = never accepted)
+  for (int j = 0; j < n_leaf; ++j)
+    for (int i = 0; i < max_depth; ++i) tab[j * TREE_RET_W + i] = u[j * max_depth + i];
+  tab[TREE_MAX_T * TREE_RET_W] = u_final;
+  HIPCHK(hipMemcpyAsync(ctx->u_over, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  ctx->u_over_on = true;
+  return 0;
 }
 
 __global__ void set_stop2_kernel(DevState* st, int tok) {

@@ -84,6 +84,7 @@ SIGNATURES = {
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),
     "vispec_sample_row": (c_int, [P, P, P, c_int, P]),
+    "vispec_set_uniform_override_host": (c_int, [P, P, P, c_int, c_int, c_float]),
     "vispec_set_next_token": (c_int, [P, P, P]),
     "vispec_ar_step": (c_int, [P, P]),
     "vispec_cohortn_ar_step": (c_int, [P, c_int, P]),

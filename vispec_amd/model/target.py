@@ -22,47 +22,56 @@ from .. import lib as L
 from ..engine import Engine, TargetConfig, TargetWeights
 
 
-_pad_lock = __import__("threading").Lock()
+_gemm_lock = __import__("threading").Lock()
+_gemm_state = {"mode": None}
+# Recorded GEMM solutions of the prefill shapes (torch's TunableOp CSV: one line per (transposition, M, N, K, leading dims) with the library
+# solution that won an offline tuning run, preceded by validator lines: PyTorch / ROCm / hipBLASLt / rocBLAS versions and the GPU arch).
+# Written by tools/tune_prefill.py on an MI355X; TunableOp ignores the file when a validator does not match the running stack.
+PREFILL_GEMM_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tunable", "prefill_gemms_gfx950.csv")
 
 
-def _tune_gate_up_padding(weights, Ln: int, D: int):
-    """hipBLASLt's heuristic picks a stream-K kernel for the prefill's gate|up GEMM at some row counts (LLaVA-7B: [2704 x 4096] x
-    [22016 x 4096]^T 513 us = 0.95 PFLOP/s, but 353 us = 1.4 PFLOP/s with 512 zero rows appended — tools/gateup_split_probe.py).  Once
-    per weight set, at the first prefill, the zero-row paddings {0, 256, 512} of layer 0's matrix are timed at that prompt length and
-    the best one (if it wins by more than 5 %) is applied to a prefill-only copy of every layer's matrix (`wgu_prefill`); the padded
-    output columns are never read (vispec_silu_mul takes the row stride).  bf16 weights only."""
-    if getattr(weights, "gu_pad", None) is not None:
-        return
-    with _pad_lock:
-        if getattr(weights, "gu_pad", None) is not None:
-            return
-        pad_best = 0
-        lw0 = weights.layers[0]
-        if "wgu_scale" not in lw0 and os.environ.get("VISPEC_PREFILL_PAD", "1") != "0" and Ln >= 512:
-            base = lw0["wgu"]
-            x = torch.randn(Ln, D, device=base.device, dtype=base.dtype)
+def prefill_gemm_selection():
+    """Which library kernel runs the prefill's GEMMs is decided HERE, once per process and identically on every rank and lane — not by a
+    timing taken at the first prompt (rounds 2-3 padded the gate|up weight with zero rows until hipBLASLt's heuristic left a slow
+    stream-K kernel: a second copy of every gate|up matrix, chosen by whichever lane got there first, gone with the next ROCm).
 
-            def timed(w):
-                for _ in range(2):
-                    F.linear(x, w)
-                torch.cuda.synchronize(base.device)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    F.linear(x, w)
-                e1.record()
-                torch.cuda.synchronize(base.device)
-                return e0.elapsed_time(e1)
-
-            t_best = timed(base)
-            for pad in (256, 512):
-                tp = timed(torch.cat([base, torch.zeros(pad, D, device=base.device, dtype=base.dtype)]))
-                if tp < 0.95 * t_best:
-                    t_best, pad_best = tp, pad
-            if pad_best:
-                for lw in weights.layers:
-                    lw["wgu_prefill"] = torch.cat([lw["wgu"], torch.zeros(pad_best, D, device=base.device, dtype=base.dtype)]).contiguous()
-        weights.gu_pad = pad_best
+      VISPEC_PREFILL_GEMMS=recorded (default)  torch's TunableOp in LOOKUP-ONLY mode over the committed table PREFILL_GEMM_FILE (or
+                                               $VISPEC_PREFILL_GEMM_FILE): a shape in the table runs the recorded rocBLAS / hipBLASLt solution,
+                                               any other shape — and every shape when the table's validators do not match this PyTorch /
+                                               ROCm / GPU — runs the libraries' own default.  Deterministic; nothing is timed at run time.
+      VISPEC_PREFILL_GEMMS=default             TunableOp stays off.
+      VISPEC_PREFILL_GEMMS=tune                tuning on, results written to the file (tools/tune_prefill.py: offline, one process, idle GPU)."""
+    if _gemm_state["mode"] is not None:
+        return _gemm_state["mode"]
+    with _gemm_lock:
+        if _gemm_state["mode"] is not None:
+            return _gemm_state["mode"]
+        mode = os.environ.get("VISPEC_PREFILL_GEMMS", "recorded")
+        path = os.environ.get("VISPEC_PREFILL_GEMM_FILE", PREFILL_GEMM_FILE)
+        if mode not in ("recorded", "default", "tune"):
+            raise ValueError("VISPEC_PREFILL_GEMMS must be recorded, default or tune")
+        if mode != "default":
+            try:
+                import torch.cuda.tunable as tn
+                if mode == "tune":
+                    tn.enable(True)
+                    tn.tuning_enable(True)
+                    tn.set_filename(path)
+                elif os.path.exists(path):
+                    tn.enable(True)
+                    tn.tuning_enable(False)
+                    tn.set_filename(path)
+                    if not tn.read_file(path):  # validators of another stack: the libraries' defaults, and say so once
+                        tn.enable(False)
+                        mode = "default (the recorded table does not match this PyTorch / ROCm / GPU)"
+                        import warnings
+                        warnings.warn(f"{path}: recorded prefill GEMM solutions ignored (validator mismatch); re-run tools/tune_prefill.py")
+                else:
+                    mode = "default (no recorded table)"
+            except Exception as e:  # TunableOp is an optimisation: never lose a run to it
+                mode = f"default (TunableOp unavailable: {type(e).__name__})"
+        _gemm_state["mode"] = mode
+        return mode
 
 
 _sdpa_lock = __import__("threading").Lock()
@@ -217,7 +226,7 @@ class TargetLM:
         S = kv.shape[3]
         p = lambda t: C.c_void_p(t.data_ptr())
         native_attn = hd == 128 and os.environ.get("VISPEC_PREFILL_SDPA", "0") != "1"  # (A/B switch: torch's SDPA instead)
-        _tune_gate_up_padding(self.w, Ln, c.hidden_size)
+        prefill_gemm_selection()
 
         def rmsnorm(t, w):
             out = torch.empty_like(t)
@@ -245,7 +254,7 @@ class TargetLM:
                 q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
                 a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0].transpose(0, 1).reshape(Ln, H * hd)
             h = add_rmsnorm(x, scaled_linear(a, lw["wo"], None, lw.get("wo_scale")), lw["ln2"])
-            gu = scaled_linear(h, lw.get("wgu_prefill", lw["wgu"]), None, lw.get("wgu_scale"))  # [L, 2I (+ padding columns)]
+            gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))  # [L, 2I]
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
             L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
             y = scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))

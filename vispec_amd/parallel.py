@@ -20,33 +20,44 @@ def replicate_weights(tensors: Iterable[torch.Tensor], src: int = 0, group=None,
     mode = mode or os.environ.get("VISPEC_REPLICATE", "broadcast")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = 0
-    for t in tensors:
-        assert t.is_contiguous()
-        total += t.numel() * t.element_size()
+    # gloo moves CUDA tensors for broadcast / all_reduce only: the dry run of the N > 1 control flow on one GPU (bench.py with
+    # VISPEC_DIST_BACKEND=gloo) stages every tensor through the host; RCCL ("nccl") works on the device tensors themselves
+    via_host = world > 1 and dist.get_backend(group) == "gloo"
+    for t_dev in tensors:
+        assert t_dev.is_contiguous()
+        total += t_dev.numel() * t_dev.element_size()
         if world == 1:
             continue
-        if mode != "scatter":
-            dist.broadcast(t, src, group=group)
-            continue
-        flat = t.view(-1)
-        n = flat.numel()
-        shard = n // world
-        if n * t.element_size() < SMALL or shard == 0:
-            dist.broadcast(t, src, group=group)
-            continue
-        body = flat[: shard * world]
-        mine = torch.empty(shard, dtype=t.dtype, device=t.device)
-        dist.scatter(mine, list(body.split(shard)) if rank == src else None, src=src, group=group)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        if rank != src:
-            torch.cat(parts, out=body)
-        if shard * world < n:
-            tail = flat[shard * world :].clone()
-            dist.broadcast(tail, src, group=group)
-            if rank != src:
-                flat[shard * world :] = tail
+        t = t_dev.cpu() if via_host and t_dev.is_cuda else t_dev
+        _replicate_one(t, src, group, mode, world, rank)
+        if t is not t_dev and rank != src:
+            t_dev.copy_(t)
     return total
+
+
+def _replicate_one(t, src, group, mode, world, rank):
+    """One tensor: a broadcast, or (mode "scatter") scatter of 1/G shards over the root's peer links + all-gather."""
+    if mode != "scatter":
+        dist.broadcast(t, src, group=group)
+        return
+    flat = t.view(-1)
+    n = flat.numel()
+    shard = n // world
+    if n * t.element_size() < SMALL or shard == 0:
+        dist.broadcast(t, src, group=group)
+        return
+    body = flat[: shard * world]
+    mine = torch.empty(shard, dtype=t.dtype, device=t.device)
+    dist.scatter(mine, list(body.split(shard)) if rank == src else None, src=src, group=group)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    if rank != src:
+        torch.cat(parts, out=body)
+    if shard * world < n:
+        tail = flat[shard * world :].clone()
+        dist.broadcast(tail, src, group=group)
+        if rank != src:
+            flat[shard * world :] = tail
 
 
 def checksum(tensors: Iterable[torch.Tensor]) -> torch.Tensor:
