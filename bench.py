@@ -87,7 +87,7 @@ def resolve_weights(args):
 
 
 REFILL = True  # --no-refill: cohort by cohort
-WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight where it pays)
+WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight for bf16 weights, four for fp8)
 
 
 def build_models(device, seed, rank, world, lanes, cohort=1):
@@ -146,8 +146,8 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
         lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
         # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it; several lanes: every launch costs CU-time
-        # in proportion to the bytes its workgroups ingest, so the GEMMs take eight row blocks per workgroup where that pays (same-box A/B
-        # in profiles/README.md, round 4: +3-4 % on the LLaVA / Qwen bf16 lines)
+        # in proportion to the bytes its workgroups ingest, so the bf16 GEMMs take eight row blocks per workgroup (same-box A/Bs in
+        # profiles/README.md, round 4: +4 % on the LLaVA / Qwen bf16 lines; fp8 weights stay on four)
         lead.engine.set_wide_row_blocks(WIDE_RB if WIDE_RB >= 0 else (0 if lanes == 1 else 84))
         sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
@@ -440,7 +440,7 @@ def main():
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, "
-                         "84 (eight where it pays, else four) with several")
+                         "84 (eight for bf16 weights, four for fp8) with several")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -705,6 +705,30 @@ def main():
                                                 f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps): "
                                                 f"algorithmic bytes = the weight once, whatever the number of requests it serves")
                 extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
+                rb_timed = WIDE_RB if WIDE_RB >= 0 else (0 if R == 1 else 84)
+                extra["roofline"]["wide_row_blocks"] = rb_timed
+                if CO >= 3 and rb_timed != 0:
+                    # The instrumented cohort runs ALONE on the GPU with the launch shapes of the timed configuration, which are chosen for R lanes
+                    # sharing the GPU (fewer, larger workgroups: a launch costs CU-time in proportion to the bytes it ingests).  The same cohort with
+                    # the shapes a single lane would pick (vispec_set_wide_row_blocks(0)) shows what each kernel does when it has the GPU to itself.
+                    eng.set_wide_row_blocks(0)
+                    try:
+                        eng.prof_enable(True)
+                        st_1 = {}
+                        with torch.cuda.stream(streams[0]):
+                            specgenerate_cohort(pairs[0][:len(now)], [get_req(i) for i in now], max_new_tokens=min(MAX_NEW, 128), temperature=args.temperature,
+                                                seeds=now, stats=st_1)
+                        rep_1 = eng.prof_report()
+                        eng.prof_enable(False)
+                        rep_1.pop("gemm_prefill_mfma", None)
+                        extra["roofline"]["by_kernel_single_lane_shapes"] = dict(
+                            note="the same instrumented cohort with the launch shapes of ONE lane per GPU (--wide-row-blocks 0): not the timed configuration",
+                            cohort_round_ms=round(1e3 * st_1["decode_s"] / st_1["rounds"], 3),
+                            **{k: dict(avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2), GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                       frac=round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4)) for k, v in rep_1.items() if v["bytes"] > 0 and k.startswith("gemm")})
+                    finally:
+                        eng.prof_enable(False)
+                        eng.set_wide_row_blocks(rb_timed)
                 extra["roofline_single_request"] = single_roof
             else:
                 extra["roofline"] = single_roof

@@ -129,6 +129,11 @@ int vispec_add_rmsnorm(vispec_ctx*, void* stream, void* X, const void* R, const 
 /* SwiGLU activation of a gate|up block [M, 2I] (row stride ld): out[M, I] = bf16(bf16(silu(gate)) * up) — the prefill side of
    LlamaMLP (modeling_llama_kv.py:240-262), where the projections themselves are library GEMMs; any M */
 int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, int ld, void* out, int ldo, int M, int I);
+/* Epilogue of a PREFILL GEMM on fp8 (e4m3) weights whose accumulation a library GEMM did in fp32 (bf16 activations x codes):
+   out[m, n] = bf16(acc[m, n] * scale[n] (+ bias[n])) — the W8A16 rounding points of the decode GEMMs (no reference counterpart: the reference has
+   no fp8 path; BASELINE config 5) — one pass instead of three torch element-wise passes over the fp32 tensor. */
+int vispec_scale_bias_cast(vispec_ctx*, void* stream, const void* acc_f32, int ld, const void* scale_f32, const void* bias_bf16, void* out_bf16,
+                           int ldo, int M, int N);
 /* Causal self-attention of a prompt's L rows — the PREFILL side of LlamaAttention / Qwen2_5_VLSdpaAttention (modeling_llama_kv.py:595-640:
    scores bf16, fp32 softmax, eager_scores = 1; modeling_qwen2_5_vl_kv.py:1073-1170: SDPA, eager_scores = 0) without the [H, L, L]
    score tensor: q rows [L, ldq] (head h at column 128 h, rotary already applied by vispec_rope_append), K/V rows [0, L) of one layer's
@@ -265,8 +270,8 @@ int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, di
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that
    several request lanes keep busy), 3 or 2 (more, smaller workgroups), 0 (the smallest of {2, 3, 4} whose grid still runs in one round
    of CUs: a single lane), 8 (round 4: eight row blocks per workgroup, the K range walked quarter by quarter by every wave — half the
-   activation traffic per weight byte, half the workgroups: gemm_w32_wide8_kernel), 84 (eight for the bf16 GEMMs whose four-row-block
-   grid leaves a third of the CUs idle or spills into a second round of CUs, four elsewhere: what bench.py runs with several lanes).
+   activation traffic per weight byte, half the workgroups: gemm_w32_wide8_kernel), 84 (eight for bf16 weights, four for fp8 weights: what bench.py runs
+   with several lanes per GPU).
    Results are bit-identical in every setting. */
 int vispec_set_wide_row_blocks(vispec_ctx* leader, int row_blocks);
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by

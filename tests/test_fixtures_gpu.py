@@ -227,32 +227,42 @@ def _tuple_np(r):
     return r[0][0].cpu().numpy(), r[1].numpy(), r[2][0, 0].numpy() > 0, r[3].cpu().numpy()
 
 
-def test_g4_g14_topk_genrate_fixture_through_the_draft_kernels(golden_dir):
-    """Model.topK_genrate (cnets_ours.py:1043-1238) on the reference's own inputs: (a) the first call — draft prefill with image-token
-    compression + the first tree, (b) a decode round on accepted hidden rows — through vispec_draft_prefill / vispec_draft_round.  Integer
-    tuples (draft_tokens, retrieve_indices, tree_mask, tree_position_ids) of g4 and the tokens / mask of g14 exact; the hidden rows the
-    reference's forward hook saw (g14: last row of the prefill / catch-up forward, the k rows of the last tree level) within 2^-6 of scale.
-    The fixtures are the reference's fp32 run; a bf16 implementation may legitimately order two candidates differently when their fp32 scores
-    differ by less than bf16 resolves — the test then requires the kernel's choice to be score-equivalent (and reports it)."""
-    for fname, pre, sampling in (("g4_topk.npz", "greedy_", False), ("g4_topk.npz", "sampling_", True), ("g14_tree_levels.npz", "", False)):
-        # (sampling = the reference called with logits_processor != None: same tree, retrieve rows sorted — cnets_ours.py:1215-1224)
+def test_g4_g14_topk_genrate_fixture_inputs_through_the_draft_kernels(golden_dir):
+    """Model.topK_genrate (cnets_ours.py:1043-1238) on the reference's own INPUTS (g4 / g14: hidden states, embeddings, image mask, ids of
+    (a) the first call — draft prefill with image-token compression + the first tree — and (b) a decode round on accepted hidden rows) through
+    vispec_draft_prefill / vispec_draft_round.
+
+    What can be compared with what: these fixtures are the reference's fp32 CPU run of a RANDOM-weight pair, whose next-token distributions are
+    nearly flat — in bf16 (what the reference computes in on a GPU, and the kernels here) the top log-probabilities of a row are EQUAL numbers,
+    so the tree a bf16 implementation grows is decided by the tie rule (value desc, index asc), not by the fp32 order the fixture recorded:
+    the bf16-emulating oracle itself shares only 16 / 12 of the fixture's 30 nodes.  Hence: (1) selection-independent floats against the
+    FIXTURE — the last hidden row of the prefill forward and of the catch-up forward (g14's forward hook), 2^-6 of scale; (2) the integer tuples
+    (draft_tokens, retrieve_indices, tree_mask, tree_position_ids; greedy and the sampling row order) and the last level's hidden rows against
+    the ORACLE in bf16 mode run on the same fixture inputs — exact / 2^-6 — the oracle being held to these very fixtures in fp32 mode by
+    tests/test_oracle_golden.py (test_g4_topk_genrate, test_g14_tree_level_hidden_rows)."""
+    from helpers import oracle_draft, oracle_target
+    D = T["D"]
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for fname, sampling in (("g4_topk.npz", False), ("g4_topk.npz", True), ("g14_tree_levels.npz", False)):
         g = load(golden_dir, fname)
         sm, _, _ = build(20, 14, False)
         eng, dl = sm.engine, sm.spec_layer
         head = sm.base_model.lm_head
-        eng.set_sampling(1.0 if sampling else 0.0, 0)
+        ot, _ = oracle_target(seed=20, bf16=True)
+        od, _ = oracle_draft(num_q=2, seed=14, bf16=True)
+        od.reset_kv()
         hidden, ids, emb, mask = g["hidden"], g["ids"], g["embeds"], g["mask"]
-        t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))
         # ---- (a) first call: prompt = ids[:-1], first token = ids[-1]
+        eng.set_sampling(1.0 if sampling else 0.0, 0)
         eng.begin_request(ids[:-1].astype(np.int32), 200)
         dl.reset_kv()
         r = dl.topK_genrate(t_(hidden)[None].cuda(), t_(ids)[None].cuda(), head, None, inputs_embeds=t_(emb)[None].to(torch.bfloat16).cuda(),
                             image_mask=t_(mask)[None].cuda())
-        _check_tuple(_tuple_np(r), g, pre + "a", eng, f"{fname} (a)")
+        w = od.topK_genrate(hidden, ids, ot.lm_head, inputs_embeds=emb, image_mask=mask, sampling=sampling)
+        _same_tuple(_tuple_np(r), w, f"{fname} (a), sampling={sampling}")
+        _close(eng.buffer("draft_out", (64, D))[: eng.top_k].float().cpu().numpy(), od.level_debug[-1]["out"])
         if fname.startswith("g14"):
-            D = T["D"]
-            _close(eng.buffer("draft_last", (16, D))[0].float().cpu().numpy(), g["a_first_last_row"])
-            _close(eng.buffer("draft_out", (64, D))[: eng.top_k].float().cpu().numpy(), g["a_level2_out"])
+            _close(eng.buffer("draft_last", (16, D))[0].float().cpu().numpy(), g["a_first_last_row"])  # against the reference itself
         # ---- (b) decode round: the reference passes accept_hidden_state_new = h2 [a + 1, D] and the ids grown by a + 1 tokens; the library
         # stages the same through its accept step — impose that accept on a chain tree whose nodes carry h2 as their hidden states
         h2, ids2 = g["h2"], g["ids2"]
@@ -262,8 +272,8 @@ def test_g4_g14_topk_genrate_fixture_through_the_draft_kernels(golden_dir):
         eng.set_total_token(a1)
         chain = np.arange(a1, dtype=np.int32)
         eng.set_tree(new[:a1].astype(np.int32), chain, np.array([(1 << (j + 1)) - 1 for j in range(a1)], np.uint64), chain[None])
-        hn = eng.buffer("hidden_new", (64, T["D"]))
-        hn[:a1] = t_(h2).to(torch.bfloat16).to(hn.device)
+        hn = eng.buffer("hidden_new", (64, D))
+        hn[:a1] = t_(synth.bf16_grid(h2)).to(torch.bfloat16).to(hn.device)
         am = eng.buffer("am", (64,), torch.int32)
         am[:a1] = t_(new[1:].astype(np.int32)).to(am.device)
         eng.set_sampling(0.0, 0)  # (the imposed accept is the greedy one, whatever the tree ordering under test)
@@ -272,36 +282,23 @@ def test_g4_g14_topk_genrate_fixture_through_the_draft_kernels(golden_dir):
         eng.set_sampling(1.0 if sampling else 0.0, 0)
         eng.set_total_token(30)
         r2 = dl.topK_genrate(t_(h2)[None].cuda(), t_(ids2)[None].cuda(), head, None)
-        _check_tuple(_tuple_np(r2), g, pre + "b", eng, f"{fname} (b)")
+        w2 = od.topK_genrate(synth.bf16_grid(h2), ids2, ot.lm_head, sampling=sampling)
+        _same_tuple(_tuple_np(r2), w2, f"{fname} (b), sampling={sampling}")
+        _close(eng.buffer("draft_out", (64, D))[: eng.top_k].float().cpu().numpy(), od.level_debug[-1]["out"])
         if fname.startswith("g14"):
-            _close(eng.buffer("draft_last", (16, D))[0].float().cpu().numpy(), g["b_first_last_row"])
-            _close(eng.buffer("draft_out", (64, D))[: eng.top_k].float().cpu().numpy(), g["b_level2_out"])
+            _close(eng.buffer("draft_last", (16, D))[0].float().cpu().numpy(), g["b_first_last_row"])  # against the reference itself
 
 
 def _close(got, want, frac=2.0 ** -6):
     np.testing.assert_allclose(got, want, rtol=0, atol=frac * float(np.abs(want).max()))
 
 
-def _check_tuple(got, g, tag, eng, what):
-    from test_loop_gpu import dev_tree_inputs
+def _same_tuple(got, want, what):
     tok, ret, mask, pos = got
-    w_tok = g[f"{tag}_tokens"]
-    w_mask = g[f"{tag}_mask"] > 0
-    if np.array_equal(tok, w_tok):
-        np.testing.assert_array_equal(mask, w_mask, err_msg=what)
-        if f"{tag}_retrieve" in g.files:
-            np.testing.assert_array_equal(ret, g[f"{tag}_retrieve"], err_msg=what)
-            np.testing.assert_array_equal(pos, g[f"{tag}_pos"], err_msg=what)
-        return
-    # bf16 vs the fp32 fixture: the token multisets may differ only by candidates whose cumulative scores tie within bf16 resolution
-    sc, tk, pa = dev_tree_inputs(eng)
-    thr = np.sort(sc)[::-1][eng.total_token - 2]  # score of the last node kept by the global re-rank
-    extra = set(tok[1:].tolist()) ^ set(w_tok[1:].tolist())
-    tol = 2.0 ** -6 * float(np.abs(sc[np.isfinite(sc)]).max())
-    for t_id in extra:
-        near = [s for s, k in zip(sc, tk) if k == t_id]
-        assert near and min(abs(s - thr) for s in near) <= tol, f"{what}: token {t_id} differs from the fixture and is not a near-tie at the cut"
-    print(f"{what}: {len(extra)} tokens differ from the fp32 fixture, all near-ties at the re-rank cut (within 2^-6 of scale)")
+    np.testing.assert_array_equal(tok, want[0], err_msg=what + ": draft_tokens")
+    np.testing.assert_array_equal(ret, want[1], err_msg=what + ": retrieve_indices")
+    np.testing.assert_array_equal(mask, np.asarray(want[2]) > 0, err_msg=what + ": tree_mask")
+    np.testing.assert_array_equal(pos, want[3], err_msg=what + ": tree_position_ids")
 
 
 def test_g13_lm_head_logsoftmax_topk_and_input_fusion_at_the_real_dims(lib, golden_dir):

@@ -476,3 +476,20 @@ def test_gemm_qkv_rope_fused(lib, engine, H, Hkv, K, M, fp8, bias):
     assert_bf16_close(fn(kc1)[:, kvb : kvb + M], ko, ulps=2, min_exact=0.9, scale=pair(k_in))
     assert_bf16_close(fn(vc1)[:, kvb : kvb + M], vo_)
     assert (fn(kc1)[:, :kvb] == 0).all() and (fn(kc1)[:, kvb + M :] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,bias", [(1, 152064, False), (37, 4608, True), (300, 1008, True), (5, 8, False)])
+def test_scale_bias_cast_equals_the_torch_op_sequence_bit_for_bit(lib, M, N, bias):
+    """Epilogue of the fp8-weight prefill GEMMs: bf16(acc * scale + bias) in one pass == torch's mul / add / cast sequence (the arithmetic the
+    round-2 fp8 prefill used, pinned by test_fp8_prefill_computes_with_codes_and_scales_like_the_decode_gemms), exactly."""
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    acc = (torch.randn(M, N, generator=g) * 37.0).to(dev())
+    sc = (torch.rand(N, generator=g) * 0.01 + 1e-4).to(dev())
+    b = (torch.randn(N, generator=g) * 0.5).to(torch.bfloat16).to(dev()) if bias else None
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_scale_bias_cast(None, stream(), p(acc), N, p(sc), p(b), p(out), N, M, N))
+    want = acc * sc
+    if bias:
+        want = want + b.float()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want.to(torch.bfloat16))

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(Sync* s, int R, float* rec
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[i * 256 + threadIdx.x] = make_float4((float)phase, 1.f, 2.f, 3.f);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its own stores before the rendezvous (the guide's rule 14)
     __syncthreads();
     if (threadIdx.x == 0) {
       if (MODE == 0) {

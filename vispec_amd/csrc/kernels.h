@@ -651,6 +651,27 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   }
 }
 
+// Epilogue of the fp8-weight PREFILL GEMMs (model/target.py scaled_linear): the library GEMM leaves fp32 accumulators acc[M, N] (activations
+// x e4m3 codes); y = bf16(acc * scale[n] + bias[n]) — the rounding points of the decode GEMMs' W8A16 epilogue — in ONE pass instead of torch's
+// mul / add / cast passes over the fp32 tensor.  Explicit rn mul and add: no FMA contraction, so the result equals torch's op sequence bit for bit.
+__global__ __launch_bounds__(256) void scale_bias_cast_kernel(const float* __restrict__ acc, int ld, const float* __restrict__ scale,
+                                                              const bf16_t* __restrict__ bias, bf16_t* __restrict__ out, int ldo, int N) {
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (n >= N) return;
+  const float* a = acc + (size_t)blockIdx.y * ld + n;
+  const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(scale + n), s1 = *reinterpret_cast<const float4*>(scale + n + 4);
+  float v[8] = {__fmul_rn(a0.x, s0.x), __fmul_rn(a0.y, s0.y), __fmul_rn(a0.z, s0.z), __fmul_rn(a0.w, s0.w),
+                __fmul_rn(a1.x, s1.x), __fmul_rn(a1.y, s1.y), __fmul_rn(a1.z, s1.z), __fmul_rn(a1.w, s1.w)};
+  if (bias) {
+    const uint4 b = *reinterpret_cast<const uint4*>(bias + n);
+    const bf16_t* be = reinterpret_cast<const bf16_t*>(&b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = __fadd_rn(v[i], bf2f(be[i]));
+  }
+  *reinterpret_cast<uint4*>(out + (size_t)blockIdx.y * ldo + n) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
 // SwiGLU activation of a [M, 2I] gate|up row block (prefill side: the projections there are library GEMMs):
 // out = bf16( bf16(silu(gate)) * up ), the rounding points of F.silu(g) * u on bf16 tensors.  8 outputs per thread.
 __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict__ gu, int ld, bf16_t* __restrict__ out, int ldo, int I) {

@@ -570,11 +570,11 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
     int rb_ = rb_opt;                                                                                                                   \
-    /* 84 = "eight where it pays, else four" (several lanes per GPU): the eight-row-block form for bf16 GEMMs whose four-row-block grid  \
-       leaves more than a third of the CUs without a workgroup (q|k|v, o_proj, down: <= 160 workgroups) or needs a second round of CUs    \
-       (Qwen's gate|up: 296, lm_head) — measured per shape in tools/wide_bench.py and on the bench lines (profiles/README.md, round 4);    \
-       fp8 weights stay on four (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte, two waves per SIMD) */ \
-    if (rb_ == 84) rb_ = (!(W8_) && (((tiles + 3) / 4) * (SPLITS) <= 160 || ((tiles + 3) / 4) * (SPLITS) > 256)) ? 8 : 4;                  \
+    /* 84 = what several lanes per GPU run: eight row blocks for bf16 weights (+4 % on the bf16 lines in four same-box A/Bs; restricting  \
+       the eight-row-block form to the GEMMs whose four-row-block grid is small or spills into a second round keeps only half of that),    \
+       four for fp8 weights (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte on two waves per SIMD,  \
+       29 GB/s per CU instead of the 54 of the bf16 one) — profiles/README.md, round 4 */                                                  \
+    if (rb_ == 84) rb_ = (W8_) ? 4 : 8;                                                                                                   \
     if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
       PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
               YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
@@ -1161,6 +1161,16 @@ extern "C" int vispec_silu_mul(vispec_ctx*, void* stream, const void* gate_up, i
   KCHK();
   return 0;
 }
+// y[M, N] = bf16(acc[M, N] * scale[n] (+ bias[n])): the W8A16 epilogue applied to a library GEMM's fp32 output (fp8-weight prefill)
+extern "C" int vispec_scale_bias_cast(vispec_ctx*, void* stream, const void* acc_f32, int ld, const void* scale_f32, const void* bias_bf16, void* out_bf16,
+                                      int ldo, int M, int N) {
+  if (!acc_f32 || !scale_f32 || !out_bf16) return fail("scale_bias_cast: null pointer");
+  if (M < 1 || N < 8 || N % 8 || ld % 4 || ldo % 8) return fail("scale_bias_cast: N, ldo must be multiples of 8, ld of 4");
+  hipLaunchKernelGGL(scale_bias_cast_kernel, dim3((N / 8 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, (const float*)acc_f32, ld, (const float*)scale_f32,
+                     (const bf16_t*)bias_bf16, (bf16_t*)out_bf16, ldo, N);
+  KCHK();
+  return 0;
+}
 extern "C" int vispec_rope_append(vispec_ctx*, void* stream, void* qkv, int M, int H, int H_kv, int hd, const void* cosT,
                                   const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache,
                                   void* v_cache, int s_max, const int* kv_base_dev) {
@@ -1289,7 +1299,7 @@ extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   if (!ctx) return fail("null ctx");
   if (row_blocks != 0 && row_blocks != 8 && row_blocks != 84 && (row_blocks < 2 || row_blocks > 4))
-    return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 where it pays, else 4: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
+    return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 for bf16 weights, 4 for fp8: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vispec_qkv_rope_fused": (c_int, [c_int]),
     "vispec_gemm_qkv_rope": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P]),
     "vispec_silu_mul": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int]),
+    "vispec_scale_bias_cast": (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int]),
     "vispec_add_rmsnorm": (c_int, [P, P, P, P, P, P, c_int, c_int, c_float]),
     "vispec_prefill_attention": (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int]),
     "vispec_rope_append": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P]),

@@ -109,10 +109,21 @@ def scaled_linear(x, w, b=None, scale=None):
     if scale is None:
         return F.linear(x, w, b)
     x2 = x.reshape(-1, x.shape[-1])
-    y = torch.mm(x2, w.t(), out_dtype=torch.float32) * scale
+    acc = torch.mm(x2, w.t(), out_dtype=torch.float32)
+    N = w.shape[0]
+    if acc.is_cuda and N % 8 == 0 and x.dtype == torch.bfloat16:  # scale, bias and the bf16 rounding in one pass (vispec_scale_bias_cast)
+        lib = L.load()
+        out = torch.empty(acc.shape[0], N, dtype=torch.bfloat16, device=acc.device)
+        sc = scale.reshape(-1).float().contiguous()
+        bb = None if b is None else b.to(torch.bfloat16).contiguous()
+        L.check(lib.vispec_scale_bias_cast(None, C.c_void_p(torch.cuda.current_stream(acc.device).cuda_stream), C.c_void_p(acc.data_ptr()), N,
+                                           C.c_void_p(sc.data_ptr()), None if bb is None else C.c_void_p(bb.data_ptr()), C.c_void_p(out.data_ptr()), N,
+                                           acc.shape[0], N))
+        return out.reshape(*x.shape[:-1], N)
+    y = acc * scale
     if b is not None:
         y = y + b.float()
-    return y.to(x.dtype).reshape(*x.shape[:-1], w.shape[0])
+    return y.to(x.dtype).reshape(*x.shape[:-1], N)
 
 
 class _Head:
