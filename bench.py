@@ -397,6 +397,52 @@ def vision_tower_leg(tcfg, device, n_img, iters=5):
     return (time.time() - t0) / iters, what
 
 
+def dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device, iters=24):
+    """The dominant kernel the way the timed configuration runs it: gate|up + SwiGLU for CO requests, launched on EVERY lane's stream at once
+    through the library's own cohort GEMM entry (vispec_gemm_cohort, the launch shape of the timed region), each launch on another layer's
+    weights so that they stream from HBM.  The `roofline` object above times this kernel ALONE on the GPU, where the multi-lane launch shape
+    (fewer, larger workgroups) fills a third of the CUs by design; here all lanes' launches share the chip as they do in the timed region:
+    achieved = (launches x weight bytes) / wall time, HIP events on the launching streams."""
+    import ctypes as C
+    from vispec_amd import lib as L
+    lib = L.load()
+    R = len(sms)
+    D, I = tcfg.hidden_size, tcfg.intermediate_size
+    tw = sms[0].engine.tw
+    layers = tw.packed8 if fp8 else tw.packed
+    X = [torch.randn(32 * CO, D, device=device, dtype=torch.bfloat16) for _ in range(R)]
+    Y = [torch.empty(32 * CO, I, device=device, dtype=torch.bfloat16) for _ in range(R)]
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def launch(lane, it):
+        li = (it * R + lane) % len(layers)
+        sc = tw.scales8[li]["wgu"] if fp8 else None
+        L.check(lib.vispec_gemm_cohort(sms[lane].engine.h, C.c_void_p(streams[lane].cuda_stream), p(X[lane]), D, p(layers[li]["wgu"]), None if sc is None else p(sc),
+                                       None, p(Y[lane]), I, None, 0, CO, TREE["total_token"], I, D, 2))
+
+    for it in range(3):
+        for lane in range(R):
+            launch(lane, it)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(R)]
+    e0.record()
+    for st in streams:
+        st.wait_event(e0)
+    for it in range(iters):
+        for lane in range(R):
+            launch(lane, it)
+    for lane in range(R):
+        ends[lane].record(streams[lane])
+    torch.cuda.synchronize()
+    wall_ms = max(e0.elapsed_time(e) for e in ends)
+    nbytes = 2 * I * D * (1 if fp8 else 2)
+    ach = iters * R * nbytes / (wall_ms * 1e-3) / 1e9
+    return dict(what=f"gate|up + SwiGLU for {CO} requests launched on all {R} lanes' streams at once (vispec_gemm_cohort, the timed region's launch shape; every "
+                     f"launch on another layer's weights), {iters} launches per lane", streams=R, launches=iters * R,
+                us_per_launch_per_stream=round(1e3 * wall_ms / iters, 2), achieved=round(ach, 1), unit="GB/s", frac=round(ach / 8000.0, 4))
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on 127.0.0.1) —
     the same environment `python -m torch.distributed.run --nproc-per-node N` would set.  Rank 0's stdout carries the JSON line."""
@@ -700,13 +746,22 @@ def main():
                 eng.prof_enable(False)
                 rep_c.pop("gemm_prefill_mfma", None)
                 _, gemm_c, dom_c = price(rep_c)
-                keys_c = PROF_KERNEL_KEYS_WIDE if CO >= 3 else PROF_KERNEL_KEYS_PAIRED
-                extra["roofline"] = roofline_of(rep_c, gemm_c, dom_c, keys_c,
-                                                f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps): "
-                                                f"algorithmic bytes = the weight once, whatever the number of requests it serves")
-                extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
                 rb_timed = WIDE_RB if WIDE_RB >= 0 else (0 if R == 1 else 84)
+                wide8 = CO >= 3 and (rb_timed == 8 or (rb_timed == 84 and not fp8))
+                keys_c = (PROF_KERNEL_KEYS_WIDE8 if wide8 else PROF_KERNEL_KEYS_WIDE) if CO >= 3 else PROF_KERNEL_KEYS_PAIRED
+                extra["roofline"] = roofline_of(rep_c, gemm_c, dom_c, keys_c,
+                                                f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps, ALONE on the GPU): "
+                                                f"algorithmic bytes = the weight once, whatever the number of requests it serves"
+                                                + ("; the launch shape is the multi-lane one (eight weight row blocks per workgroup: half the workgroups, half "
+                                                   "the activation traffic) — alone it fills about a third of the CUs, each at the CU's ingest cap; `deployed` "
+                                                   "times the same kernel the way the timed region runs it" if wide8 else ""))
+                extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
                 extra["roofline"]["wide_row_blocks"] = rb_timed
+                if CO >= 3 and R >= 2:
+                    try:
+                        extra["roofline"]["deployed"] = dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device)
+                    except Exception as e:
+                        extra["roofline"]["deployed"] = f"not measured: {type(e).__name__}: {e}"[:200]
                 if CO >= 3 and rb_timed != 0:
                     # The instrumented cohort runs ALONE on the GPU with the launch shapes of the timed configuration, which are chosen for R lanes
                     # sharing the GPU (fewer, larger workgroups: a launch costs CU-time in proportion to the bytes it ingests).  The same cohort with
@@ -844,6 +899,9 @@ def main():
 PROF_KERNEL_KEYS_WIDE = {"gemm_none": "gemm_w32_wide_kernel<0,", "gemm_residual": "gemm_w32_wide_kernel<1,", "gemm_swiglu": "gemm_w32_wide_kernel<2,",
                          "gemm_splitk_partial": "gemm_w32_wide_kernel<3,", "gemm_qkv_rope": "gemm_w32_wide_kernel<4,",
                          "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
+PROF_KERNEL_KEYS_WIDE8 = {"gemm_none": "gemm_w32_wide8_kernel<0,", "gemm_residual": "gemm_w32_wide8_kernel<1,", "gemm_swiglu": "gemm_w32_wide8_kernel<2,",
+                          "gemm_splitk_partial": "gemm_w32_wide8_kernel<3,", "gemm_qkv_rope": "gemm_w32_wide8_kernel<4,",
+                          "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
 PROF_KERNEL_KEYS_PAIRED = {"gemm_none": "gemm_w32_kernel<2, 0,", "gemm_residual": "gemm_w32_kernel<2, 1,", "gemm_swiglu": "gemm_w32_kernel<2, 2,",
                            "gemm_splitk_partial": "gemm_w32_kernel<2, 3,", "gemm_qkv_rope": "gemm_w32_kernel<2, 4,",
                            "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}

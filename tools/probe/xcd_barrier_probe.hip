@@ -58,10 +58,11 @@ __global__ __launch_bounds__(256) void barrier_kernel(Sync* s, int R, float* rec
   for (int r = 0; r < R; ++r) {
     const unsigned phase = (unsigned)r + 1;
     if (MODE == 2) {  // publish: this workgroup's record for this phase (32 floats = 128 B)
-      if (threadIdx.x < 32) rec[(size_t)blockIdx.x * 32 + threadIdx.x] = (float)(phase * 1000 + blockIdx.x % 1000);
+      if (threadIdx.x < 32) rec[((size_t)(phase & 1) * 512 + blockIdx.x) * 32 + threadIdx.x] = (float)(phase * 1000 + blockIdx.x % 1000);
     }
     if (MODE == 3) {  // a 64 KiB slab per workgroup: 256 threads x 64 floats, 16-byte stores
-      float4* d = reinterpret_cast<float4*>(slab + (size_t)blockIdx.x * 16384);
+      float4* d = reinterpret_cast<float4*>(slab + ((size_t)(phase & 1) * 512 + blockIdx.x) * 16384);  // (double-buffered by phase parity: a
+                                                                                                    // fast neighbour may already be writing phase r + 1)
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[i * 256 + threadIdx.x] = make_float4((float)phase, 1.f, 2.f, 3.f);
     }
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(Sync* s, int R, float* rec
     if (MODE == 2) {  // consume: the record of the workgroup "across the chip"
       const unsigned other = (blockIdx.x + G / 2 + 3) % G;
       if (threadIdx.x < 32) {
-        const float v = rec[(size_t)other * 32 + threadIdx.x];
+        const float v = rec[((size_t)(phase & 1) * 512 + other) * 32 + threadIdx.x];
         if (v != (float)(phase * 1000 + other % 1000)) atomicAdd(bad, 1u);
         if (threadIdx.x == 0) seen = v;
       }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(Sync* s, int R, float* rec
     }
     if (MODE == 3) {
       const unsigned other = (blockIdx.x + G / 2 + 3) % G;
-      const float v = slab[(size_t)other * 16384 + threadIdx.x * 4];
+      const float v = slab[((size_t)(phase & 1) * 512 + other) * 16384 + threadIdx.x * 4];
       if (v != (float)phase) atomicAdd(bad, 1u);
     }
   }
@@ -144,7 +145,7 @@ static int run(const char* name, int G, Sync* s, float* rec, float* slab, unsign
 
 int main() {
   Sync* s; float *rec, *slab; unsigned* bad;
-  CK(hipMalloc(&s, sizeof(Sync))); CK(hipMalloc(&rec, 512 * 32 * 4)); CK(hipMalloc(&slab, (size_t)512 * 16384 * 4)); CK(hipMalloc(&bad, 8));
+  CK(hipMalloc(&s, sizeof(Sync))); CK(hipMalloc(&rec, 2 * 512 * 32 * 4)); CK(hipMalloc(&slab, (size_t)2 * 512 * 16384 * 4)); CK(hipMalloc(&bad, 8));
   for (int G : {256, 512}) {
     if (run<0>("flat", G, s, rec, slab, bad)) return 1;
     if (run<1>("xcd", G, s, rec, slab, bad)) return 1;
