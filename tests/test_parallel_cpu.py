@@ -70,3 +70,39 @@ def test_bench_request_plan_covers_every_request_exactly_once(world, lanes, coho
             sizes = sorted((len(lane[0]) for lane in p), reverse=True)
             mine = sum(sizes)
             assert sum(1 for z in sizes if z) == max(1, min(lanes, -(-mine // cohort)))
+
+
+def test_bench_resolves_real_checkpoint_directories(tmp_path, monkeypatch):
+    """bench.py --weights-dir / $VISPEC_WEIGHTS / --base-model-path + --spec-model-path (real checkpoints when present): the
+    published pair is looked up under its hub names (with or without the organisation directory), explicit paths win, half a pair or a
+    missing directory is refused, nothing given -> synthetic weights."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from types import SimpleNamespace as NS
+    monkeypatch.delenv("VISPEC_WEIGHTS", raising=False)
+    bench.MODEL = "llava7b"
+    assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=None)) is None
+    root = tmp_path / "w"
+    (root / "llava-hf" / "llava-v1.6-vicuna-7b-hf").mkdir(parents=True)
+    (root / "JLKang" / "ViSpec-llava-v1.6-vicuna-7b-hf").mkdir(parents=True)
+    got = bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(root)))
+    assert got == (str(root / "llava-hf" / "llava-v1.6-vicuna-7b-hf"), str(root / "JLKang" / "ViSpec-llava-v1.6-vicuna-7b-hf"))
+    monkeypatch.setenv("VISPEC_WEIGHTS", str(root))
+    assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=None)) == got
+    flat = tmp_path / "flat"
+    (flat / "Qwen2.5-VL-7B-Instruct").mkdir(parents=True)
+    (flat / "ViSpec-Qwen2.5-VL-7B-Instruct").mkdir(parents=True)
+    bench.MODEL = "qwen7b-fp8"  # the fp8 / high-res variants use the Qwen2.5-VL-7B pair
+    assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(flat))) == (
+        str(flat / "Qwen2.5-VL-7B-Instruct"), str(flat / "ViSpec-Qwen2.5-VL-7B-Instruct"))
+    bench.MODEL = "llava13b"  # not in this directory: synthetic
+    assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(flat))) is None
+    bench.MODEL = "llava7b"
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    assert bench.resolve_weights(NS(base_model_path=str(a), spec_model_path=str(b), weights_dir=str(root))) == (str(a), str(b))
+    monkeypatch.delenv("VISPEC_WEIGHTS")
+    with pytest.raises(SystemExit):
+        bench.resolve_weights(NS(base_model_path=str(a), spec_model_path=None, weights_dir=None))
+    with pytest.raises(SystemExit):
+        bench.resolve_weights(NS(base_model_path=str(a), spec_model_path=str(tmp_path / "missing"), weights_dir=None))
