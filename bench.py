@@ -39,8 +39,8 @@ MAX_NEW = 512
 # Acceptance is measured on a synthetic successor pair whose draft disagrees with the target on a fraction rho of the vocabulary.
 # rho is chosen per model so that the measured mean accept length lands near the reference's published one (README.md:186-195 of
 # the reference, T=0 averages): tau = p + p^2 + p^3 + p^4 with p ~ 1 - 0.91 rho at depth 3.
-TAU_PUBLISHED = {"llava7b": 2.98, "llava13b": 2.89, "qwen7b": 2.24, "qwen7b-hires": 2.24, "qwen7b-fp8": 2.24}
-RHO = {"llava7b": 0.115, "llava13b": 0.125, "qwen7b": 0.24, "qwen7b-hires": 0.24, "qwen7b-fp8": 0.24}
+TAU_PUBLISHED = {"llava7b": 2.98, "llava13b": 2.89, "qwen7b": 2.24, "qwen7b-hires": 2.24, "qwen7b-fp8": 2.24, "qwen7b-fp8a8": 2.24}
+RHO = {"llava7b": 0.115, "llava13b": 0.125, "qwen7b": 0.24, "qwen7b-hires": 0.24, "qwen7b-fp8": 0.24, "qwen7b-fp8a8": 0.24}
 TREE = dict(total_token=30, depth=3, top_k=8, num_q=2)
 # --model selects the BASELINE.json config; the default (configs[1]) is the headline line, the others are extra coverage runs
 MODELS = {
@@ -50,6 +50,8 @@ MODELS = {
     "qwen7b-hires": dict(name="Qwen2.5-VL-7B-Instruct", desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124), bf16 weights"),
     "qwen7b-fp8": dict(name="Qwen2.5-VL-7B-Instruct (fp8 e4m3 target weights, W8A16)",
                        desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124)"),
+    "qwen7b-fp8a8": dict(name="Qwen2.5-VL-7B-Instruct (fp8 e4m3 target weights AND activations: the fp8 MFMA, W8A8)",
+                         desc="one 1280x960 image = 68x92 patches (1564 merged tokens) + 512 text tokens (L=2124)"),
 }
 MODEL = "llava7b"
 
@@ -144,7 +146,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
     for _ in range(lanes):
         base = TargetLM(tcfg, tw)
         draft = Model(dcfg, dw, total_tokens=TREE["total_token"], depth=TREE["depth"], top_k=TREE["top_k"], num_q=TREE["num_q"])
-        lead = SpecModel(base, draft, target_weight_dtype="fp8" if MODEL.endswith("fp8") else "bf16", **TREE)
+        lead = SpecModel(base, draft, target_weight_dtype="fp8a8" if MODEL.endswith("fp8a8") else ("fp8" if MODEL.endswith("fp8") else "bf16"), **TREE)
         # one lane has the GPU to itself: smaller workgroups where the large ones cannot fill it; several lanes: every launch costs CU-time
         # in proportion to the bytes its workgroups ingest, so the bf16 GEMMs take eight row blocks per workgroup (same-box A/Bs in
         # profiles/README.md, round 4: +4 % on the LLaVA / Qwen bf16 lines; fp8 weights stay on four)
@@ -213,7 +215,7 @@ def _make_request(tcfg, req_id, device):
         parts.append(torch.randint(3, 151640, (224,), generator=g))
         ids = torch.cat(parts)
         return ids[None].to(device), dict(pixel_values=(4 * 256, req_id), image_grid_thw=torch.tensor(grids))
-    if MODEL in ("qwen7b-hires", "qwen7b-fp8"):
+    if MODEL in ("qwen7b-hires", "qwen7b-fp8", "qwen7b-fp8a8"):
         g = torch.Generator().manual_seed(1000 + req_id)
         ids = torch.cat([torch.randint(3, 151640, (48,), generator=g), torch.full((34 * 46,), tcfg.image_token_index),
                          torch.randint(3, 151640, (512,), generator=g)])
@@ -537,7 +539,7 @@ def main():
         torch.cuda.synchronize()
 
     R = max(1, args.lanes)
-    fp8 = MODEL.endswith("fp8")
+    fp8 = "fp8" in MODEL
     CO = args.cohort
     sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R, CO)
     pairs = sms if CO >= 2 else None
@@ -876,7 +878,7 @@ def main():
             "metric": f"accepted output tokens/sec (ViSpec speculative decoding, {MODELS[MODEL]['name']} + ViSpec draft, T={args.temperature:g})",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 2), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "fp8-w8a16" if fp8 else "bf16", "data": "synthetic",
+            "dtype": "fp8-w8a8" if MODEL.endswith("fp8a8") else ("fp8-w8a16" if fp8 else "bf16"), "data": "synthetic",
             "config": {"workload": f"{MODELS[MODEL]['name']}-shaped target + ViSpec draft, {MODELS[MODEL]['desc']}, "
                                    f"max_new_tokens={MAX_NEW}, temperature={args.temperature:g}, total_token=30 depth=3 top_k=8 num_q=2; "
                                    f"a step = {per_step} (replicas share one weight copy per GPU)",

@@ -110,6 +110,11 @@ int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const 
    (modeling_llama_kv.py: o_proj -> +residual -> post_attention_layernorm ; down_proj -> +residual -> next input_layernorm) */
 int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
                             const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M, int N, int K);
+/* W8A8 (vispec_set_fp8_activations) at unit level (tests): Y = bf16((q_x . q_w^T) * wscale[n] * sx[m] + b) [+ epilogue], X bf16 quantised per
+   row inside (sx = max|x| / 448, q = e4m3(x / sx)).  n_req = 1: M <= 64 rows; n_req = 2..4: vispec_gemm_cohort's row layout.  norm_w != NULL:
+   + residual and the fused RMSNorm of the split-K reduce (o_proj / down_proj form), written to `normed` (ld N).  No reference counterpart. */
+int vispec_gemm_fp8a8(vispec_ctx*, void* stream, const void* X, int ldx, const void* P8, const void* wscale_f32, const void* bias, void* Y, int ldy,
+                      const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps);
 /* The GEMM of a cohort round at unit level (tests): n_req = 2..4 requests of m_tile <= 32 rows each; request t's rows are rows
    32t .. 32t + m_tile - 1 of X / Y / R (which therefore span 32 n_req rows; rows beyond m_tile of a tile are neither read for results
    nor written).  Same epilogues as vispec_gemm_skinny (0 none, 1 +R, 2 SwiGLU).  Row for row bit-identical to vispec_gemm_skinny on the
@@ -265,6 +270,11 @@ int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, u
                          int* n_leaf, int* max_depth);
 /* hipGraph replay of the round functions (verify_accept / draft_round / ar_step) on capturable (non-null) streams: on by default. */
 int vispec_set_graphs(vispec_ctx*, int on);
+/* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"; the reference has no fp8 path): with fp8 target weights, also take the ACTIVATIONS of the
+   target's four per-layer GEMMs (modeling_qwen2_5_vl_kv.py:1065-1170: q|k|v, o_proj, gate|up, down) in e4m3 — one dynamic scale per row —
+   and multiply on v_mfma_scale_f32_32x32x64_f8f6f4 (W8A8) instead of up-converting the weight codes for the bf16 MFMA (W8A16, the default).
+   A different arithmetic ("same accepted tokens or documented divergence"); lm_head, draft and prefill unchanged. */
+int vispec_set_fp8_activations(vispec_ctx*, int on);
 int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, direct runs} */
 /* Launch shape of the GEMMs of a three- or four-request cohort round (no reference counterpart: the reference is batch-1 only,
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that

@@ -46,7 +46,9 @@ class TorchOps(vo.Ops):
             self._wcache[key] = t
         return t
 
-    def linear(self, x, W, b=None):  # nn.Linear
+    def linear(self, x, W, b=None, a8=False):  # nn.Linear (a8: the numpy back end only)
+        if a8:
+            raise NotImplementedError("fp8 activations are restated on the numpy back end only")
         if isinstance(W, tuple):
             return super().linear(x, W, b)
         w = self._w(W)

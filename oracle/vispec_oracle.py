@@ -96,7 +96,17 @@ class Ops:
         self.bf16 = bf16
         self.rd = bf16_round if bf16 else _ident
 
-    def linear(self, x, W, b=None):
+    def linear(self, x, W, b=None, a8=False):
+        if isinstance(W, tuple) and a8:
+            # W8A8 (vispec_set_fp8_activations; no reference counterpart — the reference has no fp8 path): the activations are quantised too,
+            # one dynamic scale per row: sx = max|x[m, :]| / 448, q = e4m3(x / sx); y = (q_x . q_w^T) * scale_w[n] * sx[m] (+ b).  Products of
+            # e4m3 numbers are exact in fp32 and the fp8 MFMA accumulates in fp32, so numpy reproduces it up to summation order.
+            x = np.asarray(x, np.float32)
+            sx = (np.maximum(np.abs(x).max(axis=-1, keepdims=True), np.float32(1e-12)) / np.float32(448.0)).astype(np.float32)
+            y = ((e4m3_round((x / sx).astype(np.float32)) @ W[0].T) * W[1][None, :]) * sx
+            if b is not None:
+                y = y + np.asarray(b, np.float32)
+            return self.rd(y.astype(np.float32))
         if isinstance(W, tuple):  # (e4m3 values, per-output-channel scales): y = scale * (x · q^T) (+b), W8A16
             y = (np.asarray(x, np.float32) @ W[0].T) * W[1][None, :]
             if b is not None:
@@ -485,6 +495,8 @@ class TargetLlama:
             cos, sin = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
         self.cos, self.sin = np.asarray(cos, np.float32), np.asarray(sin, np.float32)
         self.tree_mask = None  # [T,T] bool, installed by the loop (spec_model_ours.py:486-489)
+        self.a8_decode = False  # True (fp8 weights only): forwards on a non-empty cache — tree verify, AR steps — quantise the activations of the
+                                # four per-layer GEMMs too (Ops.linear a8=True); the prefill, like the product's PyTorch prefill, does not
 
     @property
     def lm_head(self):
@@ -512,12 +524,13 @@ class TargetLlama:
             T = self.tree_mask.shape[-1]
             allow[-T:, -T:] &= self.tree_mask.astype(bool)
         rep = c.num_heads // c.num_kv_heads
+        a8 = dict(a8=True) if (self.a8_decode and n_past > 0) else {}
         for i in range(c.num_layers):
             p = f"model.layers.{i}."
             h = o.rmsnorm(x, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
-            q = o.linear(h, self.w[p + "self_attn.q_proj.weight"], self.w.get(p + "self_attn.q_proj.bias"))
-            k = o.linear(h, self.w[p + "self_attn.k_proj.weight"], self.w.get(p + "self_attn.k_proj.bias"))
-            v = o.linear(h, self.w[p + "self_attn.v_proj.weight"], self.w.get(p + "self_attn.v_proj.bias"))
+            q = o.linear(h, self.w[p + "self_attn.q_proj.weight"], self.w.get(p + "self_attn.q_proj.bias"), **a8)
+            k = o.linear(h, self.w[p + "self_attn.k_proj.weight"], self.w.get(p + "self_attn.k_proj.bias"), **a8)
+            v = o.linear(h, self.w[p + "self_attn.v_proj.weight"], self.w.get(p + "self_attn.v_proj.bias"), **a8)
             q = q.reshape(S, c.num_heads, c.head_dim).transpose(1, 0, 2)
             k = k.reshape(S, c.num_kv_heads, c.head_dim).transpose(1, 0, 2)
             v = v.reshape(S, c.num_kv_heads, c.head_dim).transpose(1, 0, 2)
@@ -529,11 +542,11 @@ class TargetLlama:
                 kk = np.repeat(kk, rep, axis=0)
                 vv = np.repeat(vv, rep, axis=0)
             a = attn(q, kk, vv, allow).transpose(1, 0, 2).reshape(S, c.hidden_size)
-            x = o.add(x, o.linear(a, self.w[p + "self_attn.o_proj.weight"]))
+            x = o.add(x, o.linear(a, self.w[p + "self_attn.o_proj.weight"], **a8))
             h = o.rmsnorm(x, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
-            g = o.linear(h, self.w[p + "mlp.gate_proj.weight"])
-            u = o.linear(h, self.w[p + "mlp.up_proj.weight"])
-            x = o.add(x, o.linear(o.silu_mul(g, u), self.w[p + "mlp.down_proj.weight"]))
+            g = o.linear(h, self.w[p + "mlp.gate_proj.weight"], **a8)
+            u = o.linear(h, self.w[p + "mlp.up_proj.weight"], **a8)
+            x = o.add(x, o.linear(o.silu_mul(g, u), self.w[p + "mlp.down_proj.weight"], **a8))
         hidden = o.rmsnorm(x, self.w["model.norm.weight"], c.rms_norm_eps)  # :1062
         logits = o.linear(hidden, self.w["lm_head.weight"])  # then .float()
         return logits.astype(np.float32), hidden

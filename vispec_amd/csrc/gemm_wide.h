@@ -43,6 +43,10 @@ template <int N>
 __device__ __forceinline__ void wide_wait_vm(u32x4_t& w) {  // "+v": nothing that consumes w may be scheduled above the wait
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "i"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wide_wait_vm2(u32x4_t& w0, u32x4_t& w1) {  // the same for a step that consumes two weight registers
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w0), "+v"(w1) : "i"(N) : "memory");
+}
 template <int OFF>
 __device__ __forceinline__ void wide_load_w(u32x4_t& w, unsigned voff, const unsigned char* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(w) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
@@ -59,10 +63,11 @@ __device__ __forceinline__ void wide_wait_barrier() {  // own DMAs landed (N you
 
 // ---- epilogues (the arithmetic of gemm_w32_kernel's, on the sums held in registers) — shared by the two wide kernels.  D[i = n][j = m]:
 // register 4q + r of a lane is column 8q + 4hi + r of the tile for row j of the activation tile.
-template <int EPI, bool W8, int NL>
+template <int EPI, int W8, int NL>
 __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int split, int j, int hi, int m_tile, int N, const bf16_t* __restrict__ bias,
                                               void* __restrict__ Yv, int ldy, const bf16_t* __restrict__ R, int ldr, const float* __restrict__ wscale,
-                                              const RopeEpi& re) {
+                                              const RopeEpi& re, const float* __restrict__ xscale = nullptr) {
+  constexpr bool A8 = W8 == 2;  // e4m3 activations: the accumulator also takes the row's activation scale xscale[m] (after the weight scale)
 #pragma unroll
   for (int mt = 0; mt < NL; ++mt) {
     if (j >= m_tile) continue;
@@ -82,6 +87,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
           for (int r = 0; r < 4; ++r) {
             float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
             if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+            if (A8) { x1 *= xscale[m]; x2 *= xscale[m]; }
             if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
             x1 = rdbf(x1);
             x2 = rdbf(x2);
@@ -99,6 +105,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
           for (int r = 0; r < 4; ++r) {
             float x1 = acc[mt][4 * qq + r], x2 = acc[mt][4 * (qq + 2) + r];
             if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+            if (A8) { x1 *= xscale[m]; x2 *= xscale[m]; }
             if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
             o1[r] = rdbf(x1);
             o2[r] = rdbf(x2);
@@ -118,6 +125,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
         for (int r = 0; r < 4; ++r) {
           float y = acc[mt][4 * qq + r], u = acc[mt][4 * (qq + 2) + r];
           if (W8) { y *= wscale[n + r]; u *= wscale[N + n + r]; }
+          if (A8) { y *= xscale[m]; u *= xscale[m]; }
           if (bias) { y += bf2f(bias[n + r]); u += bf2f(bias[N + n + r]); }
           y = rdbf(y);
           u = rdbf(u);
@@ -136,6 +144,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
         for (int r = 0; r < 4; ++r) {
           v[r] = acc[mt][4 * q + r];
           if (W8) v[r] *= wscale[n + r];  // per-output-channel dequantisation scale on the fp32 accumulator
+          if (A8) v[r] *= xscale[m];
         }
         if (EPI == EPI_PARTIAL) {
           float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * WIDE_MPAD + m) * N + n;
@@ -163,12 +172,14 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
 // RB = weight row blocks per workgroup (4 K-quarters each: RB x 4 waves).  4: one byte of X per byte of W.  2: twice the workgroups for
 // GEMMs whose row blocks cannot fill the chip otherwise (a CU sustains ~45-50 GB/s of X + W whatever the lookahead — tools/wide_bench.py —
 // so an idle CU costs more than the doubled X traffic of the busy ones)
-template <int EPI, bool W8, int NL, int DBG = 0, int RB = 4>
+template <int EPI, int W8 /* 0 bf16, 1 e4m3 weights x bf16 activations, 2 e4m3 x e4m3 (X = codes, ldx in 2-byte units, xscale) */, int NL, int DBG = 0, int RB = 4>
 __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                              const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                              const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,
-                                                             const float* __restrict__ wscale, RopeEpi re, int tiles) {
+                                                             const float* __restrict__ wscale, RopeEpi re, int tiles,
+                                                             const float* __restrict__ xscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  constexpr bool A8 = W8 == 2;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rb = wave % RB, kq = wave / RB;  // row block of the workgroup / K-quarter
   const int j = lane & 31, hi = lane >> 5;
@@ -176,10 +187,12 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
   const int tile_raw = blockIdx.x * RB + rb;
   const bool tile_ok = tile_raw < tiles;
   const int tile = tile_ok ? tile_raw : 0;  // a ragged last workgroup streams tile 0 again and stores nothing
-  constexpr int KSTEP = W8 ? 32 : 16;       // k per 1 KiB weight tile
+  constexpr int KSTEP = A8 ? 64 : (W8 ? 32 : 16);  // k per step: one 1 KiB weight tile — A8: one MFMA = 64 k = TWO weight tiles
+  constexpr int TPS = A8 ? 2 : 1;                  // weight tiles per step
+  constexpr int XB = A8 ? 64 : KSTEP * 2;          // bytes of an X row one step covers (a group is 128 bytes of every row in all three forms)
   constexpr int PPW = (4 * NL + RB - 1) / RB;  // 1 KiB activation pieces a wave moves per 64-k group (the quarter's RB waves share 4 NL;
                                                // RB = 3 with NL = 4: 18 slots for 16 pieces, the last piece is fetched three times)
-  constexpr int LOADS = W8 ? 2 : 4;         // weight tiles per 64-k group
+  constexpr int LOADS = W8 ? 2 : 4;         // steps per group
   const int KS = K / KSTEP;
   const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
   const int len = ks_hi - ks_lo;
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     const int gq = (b - a) / LOADS;
     Gmax = max(Gmax, gq + ((gq > 0 && (b - a) % LOADS) ? 1 : 0));
   }
-  const uint4* pa = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * 64 + lane + (size_t)w_lo * 64;
+  const uint4* pa = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * TPS * 64 + lane + (size_t)w_lo * TPS * 64;
   f32x16 acc[NL];
 #pragma unroll
   for (int mt = 0; mt < NL; ++mt)
@@ -220,30 +233,40 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     // 128-byte line the live lanes of that row fetch, so the piece costs the TA / L2 one line less per dead row (T = 30: 2 of 32)
     const int row = 32 * mt + (VISPEC_WIDE_DEADROW_REDIRECT ? min(8 * pc + (lane >> 3), m_tile - 1) : 8 * pc + (lane >> 3)),
               g = (lane & 7) ^ ((4 * pc + (lane >> 4)) & 7);
-    xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;
+    xoff[i] = ((unsigned)row * (unsigned)ldx + (unsigned)g * 8u) * 2u;  // (bytes; A8: ldx is the row pitch in 2-byte units)
     xdst[i] = lds_q + (unsigned)(mt * 4 + pc) * 1024u;
   }
-  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X + (size_t)w_lo * KSTEP);  // + 128 B per group
-  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + ((size_t)tile * KS + w_lo) * 1024;  // + LOADS KiB per group
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X) + (size_t)w_lo * XB;  // + 128 B per group
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + ((size_t)tile * KS + w_lo) * TPS * 1024;  // + LOADS TPS KiB per group
   const unsigned wvo = lane * 16;
   // fragment reads: lane (j, hi) takes k-segment s of row j: bf16 step u -> s = 2u + hi ; fp8 tile c -> s = 4c + 2hi and s + 1
   const unsigned rrow = (unsigned)(j >> 3) * 1024u + (unsigned)(j & 7) * 128u, fsw = (unsigned)(j >> 1) & 7u;
   unsigned ro[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const unsigned sseg = W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi);
+    // A8: step u = t >> 1 reads 16-byte slots 4 u + hi and 4 u + 2 + hi of the row chunk (its two weight tiles' k ranges for this lane)
+    const unsigned sseg = A8 ? (unsigned)(4 * (t >> 1) + 2 * (t & 1) + hi) : (W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi));
     ro[t] = rrow + ((sseg ^ fsw) << 4);
   }
-  u32x4_t w[LOADS];
-  constexpr int QW = DBG == 2 ? 0 : LOADS, QX = DBG == 1 ? 0 : PPW;  // weight loads / activation DMAs in flight per group and wave
+  u32x4_t w[LOADS * TPS];
+  constexpr int QW = DBG == 2 ? 0 : LOADS * TPS, QX = DBG == 1 ? 0 : PPW;  // weight loads / activation DMAs in flight per group and wave
 #define WIDE_DMA(grp, buf)                                                                                      \
   if constexpr (DBG != 1) {                                                                                     \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i)                                                             \
-        wide_dma16(xoff[i], xsrc + (size_t)min((grp) * LOADS, n_steps - LOADS) * (KSTEP * 2), xdst[i] + (buf) * WIDE_BUFBYTES); \
+        wide_dma16(xoff[i], xsrc + (size_t)min((grp) * LOADS, n_steps - LOADS) * XB, xdst[i] + (buf) * WIDE_BUFBYTES); \
   }
   // one k-step (one weight tile register) against the NL staged activation tiles
 #define WIDE_MFMA(u, xb, SK)                                                                                    \
-  if constexpr (!W8) {                                                                                          \
+  if constexpr (A8) {                                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
+      uint4 b0 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u)) & 3]);                         \
+      uint4 b1 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u) + 1) & 3]);                     \
+      if ((u) < (SK)) { b0 = make_uint4(0, 0, 0, 0); b1 = b0; }                                                 \
+      acc[mt] = mfma_f8_64(make_uint4(w[(2 * (u)) % (LOADS * TPS)].x, w[(2 * (u)) % (LOADS * TPS)].y, w[(2 * (u)) % (LOADS * TPS)].z, w[(2 * (u)) % (LOADS * TPS)].w), \
+                           make_uint4(w[(2 * (u) + 1) % (LOADS * TPS)].x, w[(2 * (u) + 1) % (LOADS * TPS)].y, w[(2 * (u) + 1) % (LOADS * TPS)].z, w[(2 * (u) + 1) % (LOADS * TPS)].w), \
+                           b0, b1, acc[mt]);                                                                    \
+    }                                                                                                           \
+  } else if constexpr (!W8) {                                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
       uint4 bv = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[u]);                                     \
       if ((u) < (SK)) bv = make_uint4(0, 0, 0, 0);                                                              \
@@ -260,24 +283,35 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(b1), acc[mt], 0, 0, 0);      \
     }                                                                                                           \
   }
+  // step u: its TPS weight tiles (registers TPS u ..) have landed -> its MFMAs -> the registers are re-issued for the next group.  In flight
+  // before the wait: (LOADS - u) TPS tiles of this group + QX DMAs + u TPS re-issued ones = QW + QX; the oldest TPS must be done.
 #define WIDE_STEP_PREF(u)                                                                                       \
   if constexpr ((u) < LOADS) {                                                                                            \
-    if constexpr (QW > 0) wide_wait_vm<(QW > 0 ? QW - 1 : 0) + QX>(w[(u) < LOADS ? (u) : 0]);                   \
+    if constexpr (QW > 0) {                                                                                     \
+      if constexpr (TPS == 2) wide_wait_vm2<(QW > 0 ? QW - TPS : 0) + QX>(w[(TPS * (u)) % (LOADS * TPS)], w[(TPS * (u) + 1) % (LOADS * TPS)]); \
+      else wide_wait_vm<(QW > 0 ? QW - 1 : 0) + QX>(w[(u) < LOADS ? (u) : 0]);                                  \
+    }                                                                                                           \
     WIDE_MFMA((u) < LOADS ? (u) : 0, xb, 0)                                                                     \
-    if constexpr (QW > 0) wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[(u) < LOADS ? (u) : 0], wvo, wn);       \
+    if constexpr (QW > 0) {                                                                                     \
+      wide_load_w<((TPS * (u)) % (LOADS * TPS)) * 1024>(w[(TPS * (u)) % (LOADS * TPS)], wvo, wn);               \
+      if constexpr (TPS == 2) wide_load_w<((TPS * (u) + 1) % (LOADS * TPS)) * 1024>(w[(TPS * (u) + 1) % (LOADS * TPS)], wvo, wn); \
+    }                                                                                                           \
   }
 #define WIDE_STEP_LAST(u)                                                                                       \
   if constexpr ((u) < LOADS) {                                                                                            \
-    if constexpr (QW > 0) wide_wait_vm<((u) < LOADS ? LOADS - 1 - (u) : 0)>(w[(u) < LOADS ? (u) : 0]);          \
+    if constexpr (QW > 0) {                                                                                     \
+      if constexpr (TPS == 2) wide_wait_vm2<((u) < LOADS ? (LOADS - 1 - (u)) * TPS : 0)>(w[(TPS * (u)) % (LOADS * TPS)], w[(TPS * (u) + 1) % (LOADS * TPS)]); \
+      else wide_wait_vm<((u) < LOADS ? LOADS - 1 - (u) : 0)>(w[(u) < LOADS ? (u) : 0]);                         \
+    }                                                                                                           \
     WIDE_MFMA((u) < LOADS ? (u) : 0, xb, skip)                                                                  \
   }
   if (G > 0) {
     WIDE_DMA(0, 0)
     wide_load_w<0>(w[0], wvo, wsrc);
     wide_load_w<1024>(w[1], wvo, wsrc);
-    if constexpr (LOADS > 2) {
-      wide_load_w<2048>(w[LOADS > 2 ? 2 : 0], wvo, wsrc);
-      wide_load_w<3072>(w[LOADS > 2 ? 3 : 0], wvo, wsrc);
+    if constexpr (LOADS * TPS > 2) {
+      wide_load_w<2048>(w[LOADS * TPS > 2 ? 2 : 0], wvo, wsrc);
+      wide_load_w<3072>(w[LOADS * TPS > 2 ? 3 : 0], wvo, wsrc);
     }
     if constexpr (DBG == 2) wide_wait_vm<QX>(w[0]);  // (the first group's tiles stay in the registers for the whole run)
   }
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
   // number of s_barrier whatever its quarter's group count (the quarters share nothing but the rendezvous itself)
   for (int g = 0; g + 1 < Gq; ++g) {  // group g + 1 is fetched while group g is on the matrix cores
     const unsigned char* xb = xq + (g & 1) * WIDE_BUFBYTES;
-    const unsigned char* wn = wsrc + (size_t)min((g + 1) * LOADS, n_steps - LOADS) * 1024;
+    const unsigned char* wn = wsrc + (size_t)min((g + 1) * LOADS, n_steps - LOADS) * TPS * 1024;
     WIDE_DMA(g + 1, (g + 1) & 1)  // that buffer was last read before the previous barrier
     WIDE_STEP_PREF(0) WIDE_STEP_PREF(1) WIDE_STEP_PREF(2) WIDE_STEP_PREF(3)
     wide_wait_barrier<QW>();
@@ -304,14 +338,16 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
 #undef WIDE_DMA
   if (G == 0) {  // a K range shorter than one group (tiny models): fragment-shaped X loads straight from global
     const uint4* pl = pa;
-    const size_t k0 = (size_t)w_lo * KSTEP + (W8 ? hi * 16 : hi * 8);
+    const size_t k0 = A8 ? (size_t)w_lo * 32 + hi * 8 : (size_t)w_lo * KSTEP + (W8 ? hi * 16 : hi * 8);  // (2-byte units)
     for (int s = 0; s < n_steps; ++s) {
       const uint4 av = *pl;
 #pragma unroll
       for (int mt = 0; mt < NL; ++mt) {
-          const bf16_t* px = X + (size_t)(j < m_tile ? 32 * mt + j : 0) * ldx + k0 + (size_t)s * KSTEP;
+          const bf16_t* px = X + (size_t)(j < m_tile ? 32 * mt + j : 0) * ldx + k0 + (size_t)s * (A8 ? 32 : KSTEP);
           const uint4 bv = *reinterpret_cast<const uint4*>(px);
-          if (!W8) {
+          if (A8) {
+            acc[mt] = mfma_f8_64(av, pl[64], bv, *reinterpret_cast<const uint4*>(px + 16), acc[mt]);
+          } else if (!W8) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[mt], 0, 0, 0);
           } else {
             const uint4 bv1 = *reinterpret_cast<const uint4*>(px + 8);
@@ -321,7 +357,7 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[mt], 0, 0, 0);
           }
         }
-      pl += 64;
+      pl += 64 * TPS;
     }
   }
   // ---- K-quarter reduction through LDS (aliases the staging area): quarters 1..3 publish two activation tiles per pass, the
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     }
   }
   if (kq != 0 || !tile_ok) return;
-  wide_epilogue<EPI, W8, NL>(acc, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re);
+  wide_epilogue<EPI, W8, NL>(acc, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re, xscale);
 }
 
 // =====================================================================================================================================
@@ -380,10 +416,10 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
 //   group g + 1's activations waits vmcnt(LA (LOADS + PPW) - PPW).  The last LA groups fetch stand-ins (the last group again).
 // Needs every quarter of the split to hold at least one whole group (the host falls back to the 4 x 4 kernel otherwise: tiny models).
 #define WIDE8_BUFBYTES (16 * 1024)
-template <bool W8> constexpr int wide8_la() { return W8 ? 4 : 2; }                                   // groups of lookahead (8 KiB of W per wave in flight)
-template <bool W8> constexpr int wide8_lds_bytes() { return (wide8_la<W8>() + 2) * WIDE8_BUFBYTES; }  // ring of LA + 1 buffers + the zero buffer
+template <int W8> constexpr int wide8_la() { return W8 ? 4 : 2; }                                   // groups of lookahead (8 KiB of W per wave in flight)
+template <int W8> constexpr int wide8_lds_bytes() { return (wide8_la<W8>() + 2) * WIDE8_BUFBYTES; }  // ring of LA + 1 buffers + the zero buffer
 
-template <int EPI, bool W8, int NL>
+template <int EPI, int W8, int NL>
 __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                              const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                              const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,

@@ -191,6 +191,54 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #endif
 }
 
+// ---- fp8 ACTIVATIONS (round 4, W8A8: BASELINE config 5 "CDNA4 fp8 MFMA"): the target's four per-layer GEMMs can take their activations in
+// e4m3 as well, one dynamic scale per row (token): x ~ sx[m] * q[m, k].  The GEMM then runs on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the
+// bf16 rate, 64 k per instruction = two 1 KiB weight tiles) with unit block scales, and the epilogue multiplies the fp32 accumulator by
+// wscale[n] * sx[m].  A different arithmetic from W8A16 (tests/test_fp8_activation_study.py prices it): its own oracle mode, its own tests.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f8_64(uint4 a0, uint4 a1, uint4 b0, uint4 b1, f32x16 c) {
+  v8i_t a, b;
+  a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+  b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+  // cbsz = blgp = 0: both operands OCP e4m3; scale exponents 127 = 2^0.  Lane l supplies 32 bytes of row / column l & 31; WHICH 32 of the
+  // 64 k they are does not matter as long as A and B agree (a dot product is order-free over k up to fp32 accumulation inside the
+  // instruction, and every kernel of the library feeds it the same way): here bytes [16 hi, +16) and [32 + 16 hi, +16) of the 64.
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+}
+// One workgroup per row: sx[m] = max(|x[m, :]|, 1e-12) / 448, q[m, k] = e4m3_rne(x[m, k] / sx[m])   (oracle: Ops.linear(..., a8=True))
+__global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16_t* __restrict__ X, int ldx, unsigned char* __restrict__ Q, int ldq,
+                                                              float* __restrict__ sx, int K) {
+  __shared__ float s_m[4];
+  const int m = blockIdx.x;
+  const bf16_t* x = X + (size_t)m * ldx;
+  float amax = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + k);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(bf2f(e[i])));
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  const float scale = __fdiv_rn(fmaxf(amax, 1e-12f), 448.0f);
+  if (threadIdx.x == 0) sx[m] = scale;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + k);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = __fdiv_rn(bf2f(e[i]), scale);
+    int lo = 0, hi2 = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi2, false);
+    hi2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi2, true);
+    *reinterpret_cast<uint2*>(Q + (size_t)m * ldq + k) = make_uint2((unsigned)lo, (unsigned)hi2);
+  }
+}
+
 // bytes of LDS one staged X group takes: UNROLL k-step images of 1 KiB, padded so that both the staging writes
 // (8 lanes = one 128-B row segment -> 8 different 16-B bank groups) and the fragment reads are conflict-free
 #define XS_STEP 1056
@@ -229,11 +277,14 @@ constexpr int gemm_w32_lds_bytes() {
 // at row 32 t + i of X / Y / R (the cohort members' tile-aliased workspaces, unchanged).  The weight pass then costs what a single request's
 // costs — one 32-row activation block per workgroup instead of the 128 rows of the wide form — and a row is the same dot products in the
 // same order as in the single-request launch (split-K partials are indexed by the tile row m).
-template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, bool W8 = false, int MT = 1, bool SLAB = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
+template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, int W8 = 0 /* 0 bf16 weights, 1 e4m3 weights x bf16 activations, 2 e4m3 x e4m3 */, int MT = 1, bool SLAB = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
 __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES : 2) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
-                                                           int S, const float* __restrict__ wscale, RopeEpi re, int m_tile) {
+                                                           int S, const float* __restrict__ wscale, RopeEpi re, int m_tile,
+                                                           const float* __restrict__ xscale = nullptr) {
+  // W8 == 2 (A8): X holds e4m3 codes (pointer and ldx in 2-BYTE units, i.e. ldx = row bytes / 2), xscale[row of X] their per-row scales
+  constexpr bool A8 = W8 == 2;
   // m_tile > 0 ("cohort"): the MT activation tiles belong to different requests, rows 32 mt .. 32 mt + m_tile - 1 of each are valid
   // (instead of the contiguous rows 0 .. M-1); the weights are still streamed once for all of them
   static_assert(!SLAB || MT == 1, "slab mode packs the requests into one activation tile");
@@ -244,15 +295,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
   const int j = lane & 31, hi = lane >> 5;
   const int tile = blockIdx.x, split = blockIdx.y;
-  // a "step" is one 1 KiB weight tile: 16 k in bf16, 32 k in fp8 (two MFMAs); a group is 64 k either way
-  constexpr int KSTEP = W8 ? 32 : 16;
-  constexpr int LOADS = W8 ? UNROLL / 2 : UNROLL;  // weight loads per group
+  // a "step" is one 1 KiB weight tile: 16 k in bf16, 32 k in fp8 (two MFMAs); a group is 64 k either way.  A8: a step is one MFMA = 64 k =
+  // TWO weight tiles, a group 128 k (the same 128 bytes of X per row)
+  constexpr int KSTEP = A8 ? 64 : (W8 ? 32 : 16);
+  constexpr int TPS = A8 ? 2 : 1;                  // weight tiles per step
+  constexpr int LOADS = W8 ? UNROLL / 2 : UNROLL;  // steps per group
+  constexpr int XU = A8 ? 32 : KSTEP;              // 2-byte units of an X row one step covers
   const int KS = K / KSTEP;
   const int ks_lo = (int)((long)KS * split / S), ks_hi = (int)((long)KS * (split + 1) / S);
   const int len = ks_hi - ks_lo;
   const int w_lo = ks_lo + (int)((long)len * wave / NW), w_hi = ks_lo + (int)((long)len * (wave + 1) / NW);
-  const uint4* pa0 = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * 64 + lane + (size_t)w_lo * 64;
-  const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P) + (size_t)(tile + tile2_off) * KS * 64 + lane + (size_t)w_lo * 64 : pa0;
+  const uint4* pa0 = reinterpret_cast<const uint4*>(P) + (size_t)tile * KS * TPS * 64 + lane + (size_t)w_lo * TPS * 64;
+  const uint4* pa1 = (NT == 2) ? reinterpret_cast<const uint4*>(P) + (size_t)(tile + tile2_off) * KS * TPS * 64 + lane + (size_t)w_lo * TPS * 64 : pa0;
   f32x16 acc[NT][MT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -270,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   constexpr int XBUFS = gemm_w32_xbufs<MT, NT>();  // same-wave LDS traffic is processed in issue order: one buffer is enough for correctness
   unsigned char* xs = smem_g + wave * (MT * XBUFS * XTILE);
   // one running base pointer + 32-bit per-row element offsets (8 address registers less than a pointer per row at MT = 2)
-  const bf16_t* xbase = X + (size_t)w_lo * KSTEP + seg * 8;
+  const bf16_t* xbase = X + (size_t)w_lo * XU + seg * 8;
   unsigned xo[MT][NINST];
   int woff[NINST];
 #pragma unroll
@@ -284,7 +338,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   const int roff = hi * XS_HALF + j * 16;
 
   struct Regs {
-    uint4 a[NT][LOADS];
+    uint4 a[NT][LOADS * TPS];
     uint4 x[MT][NINST];
   };
   auto load = [&](Regs& g) {  // all loads unconditional plain global loads; X first (it is consumed first, through LDS)
@@ -295,12 +349,12 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
         for (int i = 0; i < NINST; ++i) g.x[mt][i] = *reinterpret_cast<const uint4*>(xbase + xo[mt][i]);
     }
 #pragma unroll
-    for (int u = 0; u < LOADS; ++u) {
+    for (int u = 0; u < LOADS * TPS; ++u) {
       g.a[0][u] = ld_weight(pa0 + u * 64);
       if (NT == 2) g.a[NT - 1][u] = ld_weight(pa1 + u * 64);
     }
-    pa0 += 64 * LOADS;
-    pa1 += 64 * LOADS;
+    pa0 += 64 * LOADS * TPS;
+    pa1 += 64 * LOADS * TPS;
     xbase += 16 * UNROLL;
   };
   auto compute = [&](const Regs& g, int buf) {
@@ -322,6 +376,20 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(g.a[t][u]), as_bf16x8(bv), acc[t][mt], 0, 0, 0);
+        }
+      }
+    } else if (A8) {
+      // step sp = weight tiles 2 sp, 2 sp + 1: this lane's bytes are k = 64 sp + 16 hi + [0, 16) and + 32 — 16-byte slots 4 sp + hi and
+      // 4 sp + 2 + hi of the staged 128-byte row chunk, i.e. staged images (2 sp, half hi) and (2 sp + 1, half hi)
+#pragma unroll
+      for (int sp = 0; sp < LOADS; ++sp) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned char* xs0 = xb + mt * XTILE + (2 * sp) * XS_STEP + hi * XS_HALF + j * 16;
+          const uint4 b0 = *reinterpret_cast<const uint4*>(xs0);
+          const uint4 b1 = *reinterpret_cast<const uint4*>(xs0 + XS_STEP);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma_f8_64(g.a[t][(2 * sp) % (LOADS * TPS)], g.a[t][(2 * sp + 1) % (LOADS * TPS)], b0, b1, acc[t][mt]);
         }
       }
     } else {
@@ -374,14 +442,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     const bf16_t* px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      px[mt] = X + (size_t)(row_ok(32 * mt + j) ? grow(32 * mt + j) : 0) * ldx + (W8 ? hi * 16 : hi * 8) + (size_t)(w_lo + n_groups * LOADS) * KSTEP;
+      px[mt] = X + (size_t)(row_ok(32 * mt + j) ? grow(32 * mt + j) : 0) * ldx + (A8 ? hi * 8 : (W8 ? hi * 16 : hi * 8)) + (size_t)(w_lo + n_groups * LOADS) * XU;
     for (int rstep = n_groups * LOADS; rstep < n_steps; ++rstep) {
       const uint4 av = pa0[0];
       const uint4 av1 = pa1[0];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const uint4 bv = *reinterpret_cast<const uint4*>(px[mt]);
-        if (!W8) {
+        if (A8) {  // the step's second weight tile / second 16 bytes of the row (+ 32 bytes = 16 units)
+          const uint4 bw = *reinterpret_cast<const uint4*>(px[mt] + 16);
+          acc[0][mt] = mfma_f8_64(av, pa0[64], bv, bw, acc[0][mt]);
+          if (NT == 2) acc[NT - 1][mt] = mfma_f8_64(av1, pa1[64], bv, bw, acc[NT - 1][mt]);
+        } else if (!W8) {
           acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(bv), acc[0][mt], 0, 0, 0);
           if (NT == 2) acc[NT - 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av1), as_bf16x8(bv), acc[NT - 1][mt], 0, 0, 0);
         } else {
@@ -396,10 +468,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
             acc[NT - 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a_hi), as_bf16x8(bv1), acc[NT - 1][mt], 0, 0, 0);
           }
         }
-        px[mt] += KSTEP;
+        px[mt] += XU;
       }
-      pa0 += 64;
-      pa1 += 64;
+      pa0 += 64 * TPS;
+      pa1 += 64 * TPS;
     }
   }
   if (DBG == 2) {
@@ -464,6 +536,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
           for (int r = 0; r < 4; ++r) {
             float x1 = a[r], x2 = b[r];
             if (W8) { x1 *= wscale[c1 + r]; x2 *= wscale[c2 + r]; }
+            if (A8) { x1 *= xscale[grow(m)]; x2 *= xscale[grow(m)]; }
             if (bias) { x1 += bf2f(bias[c1 + r]); x2 += bf2f(bias[c2 + r]); }
             x1 = rdbf(x1);
             x2 = rdbf(x2);
@@ -481,6 +554,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
           for (int r = 0; r < 4; ++r) {
             float x1 = a[r], x2 = b[r];
             if (W8) { x1 *= wscale[ncol + r]; x2 *= wscale[ncol + 16 + r]; }
+            if (A8) { x1 *= xscale[grow(m)]; x2 *= xscale[grow(m)]; }
             if (bias) { x1 += bf2f(bias[ncol + r]); x2 += bf2f(bias[ncol + 16 + r]); }
             o1[r] = rdbf(x1);
             o2[r] = rdbf(x2);
@@ -519,6 +593,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
         for (int r = 0; r < 4; ++r) {
           float y = a[r], u = b[r];
           if (W8) { y *= wscale[n + r]; u *= wscale[N + n + r]; }
+          if (A8) { y *= xscale[grow(m)]; u *= xscale[grow(m)]; }
           if (bias) { y += bf2f(bias[n + r]); u += bf2f(bias[N + n + r]); }
           y = rdbf(y);
           u = rdbf(u);
@@ -547,6 +622,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     if (W8 && n < N) {  // per-output-channel dequantisation scale on the fp32 accumulator
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= wscale[n + r];
+    }
+    if (A8 && row_ok(m)) {  // ... then the row's activation scale
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= xscale[grow(m)];
     }
     if (row_ok(m) && n < N) {
       if (EPI == EPI_PARTIAL) {

@@ -103,6 +103,9 @@ struct vispec_ctx {
     }
   };
   GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft, g_car;
+  bool a8 = false;               // fp8 ACTIVATIONS for the target's four per-layer GEMMs (needs fp8 weights): vispec_set_fp8_activations
+  unsigned char* xq = nullptr;   // [128 rows][max(D, H * 128, I)] e4m3 codes of the GEMM input at hand (stream-ordered scratch)
+  float* sx = nullptr;           // [128] their per-row scales
   float* u_over = nullptr;  // tests only: uniforms of the sampling accept taken from here (vispec_set_uniform_override_host)
   bool u_over_on = false;
   bool zombie = false;  // a leader destroyed while members were alive: its workspaces (which the members alias) are freed with the last member
@@ -180,6 +183,12 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   AL(xa, D); AL(xn, D); AL(qkv, QKV); AL(attn_o, (size_t)c.num_heads * c.head_dim);
   AL(act, I); AL(hidden_new, D); AL(logits, V);
   AL(am, 1); A(sel, 16); A(draft_ids, 16); A(accept_hidden, 16 * D); A(u_over, TREE_MAX_T * TREE_RET_W + 1);
+  if (!leader) {
+    const size_t kmax = (size_t)std::max(std::max((int)c.hidden_size, (int)(c.num_heads * c.head_dim)), (int)c.intermediate_size);
+    A(xq, (size_t)ROWS * kmax); A(sx, ROWS);
+  } else {
+    ctx->xq = leader->xq; ctx->sx = leader->sx;  // (a member's own GEMMs are stream-ordered with its leader's, like gemm_part: one scratch)
+  }
   AL(dx1, 2 * D); AL(dx2, 2 * D); AL(dx, D); AL(dqkv, 3 * D); AL(dattn, D);
   AL(dh, D); AL(dn, D); AL(dact, Id); AL(dout, D); AL(dlast, D);
   AL(dlogits, V); A(dg, D);
@@ -443,6 +452,7 @@ static int choose_split(int tiles, int KS, double tile_bytes, bool reduce_is_fre
 //   Y (bf16, ld ldy) may be null when only the normed output is wanted.  M <= 32.
 struct GemmOut {
   const float* wscale = nullptr;  // non-null: P is an fp8 (e4m3) W32 image with per-output-channel scales (W8A16)
+  const float* xscale = nullptr;  // non-null (with wscale): X holds e4m3 CODES (ldx = row pitch in 2-byte units) with these per-row scales (W8A8)
   void* Y = nullptr; int ldy = 0;
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
@@ -460,15 +470,16 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
-  const int tiles = (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
+  if (o.xscale && (!o.wscale || K % 64)) return fail("gemm_skinny: fp8 activations need fp8 weights and K %% 64 == 0");
+  const int tiles = (N + 31) / 32, KS = K / (o.xscale ? 64 : (o.wscale ? 32 : 16));
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
   do {                                                                                                                                    \
     if (MT == 1 && o.m_tile < 0)                                                                                                          \
       PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT, (MT == 1)>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
-              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile);                                            \
+              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile, o.xscale);                                  \
     else                                                                                                                                  \
       PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w,       \
-              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile);                                            \
+              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile, o.xscale);                                  \
   } while (0)
   // Two activation tiles: a workgroup takes TWO row blocks (tile, tile + tiles/2) and feeds both from each staged activation
   // fragment (NT = 2) — the activation re-read from L2 is what the second tile costs (kernels.h), and with several lanes in flight
@@ -488,8 +499,9 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
     if (N % 16) return fail("gemm_skinny: SwiGLU needs N %% 16 == 0");
     if (o.norm_w) return fail("gemm_skinny: no fused norm after SwiGLU");
     prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
-    if (o.wscale) VISPEC_GEMM_NT(EPI_SWIGLU, true, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else VISPEC_GEMM_NT(EPI_SWIGLU, false, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    if (o.xscale) VISPEC_GEMM_NT(EPI_SWIGLU, 2, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (o.wscale) VISPEC_GEMM_NT(EPI_SWIGLU, 1, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM_NT(EPI_SWIGLU, 0, N / 16, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
@@ -505,10 +517,12 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (force_split > 0) S = force_split;
   if (S == 1 && !o.norm_w) {
     prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
-    if (epi == EPI_RESIDUAL && o.wscale) VISPEC_GEMM_NT(EPI_RESIDUAL, true, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else if (epi == EPI_RESIDUAL) VISPEC_GEMM_NT(EPI_RESIDUAL, false, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
-    else if (o.wscale) VISPEC_GEMM_NT(EPI_NONE, true, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
-    else VISPEC_GEMM_NT(EPI_NONE, false, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    if (epi == EPI_RESIDUAL && o.xscale) VISPEC_GEMM_NT(EPI_RESIDUAL, 2, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (epi == EPI_RESIDUAL && o.wscale) VISPEC_GEMM_NT(EPI_RESIDUAL, 1, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (epi == EPI_RESIDUAL) VISPEC_GEMM_NT(EPI_RESIDUAL, 0, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
+    else if (o.xscale) VISPEC_GEMM_NT(EPI_NONE, 2, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else if (o.wscale) VISPEC_GEMM_NT(EPI_NONE, 1, tiles, b, o.Y, o.ldy, r, o.ldr, 1, o.wscale);
+    else VISPEC_GEMM_NT(EPI_NONE, 0, tiles, b, o.Y, o.ldy, r, o.ldr, 1, nullptr);
     KCHK();
     prof_end(s);
     return 0;
@@ -516,8 +530,9 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (!ctx) return fail("gemm_skinny: split-K needs a ctx (partial workspace)");
   if ((size_t)S * 32 * MT * N > ctx->gemm_part_elems) return fail("gemm_skinny: partial workspace too small");
   prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
-  if (o.wscale) VISPEC_GEMM_NT(EPI_PARTIAL, true, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
-  else VISPEC_GEMM_NT(EPI_PARTIAL, false, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, nullptr);
+  if (o.xscale) VISPEC_GEMM_NT(EPI_PARTIAL, 2, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
+  else if (o.wscale) VISPEC_GEMM_NT(EPI_PARTIAL, 1, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, o.wscale);
+  else VISPEC_GEMM_NT(EPI_PARTIAL, 0, tiles, nullptr, ctx->gemm_part, 0, nullptr, 0, S, nullptr);
 #undef VISPEC_GEMM_NT
 #undef VISPEC_GEMM
   KCHK();
@@ -554,7 +569,8 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_wide: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_wide: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
-  const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.wscale ? 32 : 16);
+  if (o.xscale && (!o.wscale || K % 64)) return fail("gemm_wide: fp8 activations need fp8 weights and K %% 64 == 0");
+  const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.xscale ? 64 : (o.wscale ? 32 : 16));
   const int M = 32 * (n_req - 1) + o.m_tile;
   // Row blocks per workgroup (vispec_set_wide_row_blocks): four = one byte of X per byte of W, the form for a GPU that several lanes
   // keep full; two = twice the workgroups at twice the X traffic, which pays on a single stream where four row blocks leave half
@@ -566,7 +582,7 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   static const int w8_tiles_max = getenv("VISPEC_WIDE8_TILES_MAX") ? atoi(getenv("VISPEC_WIDE8_TILES_MAX")) : 1 << 30;
 #define WIDE_LRB(EPI_, W8_, NL_, RB_, YPTR, LDY, SPLITS)                                                                                 \
   PLAUNCH((gemm_w32_wide_kernel<EPI_, W8_, NL_, 0, RB_>), dim3((tiles + RB_ - 1) / RB_, SPLITS), dim3(RB_ * 256), WIDE_LDS_BYTES, s, x, ldx, w, \
-          b, YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles)
+          b, YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles, o.xscale)
 #define WIDE_L(EPI_, W8_, NL_, YPTR, LDY, SPLITS)                                                                                       \
   do {                                                                                                                                  \
     int rb_ = rb_opt;                                                                                                                   \
@@ -575,21 +591,24 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
        four for fp8 weights (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte on two waves per SIMD,  \
        29 GB/s per CU instead of the 54 of the bf16 one) — profiles/README.md, round 4 */                                                  \
     if (rb_ == 84) rb_ = (W8_) ? 4 : 8;                                                                                                   \
-    if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
+    if ((W8_) == 2) rb_ = 4;  /* fp8 activations: the four-row-block kernel only */                                                        \
+    if ((W8_) != 2 && rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
       PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
               YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
       break;                                                                                                                            \
     }                                                                                                                                   \
     if (rb_ == 8) rb_ = 4;                                                                                                              \
     if (rb_ == 0) rb_ = ((tiles + 1) / 2) * (SPLITS) <= 256 ? 2 : (((tiles + 2) / 3) * (SPLITS) <= 256 ? 3 : 4);  /* most workgroups in one round of CUs */ \
-    if (rb_ == 2) WIDE_LRB(EPI_, W8_, NL_, 2, YPTR, LDY, SPLITS);                                                                       \
+    if constexpr ((W8_) == 2) WIDE_LRB(EPI_, W8_, NL_, 4, YPTR, LDY, SPLITS);                                                           \
+    else if (rb_ == 2) WIDE_LRB(EPI_, W8_, NL_, 2, YPTR, LDY, SPLITS);                                                                  \
     else if (rb_ == 3) WIDE_LRB(EPI_, W8_, NL_, 3, YPTR, LDY, SPLITS);                                                                  \
     else WIDE_LRB(EPI_, W8_, NL_, 4, YPTR, LDY, SPLITS);                                                                                \
   } while (0)
 #define WIDE_D(EPI_, YPTR, LDY, SPLITS)                                                                       \
   do {                                                                                                        \
-    if (o.wscale) { if (n_req == 3) WIDE_L(EPI_, true, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, true, 4, YPTR, LDY, SPLITS); }     \
-    else { if (n_req == 3) WIDE_L(EPI_, false, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, false, 4, YPTR, LDY, SPLITS); }            \
+    if (o.xscale) { if (n_req == 3) WIDE_L(EPI_, 2, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, 2, 4, YPTR, LDY, SPLITS); }           \
+    else if (o.wscale) { if (n_req == 3) WIDE_L(EPI_, 1, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, 1, 4, YPTR, LDY, SPLITS); }      \
+    else { if (n_req == 3) WIDE_L(EPI_, 0, 3, YPTR, LDY, SPLITS); else WIDE_L(EPI_, 0, 4, YPTR, LDY, SPLITS); }                    \
   } while (0)
   if (epi == EPI_ROPE) {
     if (!re) return fail("gemm_wide: rope epilogue without its arguments");
@@ -744,12 +763,14 @@ struct QkvReq {  // per-request part of a q|k|v projection: positions and the ca
 // streamed once for all of them.
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, const QkvReq* rq, int n_req,
-                           int s_max, bool slab = false) {
+                           int s_max, bool slab = false, const float* xscale = nullptr /* X = e4m3 codes, ldx in 2-byte units */) {
   const int N = (H + 2 * H_kv) * 128;
   slab = slab && n_req >= 2 && M <= 8;  // slab: the requests' rows packed into one activation tile (request t still at rows 32t .. of X / qkv)
   const int m_tile = slab ? -M : (n_req >= 2 ? M : 0), Mk = slab ? 8 * (n_req - 1) + M : (n_req >= 2 ? 32 * (n_req - 1) + M : M);
   if (!qkv_rope_fused(N)) {
-    if (launch_gemm(ctx, s, X, ldx, P, bias, qkv, N, nullptr, 0, Mk, N, K, EPI_NONE, wscale, m_tile)) return -1;
+    GemmOut o0;
+    o0.wscale = (const float*)wscale; o0.xscale = xscale; o0.m_tile = m_tile; o0.Y = qkv; o0.ldy = N;
+    if (launch_gemm_ex(ctx, s, X, ldx, P, bias, Mk, N, K, EPI_NONE, o0)) return -1;
     for (int t = 0; t < n_req; ++t)
       if (launch_rope(s, (bf16_t*)qkv + (size_t)32 * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
     return 0;
@@ -762,21 +783,24 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
   if (n_req > 2 && !slab) {  // three or four requests: the wide-cohort kernel
     GemmOut o;
-    o.wscale = (const float*)wscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
+    o.wscale = (const float*)wscale; o.xscale = xscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
     return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, EPI_ROPE, o, -1, &re);
   }
   prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
 #define VISPEC_QKV(W8_, MT_, NT_)                                                                                                         \
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, MT_>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT_>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
-                     (const float*)wscale, re, m_tile)
+                     (const float*)wscale, re, m_tile, xscale)
+  if (xscale && (slab || K % 64)) return fail("gemm_qkv_rope: fp8 activations: no slab form, K %% 64 == 0");
   if (slab) {
 #define VISPEC_QKV_SLAB(W8_, NT_)                                                                                                          \
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, 1, true>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, 1>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
-                     (const float*)wscale, re, m_tile)
+                     (const float*)wscale, re, m_tile, (const float*)nullptr)
     if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV_SLAB(true, 2); else if (wscale) VISPEC_QKV_SLAB(true, 1); else VISPEC_QKV_SLAB(false, 1);
 #undef VISPEC_QKV_SLAB
+  } else if (xscale) {  // e4m3 activations: the paired form (two row blocks per workgroup), one or two activation tiles
+    if (Mk <= 32) VISPEC_QKV(2, 1, 2); else VISPEC_QKV(2, 2, 2);
   } else if (Mk <= 32) { if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV(true, 1, 2); else if (wscale) VISPEC_QKV(true, 1, 1); else VISPEC_QKV(false, 1, 1); }
   else if (g_mt2_single_block || (wscale && !VISPEC_W8_PAIR)) { if (wscale) VISPEC_QKV(true, 2, 1); else VISPEC_QKV(false, 2, 1); }
   else { if (wscale) VISPEC_QKV(true, 2, 2); else VISPEC_QKV(false, 2, 2); }  // N %% 128 == 0: the tile count is even
@@ -997,6 +1021,25 @@ extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, 
     return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 8 * (n_req - 1) - m_tile, N, K, epilogue, wscale, m_tile);
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 32 * (n_req - 1) + m_tile, N, K, epilogue, wscale, m_tile);
 }
+// The W8A8 GEMM at unit level (tests): X is bf16 — it is quantised here exactly as target_forward does (quant_rows_e4m3_kernel into the ctx's
+// scratch) — then multiplied by the e4m3 weight image on the fp8 MFMA.  n_req = 1: rows 0 .. M-1 (M <= 64); n_req = 2..4: the cohort layout of
+// vispec_gemm_cohort (request t at rows 32 t .., m_tile live rows each; M ignored).  epilogue 0 none / 1 +R / 2 SwiGLU; norm_w != NULL adds the
+// fused RMSNorm of the split-K reduce (the o_proj / down_proj form).
+extern "C" int vispec_gemm_fp8a8(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P8, const void* wscale, const void* bias, void* Y, int ldy,
+                                 const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps) {
+  if (!ctx || !wscale || epilogue < 0 || epilogue > 2 || K % 64 || ldx != K) return fail("gemm_fp8a8: needs a ctx, weight scales, K %% 64 == 0 and a dense X (ldx == K)");
+  if (n_req < 1 || n_req > 4 || (n_req > 1 && (m_tile < 1 || m_tile > 32)) || (n_req == 1 && (M < 1 || M > 64))) return fail("gemm_fp8a8: bad row layout");
+  const size_t kmax = (size_t)std::max(std::max((int)ctx->c.hidden_size, (int)(ctx->c.num_heads * ctx->c.head_dim)), (int)ctx->c.intermediate_size);
+  if ((size_t)K > kmax) return fail("gemm_fp8a8: K exceeds the ctx's quantisation scratch (max of hidden, heads x head_dim, intermediate size)");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = n_req == 1 ? M : 32 * (n_req - 1) + m_tile;
+  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)X, ldx, ctx->xq, K, ctx->sx, K);
+  KCHK();
+  GemmOut o;
+  o.wscale = (const float*)wscale; o.xscale = ctx->sx; o.m_tile = n_req == 1 ? 0 : m_tile;
+  o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr; o.norm_w = norm_w; o.normed = normed; o.ldn = N; o.eps = eps;
+  return launch_gemm_ex(ctx, s, ctx->xq, K / 2, P8, bias, rows, N, K, epilogue, o);
+}
 // skinny GEMM (+bias, +residual R) with the following RMSNorm fused: Y = bf16(R + bf16(X·W^T + b)), normed = norm_w * rms(Y)
 extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
                                        int ldy, const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M,
@@ -1026,7 +1069,7 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (S < 1 || S > 16 || !ctx || (size_t)S * 32 * N > ctx->gemm_part_elems) return fail("tune: bad split");
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
-                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr)
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
     if (M > 96 && unc == 5) {  // 9xxx5: EIGHT row blocks per workgroup, K walked quarter by quarter (gemm_w32_wide8_kernel)
@@ -1035,29 +1078,29 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
                          ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
     } else if (M > 96 && unc == 4)  // 9xxx4: three row blocks per workgroup
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 3>), dim3((tiles + 2) / 3, S), dim3(768), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     else if (M > 96 && unc == 3)  // 9xxx3: two row blocks per workgroup (twice the workgroups, twice the X traffic per weight byte)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 0, 2>), dim3((tiles + 1) / 2, S), dim3(512), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     else if (M > 96 && unc == 1)  // 9xxx1 / 9xxx2: the same without activation DMAs / without weight loads (wrong results; what each stream costs)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     else if (M > 96 && unc == 2)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     else if (M > 96)
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 4>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     else
       hipLaunchKernelGGL((gemm_w32_wide_kernel<EPI_PARTIAL, false, 3>), dim3((tiles + 3) / 4, S), dim3(1024), WIDE_LDS_BYTES, s, x, ldx, w, nullptr,
-                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles);
+                         ctx->gemm_part, 0, nullptr, 0, 30, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
     KCHK();
     return 0;
   }
   if (M > 64) {  // 8xxxx: FOUR activation tiles, one row block per workgroup (what a cohort of four would run) — measurement only
     if (dbg != 7 || M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: M > 64 needs variant 8xxxx, M <= 128 and a partial workspace of S*128*N");
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 0, false, 4>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     KCHK();
     return 0;
   }
@@ -1065,14 +1108,14 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
     if (M > 64 || (size_t)S * 64 * N > ctx->gemm_part_elems) return fail("tune: bad M / split for two tiles");
 #define V2(DBG_)                                                                                                                   \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, DBG_, false, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4, 2>()), s, x, \
-                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0)
+                     ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr)
     if (dbg == 5) {  // 6xxxx: the paired form with only HALF of the activations loaded (wrong results; what halving that traffic again would buy)
       hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 3, false, 2>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s, x,
-                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     } else if (dbg == 4) {  // 5xxxx: two row blocks per workgroup (NT = 2) sharing every staged activation group: half the L2 -> CU activation traffic
       if (tiles & 1) return fail("tune: NT=2 needs an even tile count");
       hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 0, false, 2>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s, x,
-                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                         ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     } else if (dbg == 1) V2(1); else if (dbg == 2) V2(2); else V2(0);
 #undef V2
     KCHK();
@@ -1081,19 +1124,19 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
   if (dbg == 4) {  // 5xxxx at M <= 32: two row blocks per workgroup, one activation tile
     if (tiles & 1) return fail("tune: NT=2 needs an even tile count");
     hipLaunchKernelGGL((gemm_w32_kernel<2, EPI_PARTIAL, 4, 4, 0, false, 1>), dim3(tiles / 2, S), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 1>()), s, x,
-                       ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                       ldx, w, tiles / 2, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     KCHK();
     return 0;
   }
   if (dbg == 1) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 1>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     KCHK();
     return 0;
   }
   if (dbg == 2) {
     hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, 4, 4, 2>), dim3(tiles, S), dim3(256), (gemm_w32_lds_bytes<1, 4, 4>()), s, x, ldx, w, 0,
-                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0);
+                       nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr);
     KCHK();
     return 0;
   }
@@ -1301,6 +1344,16 @@ extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   if (row_blocks != 0 && row_blocks != 8 && row_blocks != 84 && (row_blocks < 2 || row_blocks > 4))
     return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 for bf16 weights, 4 for fp8: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
+  return 0;
+}
+// fp8 (e4m3) ACTIVATIONS for the target's four per-layer GEMMs of the verify / AR forwards (BASELINE config 5, "CDNA4 fp8 MFMA"): each GEMM
+// input is quantised per row (dynamic scale) and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4.  Needs fp8 target weights; the lm_head,
+// the draft and the PyTorch prefill keep bf16 activations.  Set it on every ctx of a cohort.  (Cached graphs are dropped.)
+extern "C" int vispec_set_fp8_activations(vispec_ctx* ctx, int on) {
+  if (!ctx) return fail("null ctx");
+  if (on && (ctx->c.hidden_size % 64 || ctx->c.intermediate_size % 64)) return fail("fp8 activations need hidden and intermediate sizes that are multiples of 64");
+  ctx->a8 = on != 0;
+  for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
   return 0;
 }
 extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
@@ -1734,7 +1787,20 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       rq[t].kc = co.c[t]->target_kv + (size_t)(2 * l) * slab;
       rq[t].vc = co.c[t]->target_kv + (size_t)(2 * l + 1) * slab;
     }
-    if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
+    // fp8 activations (vispec_set_fp8_activations, fp8 weights only): each of the layer's four GEMM inputs is quantised row by row to e4m3
+    // (quant_rows_e4m3_kernel) and multiplied on the fp8 MFMA; X then points at the codes (pitch in 2-byte units) and `xscale` at the row scales
+    const bool a8 = ctx->a8 && w.sqkv != nullptr;
+    const int MR = co.M(T);  // activation rows of the launch (a cohort: 32 (n - 1) + T, dead rows included)
+    auto quant = [&](const bf16_t* X, int K_) {
+      hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3(MR), dim3(256), 0, s, X, K_, ctx->xq, K_, ctx->sx, K_);
+      return hipGetLastError() == hipSuccess ? 0 : fail("quant_rows launch failed");
+    };
+    if (a8) {
+      if (quant(ctx->xn, D)) return -1;
+      if (launch_qkv_rope(ctx, s, ctx->xq, D / 2, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos, false,
+                          ctx->sx))
+        return -1;
+    } else if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
       return -1;
     {
       AttnCall calls[4];
@@ -1751,9 +1817,18 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.norm_w = w.ln2; o.normed = ctx->xn; o.ldn = D; o.eps = c.rms_eps;
       o.wscale = (const float*)w.so;
       o.m_tile = co.mt(T);
-      if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
+      if (a8) {
+        if (quant(ctx->attn_o, H * 128)) return -1;
+        o.xscale = ctx->sx;
+        if (launch_gemm_ex(ctx, s, ctx->xq, H * 128 / 2, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
+      } else if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
     }
-    if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, co.M(T), I, D, EPI_SWIGLU, w.sgu, co.mt(T))) return -1;
+    if (a8) {
+      GemmOut o;
+      o.wscale = (const float*)w.sgu; o.xscale = ctx->sx; o.m_tile = co.mt(T); o.Y = ctx->act; o.ldy = I;
+      if (quant(ctx->xn, D)) return -1;
+      if (launch_gemm_ex(ctx, s, ctx->xq, D / 2, w.wgu, nullptr, co.M(T), I, D, EPI_SWIGLU, o)) return -1;
+    } else if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, co.M(T), I, D, EPI_SWIGLU, w.sgu, co.mt(T))) return -1;
     {
       GemmOut o;  // x += down(act) ; then the NEXT layer's input_layernorm, or the final model.norm (hidden_states[-1] is post-norm)
       const bool last = l + 1 == c.num_layers;
@@ -1762,7 +1837,11 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       o.normed = last ? ctx->hidden_new : ctx->xn;
       o.wscale = (const float*)w.sdown;
       o.m_tile = co.mt(T);
-      if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
+      if (a8) {
+        if (quant(ctx->act, I)) return -1;
+        o.xscale = ctx->sx;
+        if (launch_gemm_ex(ctx, s, ctx->xq, I / 2, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
+      } else if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
     }
   }
   if (launch_gemm(ctx, s, ctx->hidden_new, D, ctx->tm.lm_head, nullptr, ctx->logits, V, nullptr, 0, co.M(T), V, D, EPI_NONE, ctx->tm.lm_head_scale,

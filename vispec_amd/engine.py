@@ -262,7 +262,10 @@ class Engine:
         # W32-packed copies of every streamed GEMM weight (the row-major originals stay for the PyTorch prefill)
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
         self.target_weight_dtype = target_weight_dtype
-        if target_weight_dtype == "fp8":
+        # "fp8a8" (round 4): fp8 weights AND fp8 (e4m3, per-row dynamic scale) activations for the target's four per-layer GEMMs of the
+        # verify / AR forwards, multiplied on the fp8 MFMA (vispec_set_fp8_activations); "fp8" keeps bf16 activations (W8A16)
+        fp8_w = target_weight_dtype in ("fp8", "fp8a8")
+        if fp8_w:
             # BASELINE config 5: fp8 (e4m3, per-output-channel scales) target weights.  The row-major copies that the PyTorch prefill
             # uses become the e4m3 CODES held in bf16 (exact) next to their scales (`<name>_scale`): the prefill then computes
             # bf16( (x . codes) * scale + bias ) with an fp32 accumulator — the arithmetic of the W8A16 decode GEMMs — instead of
@@ -286,7 +289,7 @@ class Engine:
                 tw.lm_head = q.view(torch.float8_e4m3fn).to(torch.bfloat16)
                 tw.lm_head_scale = s_
         elif target_weight_dtype != "bf16":
-            raise ValueError("target_weight_dtype must be 'bf16' or 'fp8'")
+            raise ValueError("target_weight_dtype must be 'bf16', 'fp8' or 'fp8a8'")
         if target_weight_dtype == "bf16" and hasattr(tw, "packed8"):
             raise ValueError("these TargetWeights were quantised to fp8 by an earlier Engine (their row-major tensors now hold e4m3 codes + "
                              "scales): build bf16 engines on their own TargetWeights")
@@ -299,7 +302,7 @@ class Engine:
         if not hasattr(dw, "packed"):
             dorder = lambda k, w: qkv_rope_order(w, 2 * dcfg.num_heads) if k == "wqkv" else (swiglu_order(w) if k == "wgu" else w)
             dw.packed = {k: pack_weight(dorder(k, dw.t[k])) for k in GEMM_D}
-        fp8 = target_weight_dtype == "fp8"
+        fp8 = fp8_w
         for i, lw in enumerate(tw.layers):
             pk = tw.packed8[i] if fp8 else tw.packed[i]
             s = L.LayerWeights(**{k: _p(pk[k] if k in GEMM_T else v) for k, v in lw.items()})
@@ -318,6 +321,8 @@ class Engine:
         self.draft_kv = torch.zeros(2, dcfg.num_heads, self.draft_max_pos, dcfg.hidden_size // dcfg.num_heads,
                                     dtype=torch.bfloat16, device=self.device)
         L.check(self.lib.vispec_set_kv(self.h, _p(self.target_kv), _p(self.draft_kv)))
+        if target_weight_dtype == "fp8a8":
+            L.check(self.lib.vispec_set_fp8_activations(self.h, 1))
 
     def close(self):
         """Destroy the library context now (idempotent).  A cohort member gives its activation tile back to its leader — garbage collection

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vispec_cohort_draft_round": (c_int, [P, P, P]),
     "vispec_cohortn_verify_accept": (c_int, [P, c_int, P, c_int]),
     "vispec_cohortn_draft_round": (c_int, [P, c_int, P]),
+    "vispec_gemm_fp8a8": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float]),
     "vispec_gemm_cohort": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "vispec_get_accept_log_host": (c_int, [P, P, P, c_int]),
     "vispec_get_tree_host": (c_int, [P, P, P, P, P, P, P, P]),
     "vispec_set_graphs": (c_int, [P, c_int]),
+    "vispec_set_fp8_activations": (c_int, [P, c_int]),
     "vispec_set_wide_row_blocks": (c_int, [P, c_int]),
     "vispec_graph_stats": (c_int, [P, P]),
     "vispec_prof_enable": (c_int, [P, c_int]),
