@@ -115,6 +115,10 @@ int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, c
    + residual and the fused RMSNorm of the split-K reduce (o_proj / down_proj form), written to `normed` (ld N).  No reference counterpart. */
 int vispec_gemm_fp8a8(vispec_ctx*, void* stream, const void* X, int ldx, const void* P8, const void* wscale_f32, const void* bias, void* Y, int ldy,
                       const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps);
+/* test hook: the W8A8 scratch of the ctx as the last quantisation left it — e4m3 codes [rows][K] (uint8) and per-row scales (fp32), device to
+   device on `stream`.  After vispec_gemm_fp8a8 with norm_w: the quantised `normed` rows, written by the split-K reduce itself (the fused form of
+   the quantisation pass that target_forward uses for the q|k|v and gate|up inputs). */
+int vispec_a8_scratch_read(vispec_ctx*, void* stream, void* codes_out, void* scales_out, int rows, int K);
 /* The GEMM of a cohort round at unit level (tests): n_req = 2..4 requests of m_tile <= 32 rows each; request t's rows are rows
    32t .. 32t + m_tile - 1 of X / Y / R (which therefore span 32 n_req rows; rows beyond m_tile of a tile are neither read for results
    nor written).  Same epilogues as vispec_gemm_skinny (0 none, 1 +R, 2 SwiGLU).  Row for row bit-identical to vispec_gemm_skinny on the

@@ -100,7 +100,9 @@ class Ops:
         if isinstance(W, tuple) and a8:
             # W8A8 (vispec_set_fp8_activations; no reference counterpart — the reference has no fp8 path): the activations are quantised too,
             # one dynamic scale per row: sx = max|x[m, :]| / 448, q = e4m3(x / sx); y = (q_x . q_w^T) * scale_w[n] * sx[m] (+ b).  Products of
-            # e4m3 numbers are exact in fp32 and the fp8 MFMA accumulates in fp32, so numpy reproduces it up to summation order.
+            # e4m3 numbers are exact in fp32; the f8f6f4 MFMA sums the 64 products of a step after aligning them to the step's largest (measured,
+            # tools/probe/f8f6f4_probe.hip: 8e-5 of the sum of |products| against the exact sum) and adds the result to an fp32 accumulator, so numpy
+            # reproduces it up to that alignment loss and the summation order (the tests' tolerances: tests/test_fp8a8_gpu.py).
             x = np.asarray(x, np.float32)
             sx = (np.maximum(np.abs(x).max(axis=-1, keepdims=True), np.float32(1e-12)) / np.float32(448.0)).astype(np.float32)
             y = ((e4m3_round((x / sx).astype(np.float32)) @ W[0].T) * W[1][None, :]) * sx

@@ -89,14 +89,26 @@ def test_fp8a8_split_k_gemm_with_fused_norm_against_the_oracle(lib, eng8, M, N, 
     h = o.add(r, o.linear(x, Wt, None, a8=True))
     assert_bf16_close(fn(Y), h, min_exact=0.9, ulps=2, scale=np.maximum(np.abs(h).max(axis=-1, keepdims=True) / 16, np.maximum(np.abs(r), np.abs(h))))
     assert_bf16_close(fn(Yn), o.rmsnorm(fn(Y), nw, 1e-6), min_exact=0.9, ulps=2)
+    # the reduce also left the normed rows QUANTISED in the ctx's scratch (the next GEMM's input: target_forward's fused form of
+    # quant_rows_e4m3_kernel): exactly the oracle's quantisation of the normed rows the device wrote
+    codes = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    scales = torch.zeros(M, dtype=torch.float32, device=dev())
+    L.check(lib.vispec_a8_scratch_read(eng8.h, stream(), p(codes), p(scales), M, N))
+    torch.cuda.synchronize()
+    yn = fn(Yn)
+    sx = (np.maximum(np.abs(yn).max(axis=-1, keepdims=True), np.float32(1e-12)) / np.float32(448.0)).astype(np.float32)
+    np.testing.assert_array_equal(scales.cpu().numpy(), sx[:, 0])
+    np.testing.assert_array_equal(codes.view(torch.float8_e4m3fn).float().cpu().numpy(), vo.e4m3_round((yn / sx).astype(np.float32)))
 
 
 @pytest.mark.parametrize("N,K", [(4608, 3584), (3584, 18944), (256, 704), (1008, 256), (96, 11008), (256, 256)])
-@pytest.mark.parametrize("n_req,m_tile", [(4, 30), (3, 30), (4, 1), (2, 30)])
+@pytest.mark.parametrize("n_req,m_tile,rb", [(4, 30, 4), (3, 30, 4), (4, 1, 4), (2, 30, 4), (4, 30, 8), (3, 30, 8), (4, 1, 8)])  # (pairs: the paired-tile kernel)
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_fp8a8_cohort_rows_are_bit_identical_to_the_single_request_rows(lib, eng8, N, K, n_req, m_tile, epi):
+def test_fp8a8_cohort_rows_are_bit_identical_to_the_single_request_rows(lib, eng8, N, K, n_req, m_tile, epi, rb):
+    """rb = 8: the eight-row-block form (gemm_w32_wide8_kernel<.., 2, ..>; K = 256 has quarters shorter than a group and falls back to four)."""
     if epi == 2 and N % 16:
         N = N // 16 * 16
+    eng8.set_wide_row_blocks(rb)
     rng = np.random.default_rng(N + K + n_req + m_tile + epi)
     P8, sc, _, rows = _weights(N, K, epi, rng)
     x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
@@ -112,6 +124,7 @@ def test_fp8a8_cohort_rows_are_bit_identical_to_the_single_request_rows(lib, eng
         torch.cuda.synchronize()
         np.testing.assert_array_equal(Y[32 * t:32 * t + m_tile].view(torch.int16).cpu().numpy(), Y1[:m_tile].view(torch.int16).cpu().numpy(), err_msg=f"request {t}")
         assert (Y[32 * t + m_tile:32 * t + 32].float() == 7.0).all(), "padding rows of a tile must stay untouched"
+    eng8.set_wide_row_blocks(4)
 
 
 def _a8_model():

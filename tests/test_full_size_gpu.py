@@ -14,7 +14,8 @@ from helpers import vo  # noqa: E402
 
 
 # model -> (prompt length, image tokens, image runs)
-SHAPES = {"llava7b": (2704, 2144, 1), "llava13b": (2704, 2144, 1), "qwen7b": (1584, 1024, 4), "qwen7b-fp8": (2124, 1564, 1)}
+SHAPES = {"llava7b": (2704, 2144, 1), "llava13b": (2704, 2144, 1), "qwen7b": (1584, 1024, 4), "qwen7b-fp8": (2124, 1564, 1),
+          "qwen7b-fp8a8": (2124, 1564, 1)}  # (the last one: fp8 weights AND fp8 activations on the f8f6f4 MFMA — no BASELINE config, bench.py --model qwen7b-fp8a8)
 
 
 @pytest.fixture(scope="module", params=list(SHAPES))
@@ -203,6 +204,7 @@ WIDTHS = {
                    dkw=dict(rms_norm_eps=1e-6, rope_theta=1e6, qkv_bias=True)),
 }
 WIDTHS["qwen7b-fp8"] = dict(WIDTHS["qwen7b"], fp8=True)
+WIDTHS["qwen7b-fp8a8"] = dict(WIDTHS["qwen7b"], fp8=True, a8=True)  # W8A8: both oracles quantise the decode activations too (Ops.linear a8=True)
 
 
 @pytest.mark.parametrize("kind", list(WIDTHS))
@@ -233,12 +235,13 @@ def test_full_width_two_layer_model_against_the_oracle_floats(kind):
     tcfg = TargetConfig(hidden_size=D, num_heads=H, num_kv_heads=Hk, intermediate_size=I, vocab_size=V, num_layers=NL, max_position_embeddings=MAXP,
                         image_token_index=IMG, **Wd["tkw"])
     dcfg = DraftConfig(hidden_size=D, num_heads=H, intermediate_size=I, vocab_size=V, max_position_embeddings=MAXP, **Wd["dkw"])
-    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, target_weight_dtype="fp8" if Wd["fp8"] else "bf16")
+    sm = SpecModel.from_weights(tcfg, dcfg, tw, dw, target_weight_dtype=("fp8a8" if Wd.get("a8") else "fp8") if Wd["fp8"] else "bf16")
     okw = {k: v for k, v in Wd["tkw"].items() if k in ("rms_norm_eps", "rope_theta", "attn_impl", "mrope_section")}
     codes = fp8_codes_of(sm, D, H, Hk, I, NL) if Wd["fp8"] else False
     ocfg = vo.TargetConfig(D, H, Hk, I, V, NL, MAXP, **okw)
     ot = vo.TargetLlama(ocfg, tw, bf16=True, fp8=codes)
     ot32 = vo.TargetLlama(ocfg, tw, bf16=False, fp8=codes)  # fp32 truth (same weights — the same e4m3 codes and scales for the fp8 model)
+    ot.a8_decode = ot32.a8_decode = bool(Wd.get("a8"))
     od = vo.DraftModel(vo.DraftConfig(D, H, I, V, MAXP, **{k: v for k, v in Wd["dkw"].items() if k != "qkv_bias"}), dw, bf16=True)
     eng = sm.engine
     rng = np.random.default_rng(302)
@@ -288,8 +291,14 @@ def test_full_width_two_layer_model_against_the_oracle_floats(kind):
     ot.tree_mask = ot32.tree_mask = tmask
     want_logits, want_hidden = ot.forward(pkv, input_ids=tok, position_ids=pos + L + delta)
     true_logits, true_hidden = ot32.forward(pkv32, input_ids=tok, position_ids=pos + L + delta)
-    np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=tol(want_hidden))
-    np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=tol(want_logits))
+    a8 = bool(Wd.get("a8"))
+    if not a8:
+        np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=tol(want_hidden))
+        np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=tol(want_logits))
+    # (W8A8: re-quantising every GEMM input to 3 mantissa bits amplifies one-ulp differences of the inputs — the oracle against ITSELF with a quarter
+    #  of the tree's embeddings moved by one bf16 ulp: mean 2e-2, max 1.3e-1 of scale at this width, 53 % of the hidden elements beyond 2^-6
+    #  (NOTEBOOK.md, round 4) — so two correct bf16 evaluations of the W8A8 model differ element-wise by more than any ulp-sized bar; what is
+    #  asserted is the triangulation below, the mean error, and the integer logic)
     scale = np.abs(true_logits).max()
     rel = np.abs(got_logits - want_logits) / scale
     e_hip, e_ora = np.abs(got_logits - true_logits) / scale, np.abs(want_logits - true_logits) / scale
@@ -297,9 +306,10 @@ def test_full_width_two_layer_model_against_the_oracle_floats(kind):
     print(f"{kind} full-width verify logits: HIP vs bf16 oracle mean {rel.mean():.2e} max {rel.max():.2e} of scale | vs fp32 truth: HIP mean "
           f"{e_hip.mean():.2e} max {e_hip.max():.2e}, bf16 oracle mean {e_ora.mean():.2e} max {e_ora.max():.2e} | prefill hidden max err "
           f"{np.abs(got_h - hid).max() / np.abs(hid).max():.2e} of scale")
-    assert rel.mean() <= 3e-3
-    assert e_hip.mean() <= 1.25 * e_ora.mean() and e_hip.max() <= 1.25 * e_ora.max(), "HIP logits further from fp32 truth than the reference's bf16 graph"
-    assert h_hip.mean() <= 1.25 * h_ora.mean() and h_hip.max() <= 1.25 * h_ora.max(), "HIP hidden states further from fp32 truth than the reference's bf16 graph"
+    assert rel.mean() <= (3e-2 if a8 else 3e-3)
+    mx = 1.5 if a8 else 1.25  # (maxima of two chaotic error fields: a wider band for W8A8)
+    assert e_hip.mean() <= 1.25 * e_ora.mean() and e_hip.max() <= mx * e_ora.max(), "HIP logits further from fp32 truth than the reference's bf16 graph"
+    assert h_hip.mean() <= 1.25 * h_ora.mean() and h_hip.max() <= mx * h_ora.max(), "HIP hidden states further from fp32 truth than the reference's bf16 graph"
     # ---- (4) accept on the device's logits == the oracle's evaluate_posterior on the same numbers
     cand = np.concatenate([tok, [-1]])[ret]
     best, a, _ = vo.evaluate_posterior_greedy(got_logits[ret], cand)

@@ -36,11 +36,13 @@ int main() {
   double worst = 0;
   for (int l = 0; l < 64; ++l) for (int q = 0; q < 4; ++q) for (int r = 0; r < 4; ++r) {
     int i = 8 * q + 4 * (l >> 5) + r, j = l & 31;
-    double want = 0;
-    for (int k = 0; k < 64; ++k) want += (double)e4m3(A[i * 64 + k]) * e4m3(B[j * 64 + k]);
-    double err = fabs(want - D[l * 16 + 4 * q + r]) / (fabs(want) + 1e-3);
+    double want = 0, mag = 0;
+    for (int k = 0; k < 64; ++k) { const double t = (double)e4m3(A[i * 64 + k]) * e4m3(B[j * 64 + k]); want += t; mag += fabs(t); }
+    // (error against the sum of |products|: a wrong operand layout leaves O(1); the right one leaves what the pipe's internal alignment of 64
+    //  products of very different magnitude drops — the first run of this probe saw 7e-4 of the RESULT, i.e. not an exact fp32 sum of products)
+    double err = fabs(want - D[l * 16 + 4 * q + r]) / (mag + 1e-30);
     if (err > worst) worst = err;
   }
-  printf("f8f6f4 32x32x64: worst relative error vs the assumed layouts = %.3g (%s)\n", worst, worst < 1e-5 ? "layout confirmed" : "LAYOUT MISMATCH");
+  printf("f8f6f4 32x32x64: worst error / sum |products| vs the assumed layouts = %.3g (%s)\n", worst, worst < 1e-2 ? "layout confirmed" : "LAYOUT MISMATCH");
   return 0;
 }

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
     _Pragma("unroll") for (int mt = 0; mt < NL; ++mt) {                                                         \
       uint4 b0 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u)) & 3]);                         \
       uint4 b1 = *reinterpret_cast<const uint4*>((xb) + mt * 4096 + ro[(2 * (u) + 1) & 3]);                     \
-      if ((u) < (SK)) { b0 = make_uint4(0, 0, 0, 0); b1 = b0; }                                                 \
+      {  /* (a mask, not a branch: the branchy form of the tail group spilled eight registers to scratch) */    \
+        const unsigned km_ = (u) < (SK) ? 0u : 0xffffffffu;                                                     \
+        b0.x &= km_; b0.y &= km_; b0.z &= km_; b0.w &= km_; b1.x &= km_; b1.y &= km_; b1.z &= km_; b1.w &= km_; \
+      }                                                                                                         \
       acc[mt] = mfma_f8_64(make_uint4(w[(2 * (u)) % (LOADS * TPS)].x, w[(2 * (u)) % (LOADS * TPS)].y, w[(2 * (u)) % (LOADS * TPS)].z, w[(2 * (u)) % (LOADS * TPS)].w), \
                            make_uint4(w[(2 * (u) + 1) % (LOADS * TPS)].x, w[(2 * (u) + 1) % (LOADS * TPS)].y, w[(2 * (u) + 1) % (LOADS * TPS)].z, w[(2 * (u) + 1) % (LOADS * TPS)].w), \
                            b0, b1, acc[mt]);                                                                    \
@@ -416,19 +419,27 @@ __global__ __launch_bounds__(RB * 256) void gemm_w32_wide_kernel(const bf16_t* _
 //   group g + 1's activations waits vmcnt(LA (LOADS + PPW) - PPW).  The last LA groups fetch stand-ins (the last group again).
 // Needs every quarter of the split to hold at least one whole group (the host falls back to the 4 x 4 kernel otherwise: tiny models).
 #define WIDE8_BUFBYTES (16 * 1024)
-template <int W8> constexpr int wide8_la() { return W8 ? 4 : 2; }                                   // groups of lookahead (8 KiB of W per wave in flight)
+#ifndef VISPEC_WIDE8_A8_LA
+#define VISPEC_WIDE8_A8_LA 2  // (experiments: -DVISPEC_WIDE8_A8_LA=3 = 12 KiB of W per wave in flight for the W8A8 form)
+#endif
+template <int W8> constexpr int wide8_la() { return W8 == 1 ? 4 : (W8 == 2 ? VISPEC_WIDE8_A8_LA : 2); }  // groups of lookahead (8 KiB of W per wave in flight)
 template <int W8> constexpr int wide8_lds_bytes() { return (wide8_la<W8>() + 2) * WIDE8_BUFBYTES; }  // ring of LA + 1 buffers + the zero buffer
 
 template <int EPI, int W8, int NL>
 __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                              const bf16_t* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                              const bf16_t* __restrict__ R, int ldr, int m_tile, int N, int K, int S,
-                                                             const float* __restrict__ wscale, RopeEpi re, int tiles) {
+                                                             const float* __restrict__ wscale, RopeEpi re, int tiles,
+                                                             const float* __restrict__ xscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  // W8 = 2 (fp8 activations too, `X` = e4m3 codes, ldx in 2-byte units, xscale = per-row scales): a k-step is 64 k = TWO weight tiles against
+  // 64 activation bytes per row on the f8f6f4 MFMA; a group (one 16 KiB ring buffer) is 128 k = 2 steps = 4 tile loads per wave, like bf16
+  constexpr bool A8 = W8 == 2;
   constexpr int LA = wide8_la<W8>(), NB = LA + 1;
-  constexpr int KSTEP = W8 ? 32 : 16, LOADS = W8 ? 2 : 4;
+  constexpr int KSTEP = A8 ? 64 : (W8 ? 32 : 16), LOADS = W8 ? 2 : 4, TPS = A8 ? 2 : 1, TL = LOADS * TPS;  // k per step, steps per group, tiles per step / group
+  constexpr int XB = A8 ? 64 : KSTEP * 2;  // activation bytes per step and row
   constexpr int PPW = (4 * NL + 7) / 8;  // 1 KiB activation pieces a wave moves per group (NL = 3: 16 slots for 12 pieces, the last one fetched five times)
-  constexpr int QIN = LA * (LOADS + PPW);  // memory operations in flight per wave in steady state
+  constexpr int QIN = LA * (TL + PPW);   // memory operations in flight per wave in steady state
   constexpr int XAHEAD = W8 ? 1 : 2;       // k-steps whose activation fragments are read from LDS ahead of their MFMAs (8 NL... 2 NL x 16 B per lane either way)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
@@ -468,14 +479,14 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
     z[threadIdx.x] = make_uint4(0, 0, 0, 0);
     z[threadIdx.x + 512] = make_uint4(0, 0, 0, 0);
   }
-  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X);                                     // + step * KSTEP * 2 bytes
-  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + (size_t)tile * KS * 1024;           // + step KiB
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X);                                     // + step * XB bytes
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(P) + (size_t)tile * KS * (TPS * 1024);   // + step * TPS KiB
   const unsigned wvo = lane * 16;
   const unsigned rrow = (unsigned)(j >> 3) * 1024u + (unsigned)(j & 7) * 128u, fsw = (unsigned)(j >> 1) & 7u;
   unsigned ro[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const unsigned sseg = W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi);
+    const unsigned sseg = A8 ? (unsigned)(4 * (t >> 1) + 2 * (t & 1) + hi) : (W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi));
     ro[t] = rrow + ((sseg ^ fsw) << 4);
   }
   // ---- group iterators (wave-uniform scalars): (quarter, index in quarter) -> first k-step, zeroed leading steps, last-of-quarter
@@ -490,10 +501,10 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
     ++t.q; t.i = 0; t.a += t.n;
     t.n = ks_lo + (int)((long)len * (t.q + 1) / 4) - t.a;
   };
-  u32x4_t w[LA][LOADS];
+  u32x4_t w[LA][TL];
 #define W8_DMA(step0, slot)                                                                                   \
   {                                                                                                             \
-    const unsigned char* xs_ = xsrc + (size_t)(step0) * (KSTEP * 2);                                            \
+    const unsigned char* xs_ = xsrc + (size_t)(step0) * XB;                                                     \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) wide_dma16(xoff[i], xs_, xdst[i] + (unsigned)(slot) * WIDE8_BUFBYTES); \
   }
   // The activation fragments of a group are read from LDS AHEAD of the MFMAs that consume them (two k-steps = 8 NL... 2 x NL x 16 B per lane in
@@ -516,7 +527,11 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
   // one k-step (one weight tile register) against the NL staged activation tiles
 #define W8_MFMA(SL, u)                                                                                        \
   {                                                                                                             \
-    if constexpr (!W8) {                                                                                        \
+    if constexpr (A8) {                                                                                         \
+      const u32x4_t &w0_ = w[SL][(2 * (u)) % TL], &w1_ = w[SL][(2 * (u) + 1) % TL];                             \
+      _Pragma("unroll") for (int mt = 0; mt < NL; ++mt)                                                         \
+        cur[mt] = mfma_f8_64(make_uint4(w0_.x, w0_.y, w0_.z, w0_.w), make_uint4(w1_.x, w1_.y, w1_.z, w1_.w), xf[u][mt][0], xf[u][mt][W8 ? 1 : 0], cur[mt]); \
+    } else if constexpr (!W8) {                                                                                        \
       _Pragma("unroll") for (int mt = 0; mt < NL; ++mt)                                                         \
         cur[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[SL][u]), as_bf16x8(xf[u][mt][0]), cur[mt], 0, 0, 0); \
     } else {                                                                                                    \
@@ -531,10 +546,16 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
   // step u: its weight tile has landed -> (the fragment reads of the step after next go out) -> its MFMAs -> its register is re-issued
 #define W8_STEP(SL, u)                                                                                        \
   if constexpr ((u) < LOADS) {                                                                                  \
-    wide_wait_vm<QIN - 1>(w[SL][(u) < LOADS ? (u) : 0]);                                                        \
+    if constexpr (TPS == 2) wide_wait_vm2<QIN - TPS>(w[SL][(2 * (u)) % TL], w[SL][(2 * (u) + 1) % TL]);         \
+    else wide_wait_vm<QIN - 1>(w[SL][(u) < LOADS ? (u) : 0]);                                                   \
     if constexpr ((u) + XAHEAD < LOADS) W8_XREAD(((u) + XAHEAD < LOADS ? (u) + XAHEAD : 0), xb, skip)           \
     W8_MFMA(SL, (u) < LOADS ? (u) : 0)                                                                          \
-    wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[SL][(u) < LOADS ? (u) : 0], wvo, wn);                         \
+    if constexpr (TPS == 2) {                                                                                   \
+      wide_load_w<((2 * (u)) % TL) * 1024>(w[SL][(2 * (u)) % TL], wvo, wn);                                     \
+      wide_load_w<((2 * (u) + 1) % TL) * 1024>(w[SL][(2 * (u) + 1) % TL], wvo, wn);                             \
+    } else {                                                                                                    \
+      wide_load_w<((u) < LOADS ? (u) : 0) * 1024>(w[SL][(u) < LOADS ? (u) : 0], wvo, wn);                       \
+    }                                                                                                           \
   }
   // one group: SL = its weight-register slot (g % LA, compile time), `c` = its iterator, `pf` = the iterator LA groups ahead
 #define W8_GROUP(SL)                                                                                          \
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
     const bool live = g + (SL) < Gtot;                                                                          \
     const int skip = live ? it_skip(c) : LOADS;                                                                 \
     const int s0p = it_step0(pf);                                                                               \
-    const unsigned char* wn = wsrc + (size_t)s0p * 1024;                                                        \
+    const unsigned char* wn = wsrc + (size_t)s0p * (TPS * 1024);                                                \
     const unsigned char* xb = smem_w + rd * WIDE8_BUFBYTES;                                                     \
     W8_XREAD(0, xb, skip)                                                                                       \
     if constexpr (XAHEAD > 1) W8_XREAD((XAHEAD > 1 ? 1 : 0), xb, skip)                                          \
@@ -569,13 +590,13 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
 #pragma unroll
   for (int p = 0; p < LA; ++p) {
     const int s0 = it_step0(pf);
-    const unsigned char* wp = wsrc + (size_t)s0 * 1024;
+    const unsigned char* wp = wsrc + (size_t)s0 * (TPS * 1024);
     W8_DMA(s0, p)
     wide_load_w<0>(w[p][0], wvo, wp);
     wide_load_w<1024>(w[p][1], wvo, wp);
-    if constexpr (LOADS > 2) {
-      wide_load_w<2048>(w[p][LOADS > 2 ? 2 : 0], wvo, wp);
-      wide_load_w<3072>(w[p][LOADS > 2 ? 3 : 0], wvo, wp);
+    if constexpr (TL > 2) {
+      wide_load_w<2048>(w[p][TL > 2 ? 2 : 0], wvo, wp);
+      wide_load_w<3072>(w[p][TL > 2 ? 3 : 0], wvo, wp);
     }
     it_next(pf);
   }
@@ -584,10 +605,8 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
   for (int g = 0; g < Gtot; g += LA) {
     W8_GROUP(0)
     W8_GROUP(1)
-    if constexpr (LA > 2) {
-      W8_GROUP(LA > 2 ? 2 : 0)
-      W8_GROUP(LA > 2 ? 3 : 0)
-    }
+    if constexpr (LA > 2) W8_GROUP(LA > 2 ? 2 : 0)
+    if constexpr (LA > 3) W8_GROUP(LA > 3 ? 3 : 0)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stand-in fetches of the last groups (their LDS-DMAs must not outlive the workgroup)
 #undef W8_GROUP
@@ -596,5 +615,5 @@ __global__ __launch_bounds__(512) void gemm_w32_wide8_kernel(const bf16_t* __res
 #undef W8_XREAD
 #undef W8_DMA
   if (!tile_ok) return;
-  wide_epilogue<EPI, W8, NL>(tot, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re);
+  wide_epilogue<EPI, W8, NL>(tot, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re, xscale);
 }

@@ -205,6 +205,13 @@ __device__ __forceinline__ f32x16 mfma_f8_64(uint4 a0, uint4 a1, uint4 b0, uint4
   // instruction, and every kernel of the library feeds it the same way): here bytes [16 hi, +16) and [32 + 16 hi, +16) of the 64.
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
 }
+// four values of a row -> four e4m3 codes (x / scale, rne, saturating): the arithmetic of quant_rows_e4m3_kernel for the fused form below
+__device__ __forceinline__ unsigned quant4_e4m3(float a, float b, float c, float d, float scale) {
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(a, scale), __fdiv_rn(b, scale), v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(c, scale), __fdiv_rn(d, scale), v, true);
+  return (unsigned)v;
+}
 // One workgroup per row: sx[m] = max(|x[m, :]|, 1e-12) / 448, q[m, k] = e4m3_rne(x[m, k] / sx[m])   (oracle: Ops.linear(..., a8=True))
 __global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16_t* __restrict__ X, int ldx, unsigned char* __restrict__ Q, int ldq,
                                                               float* __restrict__ sx, int K) {
@@ -653,7 +660,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
 __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int Mpad, int N,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                             bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ norm_w,
-                                                            bf16_t* __restrict__ normed, int ldn, float eps, int m_tile) {
+                                                            bf16_t* __restrict__ normed, int ldn, float eps, int m_tile,
+                                                            unsigned char* __restrict__ q8 = nullptr, float* __restrict__ sx8 = nullptr) {
+  // q8 != nullptr (W8A8, with `normed`): the normed row is ALSO written as e4m3 codes q8[row][N] with its scale sx8[row] — exactly what
+  // quant_rows_e4m3_kernel would make of `normed` (the next GEMM's input), without that launch.
   // Latency-bound (a few MB out of L2 per launch, 80 launches per round): every load of a row chunk — up to 8 partial slabs with
   // clamped (always valid) slab indices, residual, bias, norm weight — is issued before the first use, and a row that fits one
   // pass of the block (N <= 4 x threads: every model here) keeps its values in registers across the block-wide sum of squares.
@@ -710,23 +720,51 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   float tot = 0.f;
   for (int w = 0; w < (nthreads >> 6); ++w) tot += partsum[w];
   const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+  __shared__ float partmax[16];
+  float amax = 0.f;
   if (one_pass) {
     const int n = threadIdx.x * 4;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
     if (n < N) {
       const bf16_t* we = reinterpret_cast<const bf16_t*>(&wkeep);
-      const float o0 = bf2f(we[0]) * rdbf(keep[0] * inv), o1 = bf2f(we[1]) * rdbf(keep[1] * inv);
-      const float o2 = bf2f(we[2]) * rdbf(keep[2] * inv), o3 = bf2f(we[3]) * rdbf(keep[3] * inv);
+      o0 = rdbf(bf2f(we[0]) * rdbf(keep[0] * inv)), o1 = rdbf(bf2f(we[1]) * rdbf(keep[1] * inv));
+      o2 = rdbf(bf2f(we[2]) * rdbf(keep[2] * inv)), o3 = rdbf(bf2f(we[3]) * rdbf(keep[3] * inv));
       *reinterpret_cast<uint2*>(normed + (size_t)mo * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
     }
+    if (!q8) return;
+    amax = wave_max(fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))));
+    if ((threadIdx.x & 63) == 0) partmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = 0.f;
+    for (int w = 0; w < (nthreads >> 6); ++w) amax = fmaxf(amax, partmax[w]);
+    const float scale = __fdiv_rn(fmaxf(amax, 1e-12f), 448.0f);
+    if (threadIdx.x == 0) sx8[mo] = scale;
+    if (n < N) *reinterpret_cast<unsigned*>(q8 + (size_t)mo * N + n) = quant4_e4m3(o0, o1, o2, o3, scale);
     return;
   }
   for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     const float4 h = *reinterpret_cast<const float4*>(hrow + n);
     const uint2 wv = *reinterpret_cast<const uint2*>(norm_w + n);
     const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
-    const float o0 = bf2f(we[0]) * rdbf(h.x * inv), o1 = bf2f(we[1]) * rdbf(h.y * inv);
-    const float o2 = bf2f(we[2]) * rdbf(h.z * inv), o3 = bf2f(we[3]) * rdbf(h.w * inv);
+    const float o0 = rdbf(bf2f(we[0]) * rdbf(h.x * inv)), o1 = rdbf(bf2f(we[1]) * rdbf(h.y * inv));
+    const float o2 = rdbf(bf2f(we[2]) * rdbf(h.z * inv)), o3 = rdbf(bf2f(we[3]) * rdbf(h.w * inv));
     *reinterpret_cast<uint2*>(normed + (size_t)mo * ldn + n) = make_uint2(pack2(o0, o1), pack2(o2, o3));
+    if (q8) {  // (each thread re-reads only the elements it wrote: no barrier needed for hrow)
+      *reinterpret_cast<float4*>(hrow + n) = make_float4(o0, o1, o2, o3);
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))));
+    }
+  }
+  if (!q8) return;
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) partmax[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = 0.f;
+  for (int w = 0; w < (nthreads >> 6); ++w) amax = fmaxf(amax, partmax[w]);
+  const float scale = __fdiv_rn(fmaxf(amax, 1e-12f), 448.0f);
+  if (threadIdx.x == 0) sx8[mo] = scale;
+  for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
+    const float4 h = *reinterpret_cast<const float4*>(hrow + n);
+    *reinterpret_cast<unsigned*>(q8 + (size_t)mo * N + n) = quant4_e4m3(h.x, h.y, h.z, h.w, scale);
   }
 }
 

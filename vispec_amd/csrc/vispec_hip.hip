@@ -252,7 +252,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
       (const void*)gemm_w32_wide_kernel<EPI_SWIGLU, W8_, NL_, 0, RB_>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, W8_, NL_, 0, RB_>, \
       (const void*)gemm_w32_wide_kernel<EPI_ROPE, W8_, NL_, 0, RB_>
 #define WIDE_ALL_EPI(W8_, NL_) WIDE_ALL_EPI_RB(W8_, NL_, 4), WIDE_ALL_EPI_RB(W8_, NL_, 3), WIDE_ALL_EPI_RB(W8_, NL_, 2)
-    const void* wide[] = {WIDE_ALL_EPI(false, 3), WIDE_ALL_EPI(false, 4), WIDE_ALL_EPI(true, 3), WIDE_ALL_EPI(true, 4),
+    const void* wide[] = {WIDE_ALL_EPI(0, 3), WIDE_ALL_EPI(0, 4), WIDE_ALL_EPI(1, 3), WIDE_ALL_EPI(1, 4), WIDE_ALL_EPI_RB(2, 3, 4), WIDE_ALL_EPI_RB(2, 4, 4),
                           (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 1>, (const void*)gemm_w32_wide_kernel<EPI_PARTIAL, false, 4, 2>};
 #undef WIDE_ALL_EPI
 #undef WIDE_ALL_EPI_RB
@@ -263,13 +263,13 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   (const void*)gemm_w32_wide8_kernel<EPI_NONE, W8_, NL_>, (const void*)gemm_w32_wide8_kernel<EPI_RESIDUAL, W8_, NL_>,                  \
       (const void*)gemm_w32_wide8_kernel<EPI_SWIGLU, W8_, NL_>, (const void*)gemm_w32_wide8_kernel<EPI_PARTIAL, W8_, NL_>,             \
       (const void*)gemm_w32_wide8_kernel<EPI_ROPE, W8_, NL_>
-    const void* wide8_bf16[] = {WIDE8_ALL_EPI(false, 3), WIDE8_ALL_EPI(false, 4)};
-    const void* wide8_fp8[] = {WIDE8_ALL_EPI(true, 3), WIDE8_ALL_EPI(true, 4)};
+    const void* wide8_bf16[] = {WIDE8_ALL_EPI(0, 3), WIDE8_ALL_EPI(0, 4), WIDE8_ALL_EPI(2, 3), WIDE8_ALL_EPI(2, 4)};  // (W8A8: the bf16 form's ring)
+    const void* wide8_fp8[] = {WIDE8_ALL_EPI(1, 3), WIDE8_ALL_EPI(1, 4)};
 #undef WIDE8_ALL_EPI
     for (const void* f : wide8_bf16)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<false>()) != hipSuccess) (void)hipGetLastError();
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<0>()) != hipSuccess) (void)hipGetLastError();
     for (const void* f : wide8_fp8)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<true>()) != hipSuccess) (void)hipGetLastError();
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<1>()) != hipSuccess) (void)hipGetLastError();
   }
   if (leader) leader->members[slot - 1] = ctx;
   *out = ctx;
@@ -456,6 +456,7 @@ struct GemmOut {
   void* Y = nullptr; int ldy = 0;
   const void* R = nullptr; int ldr = 0;
   const void* norm_w = nullptr; void* normed = nullptr; int ldn = 0; float eps = 0.f;
+  unsigned char* q8 = nullptr; float* sx8 = nullptr;  // with normed (W8A8): the normed rows also as e4m3 codes [row][N] + per-row scales (the next GEMM's input)
   int m_tile = 0;  // > 0: cohort mode — two requests share the weight pass: tile t holds request t's rows 32t .. 32t + m_tile - 1 (M = 32 + m_tile)
                    // < 0: slab mode — 2..4 requests of -m_tile <= 8 rows each packed into ONE activation tile (M = 8 (n - 1) - m_tile): tile row
                    //      8t + i is row 32t + i of X / Y / R (kernels.h, gemm_w32_kernel SLAB)
@@ -543,7 +544,7 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   static const int red_threads = getenv("VISPEC_REDUCE_THREADS") ? atoi(getenv("VISPEC_REDUCE_THREADS")) : 512;
   PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? red_threads : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, 32 * MT,
                      N, b, epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed,
-                     o.ldn, o.eps, o.m_tile);
+                     o.ldn, o.eps, o.m_tile, o.normed ? o.q8 : nullptr, o.sx8);
   KCHK();
   prof_end(s);
   return 0;
@@ -590,11 +591,11 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
        the eight-row-block form to the GEMMs whose four-row-block grid is small or spills into a second round keeps only half of that),    \
        four for fp8 weights (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte on two waves per SIMD,  \
        29 GB/s per CU instead of the 54 of the bf16 one) — profiles/README.md, round 4 */                                                  \
-    if (rb_ == 84) rb_ = (W8_) ? 4 : 8;                                                                                                   \
-    if ((W8_) == 2) rb_ = 4;  /* fp8 activations: the four-row-block kernel only */                                                        \
-    if ((W8_) != 2 && rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
+    if (rb_ == 84) rb_ = (W8_) == 1 ? 4 : 8;                                                                                              \
+    if ((W8_) == 2 && rb_ != 8) rb_ = 4;  /* fp8 activations: four or eight row blocks */                                                  \
+    if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \
       PLAUNCH((gemm_w32_wide8_kernel<EPI_, W8_, NL_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), (wide8_lds_bytes<W8_>()), s, x, ldx, w, b, \
-              YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles);                                      \
+              YPTR, LDY, r, o.ldr, o.m_tile, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles, o.xscale);                            \
       break;                                                                                                                            \
     }                                                                                                                                   \
     if (rb_ == 8) rb_ = 4;                                                                                                              \
@@ -657,7 +658,8 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   prof_begin(s, 4, 0.0);
   static const int red_threads = getenv("VISPEC_REDUCE_THREADS") ? atoi(getenv("VISPEC_REDUCE_THREADS")) : 512;
   PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? red_threads : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, WIDE_MPAD, N, b,
-          epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn, o.eps, o.m_tile);
+          epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn, o.eps, o.m_tile,
+          o.normed ? o.q8 : nullptr, o.sx8);
   KCHK();
   prof_end(s);
   return 0;
@@ -1033,12 +1035,24 @@ extern "C" int vispec_gemm_fp8a8(vispec_ctx* ctx, void* stream, const void* X, i
   if ((size_t)K > kmax) return fail("gemm_fp8a8: K exceeds the ctx's quantisation scratch (max of hidden, heads x head_dim, intermediate size)");
   hipStream_t s = (hipStream_t)stream;
   const int rows = n_req == 1 ? M : 32 * (n_req - 1) + m_tile;
-  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)X, ldx, ctx->xq, K, ctx->sx, K);
-  KCHK();
+  const char* skip = getenv("VISPEC_A8_SKIP_QUANT");  // experiments (tools/fp8_k_sweep.py): time the GEMM without its quantisation pass
+  if (!skip || skip[0] != '1') {
+    hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)X, ldx, ctx->xq, K, ctx->sx, K);
+    KCHK();
+  }
   GemmOut o;
   o.wscale = (const float*)wscale; o.xscale = ctx->sx; o.m_tile = n_req == 1 ? 0 : m_tile;
   o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr; o.norm_w = norm_w; o.normed = normed; o.ldn = N; o.eps = eps;
+  if (norm_w && (size_t)N <= kmax) { o.q8 = ctx->xq; o.sx8 = ctx->sx; }  // as target_forward: the normed rows leave the reduce quantised as well
   return launch_gemm_ex(ctx, s, ctx->xq, K / 2, P8, bias, rows, N, K, epilogue, o);
+}
+// test hook: the ctx's W8A8 scratch (e4m3 codes [rows][K] and per-row scales) as the last quantisation left it — copied on `stream`
+extern "C" int vispec_a8_scratch_read(vispec_ctx* ctx, void* stream, void* codes_out, void* scales_out, int rows, int K) {
+  if (!ctx || !ctx->xq || rows < 1 || rows > 128 || K < 1) return fail("a8_scratch_read: bad arguments");
+  if (hipMemcpyAsync(codes_out, ctx->xq, (size_t)rows * K, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipMemcpyAsync(scales_out, ctx->sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+    return fail("a8_scratch_read: copy failed");
+  return 0;
 }
 // skinny GEMM (+bias, +residual R) with the following RMSNorm fused: Y = bf16(R + bf16(X·W^T + b)), normed = norm_w * rms(Y)
 extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
@@ -1796,7 +1810,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       return hipGetLastError() == hipSuccess ? 0 : fail("quant_rows launch failed");
     };
     if (a8) {
-      if (quant(ctx->xn, D)) return -1;
+      if (l == 0 && quant(ctx->xn, D)) return -1;  // (later layers: the codes come out of the previous layer's down_proj reduce + norm)
       if (launch_qkv_rope(ctx, s, ctx->xq, D / 2, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos, false,
                           ctx->sx))
         return -1;
@@ -1820,13 +1834,13 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       if (a8) {
         if (quant(ctx->attn_o, H * 128)) return -1;
         o.xscale = ctx->sx;
+        o.q8 = ctx->xq; o.sx8 = ctx->sx;  // the reduce + norm leaves gate|up's input quantised (it runs after the GEMM has read xq / sx)
         if (launch_gemm_ex(ctx, s, ctx->xq, H * 128 / 2, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
       } else if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
     }
     if (a8) {
       GemmOut o;
       o.wscale = (const float*)w.sgu; o.xscale = ctx->sx; o.m_tile = co.mt(T); o.Y = ctx->act; o.ldy = I;
-      if (quant(ctx->xn, D)) return -1;
       if (launch_gemm_ex(ctx, s, ctx->xq, D / 2, w.wgu, nullptr, co.M(T), I, D, EPI_SWIGLU, o)) return -1;
     } else if (launch_gemm(ctx, s, ctx->xn, D, w.wgu, nullptr, ctx->act, I, nullptr, 0, co.M(T), I, D, EPI_SWIGLU, w.sgu, co.mt(T))) return -1;
     {
@@ -1840,6 +1854,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       if (a8) {
         if (quant(ctx->act, I)) return -1;
         o.xscale = ctx->sx;
+        if (!last) { o.q8 = ctx->xq; o.sx8 = ctx->sx; }  // the next layer's q|k|v input
         if (launch_gemm_ex(ctx, s, ctx->xq, I / 2, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
       } else if (launch_gemm_ex(ctx, s, ctx->act, I, w.wdown, nullptr, co.M(T), D, I, EPI_RESIDUAL, o)) return -1;
     }
