@@ -89,7 +89,7 @@ def resolve_weights(args):
 
 
 REFILL = True  # --no-refill: cohort by cohort
-WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight for bf16 weights, four for fp8)
+WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight for bf16 weights and for W8A8, four for fp8 weights with bf16 activations)
 
 
 def build_models(device, seed, rank, world, lanes, cohort=1):
@@ -488,7 +488,7 @@ def main():
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, "
-                         "84 (eight for bf16 weights, four for fp8) with several")
+                         "84 (eight for bf16 weights and W8A8, four for W8A16) with several")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -699,10 +699,9 @@ def main():
                 # FETCH_SIZE is KB and counts half of a wide coalesced stream on gfx950 -> x2, MI355X_MICROARCH.md §HBM)
                 traffic = traffic_source = None
                 try:
-                    if MODEL != "llava7b":
-                        raise KeyError("the committed PMC pass was collected on the headline config only")
-                    import glob
-                    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.json")))[-1]
+                    import glob  # (one committed pass per model that has one: profiles/rNN_pmc_fetch_size[_<model>].json)
+                    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size" + ("" if MODEL == "llava7b" else "_" + MODEL.replace("-", ""))
+                                                             + ".json")))[-1]
                     pmc = json.load(open(pmc_file))
                     key = keys.get(dom_)
                     for k, v in pmc.items():
@@ -749,7 +748,7 @@ def main():
                 rep_c.pop("gemm_prefill_mfma", None)
                 _, gemm_c, dom_c = price(rep_c)
                 rb_timed = WIDE_RB if WIDE_RB >= 0 else (0 if R == 1 else 84)
-                wide8 = CO >= 3 and (rb_timed == 8 or (rb_timed == 84 and not fp8))
+                wide8 = CO >= 3 and (rb_timed == 8 or (rb_timed == 84 and (not fp8 or "a8" in MODEL)))  # (vispec_set_wide_row_blocks(84): W8A16 stays on four)
                 keys_c = (PROF_KERNEL_KEYS_WIDE8 if wide8 else PROF_KERNEL_KEYS_WIDE) if CO >= 3 else PROF_KERNEL_KEYS_PAIRED
                 extra["roofline"] = roofline_of(rep_c, gemm_c, dom_c, keys_c,
                                                 f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps, ALONE on the GPU): "

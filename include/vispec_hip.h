@@ -284,7 +284,7 @@ int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, di
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that
    several request lanes keep busy), 3 or 2 (more, smaller workgroups), 0 (the smallest of {2, 3, 4} whose grid still runs in one round
    of CUs: a single lane), 8 (round 4: eight row blocks per workgroup, the K range walked quarter by quarter by every wave — half the
-   activation traffic per weight byte, half the workgroups: gemm_w32_wide8_kernel), 84 (eight for bf16 weights, four for fp8 weights: what bench.py runs
+   activation traffic per weight byte, half the workgroups: gemm_w32_wide8_kernel), 84 (eight for bf16 weights and for W8A8, four for fp8 weights with bf16 activations: what bench.py runs
    with several lanes per GPU).
    Results are bit-identical in every setting. */
 int vispec_set_wide_row_blocks(vispec_ctx* leader, int row_blocks);

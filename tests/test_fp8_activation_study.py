@@ -14,8 +14,8 @@ Qwen2.5-VL-shaped tiny target with e4m3 weights — numbers of the run that deci
 
 Reading: W8A8 is 6-8x further from the model than W8A16's bf16 rounding — an order of magnitude outside BASELINE's "logits within 1e-3" — but
 on a confident model it accepts the same tokens, i.e. it would pass §7.1 step 8's relaxed bar with a documented divergence on near-tie inputs.
-It was NOT built this round (a second kernel family: block-scaled activation quantisation in every producing epilogue, fp8 staging, the
-f8f6f4 MFMA's operand layout, an A8 mode in oracle and tests); DESIGN.md §8 (config 5) carries the estimate of what it would buy."""
+It was built later in the same round as an opt-in dtype (`target_weight_dtype="fp8a8"`, `bench.py --model qwen7b-fp8a8`; kernels: the W8 = 2
+instantiations of csrc/kernels.h / gemm_wide.h, tests/test_fp8a8_gpu.py; +13 % on the fp8 line); `--model qwen7b-fp8` stays W8A16."""
 import numpy as np
 
 from helpers import vo

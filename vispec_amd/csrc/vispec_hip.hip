@@ -589,8 +589,9 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
     int rb_ = rb_opt;                                                                                                                   \
     /* 84 = what several lanes per GPU run: eight row blocks for bf16 weights (+4 % on the bf16 lines in four same-box A/Bs; restricting  \
        the eight-row-block form to the GEMMs whose four-row-block grid is small or spills into a second round keeps only half of that),    \
-       four for fp8 weights (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte on two waves per SIMD,  \
-       29 GB/s per CU instead of the 54 of the bf16 one) — profiles/README.md, round 4 */                                                  \
+       four for fp8 weights with bf16 activations (their eight-row-block kernel sits on the matrix pipe: twice the MFMAs per weight byte   \
+       plus the up-conversion on two waves per SIMD, 29 GB/s per CU instead of the 54 of the bf16 one), eight again for W8A8 (a quarter   \
+       of the MFMAs: +2.6 % over four on the line) — profiles/README.md, round 4 */                                                        \
     if (rb_ == 84) rb_ = (W8_) == 1 ? 4 : 8;                                                                                              \
     if ((W8_) == 2 && rb_ != 8) rb_ = 4;  /* fp8 activations: four or eight row blocks */                                                  \
     if (rb_ == 8 && tiles >= w8_tiles_min && tiles <= w8_tiles_max && wide8_ok(KS, SPLITS, (W8_) ? 2 : 4)) {  /* eight row blocks per workgroup */ \

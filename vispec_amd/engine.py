@@ -454,7 +454,7 @@ class Engine:
 
     def set_wide_row_blocks(self, row_blocks: int):
         """Launch shape of a 3-4 request cohort's GEMMs (leader only): 4 = default, 0 = best for ONE lane, 8 = eight row blocks per workgroup,
-        84 = eight for bf16 weights, four for fp8 (several lanes per GPU: what bench.py sets)."""
+        84 = eight for bf16 weights and for W8A8, four for fp8 weights with bf16 activations (several lanes per GPU: what bench.py sets)."""
         L.check(self.lib.vispec_set_wide_row_blocks(self.h, int(row_blocks)))
 
     def graph_stats(self) -> Dict[str, int]:
