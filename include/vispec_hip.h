@@ -275,7 +275,7 @@ int vispec_get_tree_host(vispec_ctx*, void* stream, int* tokens_T, int* pos_T, u
 /* hipGraph replay of the round functions (verify_accept / draft_round / ar_step) on capturable (non-null) streams: on by default. */
 int vispec_set_graphs(vispec_ctx*, int on);
 /* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"; the reference has no fp8 path): with fp8 target weights, also take the ACTIVATIONS of the
-   target's four per-layer GEMMs (modeling_qwen2_5_vl_kv.py:1065-1170: q|k|v, o_proj, gate|up, down) in e4m3 — one dynamic scale per row —
+   target's q|k|v, gate|up and down GEMMs (modeling_qwen2_5_vl_kv.py:1065-1170; o_proj keeps bf16 activations) in e4m3 — one dynamic scale per row —
    and multiply on v_mfma_scale_f32_32x32x64_f8f6f4 (W8A8) instead of up-converting the weight codes for the bf16 MFMA (W8A16, the default).
    A different arithmetic ("same accepted tokens or documented divergence"); lm_head, draft and prefill unchanged. */
 int vispec_set_fp8_activations(vispec_ctx*, int on);

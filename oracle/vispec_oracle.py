@@ -498,7 +498,7 @@ class TargetLlama:
         self.cos, self.sin = np.asarray(cos, np.float32), np.asarray(sin, np.float32)
         self.tree_mask = None  # [T,T] bool, installed by the loop (spec_model_ours.py:486-489)
         self.a8_decode = False  # True (fp8 weights only): forwards on a non-empty cache — tree verify, AR steps — quantise the activations of the
-                                # four per-layer GEMMs too (Ops.linear a8=True); the prefill, like the product's PyTorch prefill, does not
+                                # q/k/v, gate/up and down projections too (Ops.linear a8=True; o_proj keeps bf16 activations); the prefill, like the product's PyTorch prefill, does not
 
     @property
     def lm_head(self):
@@ -544,7 +544,8 @@ class TargetLlama:
                 kk = np.repeat(kk, rep, axis=0)
                 vv = np.repeat(vv, rep, axis=0)
             a = attn(q, kk, vv, allow).transpose(1, 0, 2).reshape(S, c.hidden_size)
-            x = o.add(x, o.linear(a, self.w[p + "self_attn.o_proj.weight"], **a8))
+            x = o.add(x, o.linear(a, self.w[p + "self_attn.o_proj.weight"]))  # (W8A8 leaves o_proj on bf16 activations: 5 % of a layer's weight
+                                                                              #  bytes, and its input has no producer that sees a whole row)
             h = o.rmsnorm(x, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
             g = o.linear(h, self.w[p + "mlp.gate_proj.weight"], **a8)
             u = o.linear(h, self.w[p + "mlp.up_proj.weight"], **a8)

@@ -1,4 +1,4 @@
-"""W8A8 (round 4): fp8 (e4m3) weights AND fp8 activations for the target's four per-layer GEMMs, multiplied on v_mfma_scale_f32_32x32x64_f8f6f4 —
+"""W8A8 (round 4): fp8 (e4m3) weights AND fp8 activations for the target's q|k|v, gate|up and down GEMMs (o_proj keeps bf16 activations), multiplied on v_mfma_scale_f32_32x32x64_f8f6f4 —
 what BASELINE config 5 literally names ("fp8 weights (CDNA4 fp8 MFMA)").  The reference has no fp8 path; the arithmetic is defined by the
 oracle's `Ops.linear(..., a8=True)` (per-row dynamic scale sx = max|x| / 448, q = e4m3(x / sx), exact products, fp32 accumulation) and SURVEY.md
 §7.1 step 8's bar: same accepted tokens as that oracle / documented divergence (tests/test_fp8_activation_study.py prices W8A8 against W8A16).

@@ -191,7 +191,7 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #endif
 }
 
-// ---- fp8 ACTIVATIONS (round 4, W8A8: BASELINE config 5 "CDNA4 fp8 MFMA"): the target's four per-layer GEMMs can take their activations in
+// ---- fp8 ACTIVATIONS (round 4, W8A8: BASELINE config 5 "CDNA4 fp8 MFMA"): the target's q|k|v, gate|up and down GEMMs can take their activations in
 // e4m3 as well, one dynamic scale per row (token): x ~ sx[m] * q[m, k].  The GEMM then runs on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the
 // bf16 rate, 64 k per instruction = two 1 KiB weight tiles) with unit block scales, and the epilogue multiplies the fp32 accumulator by
 // wscale[n] * sx[m].  A different arithmetic from W8A16 (tests/test_fp8_activation_study.py prices it): its own oracle mode, its own tests.

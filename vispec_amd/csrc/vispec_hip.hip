@@ -103,7 +103,7 @@ struct vispec_ctx {
     }
   };
   GraphSlot g_verify, g_draft, g_ar, g_cverify, g_cdraft, g_car;
-  bool a8 = false;               // fp8 ACTIVATIONS for the target's four per-layer GEMMs (needs fp8 weights): vispec_set_fp8_activations
+  bool a8 = false;               // fp8 ACTIVATIONS for the target's q|k|v, gate|up and down GEMMs (needs fp8 weights): vispec_set_fp8_activations
   unsigned char* xq = nullptr;   // [128 rows][max(D, H * 128, I)] e4m3 codes of the GEMM input at hand (stream-ordered scratch)
   float* sx = nullptr;           // [128] their per-row scales
   float* u_over = nullptr;  // tests only: uniforms of the sampling accept taken from here (vispec_set_uniform_override_host)
@@ -1361,7 +1361,7 @@ extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
-// fp8 (e4m3) ACTIVATIONS for the target's four per-layer GEMMs of the verify / AR forwards (BASELINE config 5, "CDNA4 fp8 MFMA"): each GEMM
+// fp8 (e4m3) ACTIVATIONS for the target's q|k|v, gate|up and down GEMMs (o_proj stays W8A16) of the verify / AR forwards (BASELINE config 5, "CDNA4 fp8 MFMA"): each GEMM
 // input is quantised per row (dynamic scale) and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4.  Needs fp8 target weights; the lm_head,
 // the draft and the PyTorch prefill keep bf16 activations.  Set it on every ctx of a cohort.  (Cached graphs are dropped.)
 extern "C" int vispec_set_fp8_activations(vispec_ctx* ctx, int on) {
@@ -1802,8 +1802,9 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       rq[t].kc = co.c[t]->target_kv + (size_t)(2 * l) * slab;
       rq[t].vc = co.c[t]->target_kv + (size_t)(2 * l + 1) * slab;
     }
-    // fp8 activations (vispec_set_fp8_activations, fp8 weights only): each of the layer's four GEMM inputs is quantised row by row to e4m3
-    // (quant_rows_e4m3_kernel) and multiplied on the fp8 MFMA; X then points at the codes (pitch in 2-byte units) and `xscale` at the row scales
+    // fp8 activations (vispec_set_fp8_activations, fp8 weights only): the inputs of q|k|v, gate|up and down_proj are quantised row by row to
+    // e4m3 (by the reduce + norm that produces them; quant_rows_e4m3_kernel for the first layer's input and the SwiGLU output) and multiplied on
+    // the fp8 MFMA; X then points at the codes (pitch in 2-byte units) and `xscale` at the row scales
     const bool a8 = ctx->a8 && w.sqkv != nullptr;
     const int MR = co.M(T);  // activation rows of the launch (a cohort: 32 (n - 1) + T, dead rows included)
     auto quant = [&](const bf16_t* X, int K_) {
@@ -1832,12 +1833,10 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       o.Y = ctx->xa; o.ldy = D; o.R = ctx->xa; o.ldr = D; o.norm_w = w.ln2; o.normed = ctx->xn; o.ldn = D; o.eps = c.rms_eps;
       o.wscale = (const float*)w.so;
       o.m_tile = co.mt(T);
-      if (a8) {
-        if (quant(ctx->attn_o, H * 128)) return -1;
-        o.xscale = ctx->sx;
-        o.q8 = ctx->xq; o.sx8 = ctx->sx;  // the reduce + norm leaves gate|up's input quantised (it runs after the GEMM has read xq / sx)
-        if (launch_gemm_ex(ctx, s, ctx->xq, H * 128 / 2, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
-      } else if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
+      // W8A8: o_proj itself stays on bf16 activations (W8A16: the attention output is merged per head — no kernel sees a whole row to
+      // quantise it — and o_proj is 5 % of the layer's weight bytes); its reduce + norm leaves gate|up's input quantised
+      if (a8) { o.q8 = ctx->xq; o.sx8 = ctx->sx; }
+      if (launch_gemm_ex(ctx, s, ctx->attn_o, H * 128, w.wo, nullptr, co.M(T), D, H * 128, EPI_RESIDUAL, o)) return -1;
     }
     if (a8) {
       GemmOut o;

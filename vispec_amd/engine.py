@@ -262,7 +262,7 @@ class Engine:
         # W32-packed copies of every streamed GEMM weight (the row-major originals stay for the PyTorch prefill)
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
         self.target_weight_dtype = target_weight_dtype
-        # "fp8a8" (round 4): fp8 weights AND fp8 (e4m3, per-row dynamic scale) activations for the target's four per-layer GEMMs of the
+        # "fp8a8" (round 4): fp8 weights AND fp8 (e4m3, per-row dynamic scale) activations for the target's q|k|v, gate|up and down GEMMs (not o_proj) of the
         # verify / AR forwards, multiplied on the fp8 MFMA (vispec_set_fp8_activations); "fp8" keeps bf16 activations (W8A16)
         fp8_w = target_weight_dtype in ("fp8", "fp8a8")
         if fp8_w:
