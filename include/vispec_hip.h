@@ -115,6 +115,10 @@ int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, c
    + residual and the fused RMSNorm of the split-K reduce (o_proj / down_proj form), written to `normed` (ld N).  No reference counterpart. */
 int vispec_gemm_fp8a8(vispec_ctx*, void* stream, const void* X, int ldx, const void* P8, const void* wscale_f32, const void* bias, void* Y, int ldy,
                       const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps);
+/* Row-wise e4m3 quantisation of bf16 activations X[M, K] (W8A8: sx[m] = max|x[m, :]| / 448, Q = e4m3(x / sx), uint8 codes, fp32 scales):
+   the PyTorch prefill of an fp8a8 model quantises its q|k|v, gate|up and down inputs with it and multiplies on the library's fp8 x fp8 GEMM
+   (torch._scaled_mm with row-wise scales).  No reference counterpart.  ctx may be NULL. */
+int vispec_quant_rows_e4m3(vispec_ctx*, void* stream, const void* X, int ldx, void* Q_u8, int ldq, void* sx_f32, int M, int K);
 /* test hook: the W8A8 scratch of the ctx as the last quantisation left it — e4m3 codes [rows][K] (uint8) and per-row scales (fp32), device to
    device on `stream`.  After vispec_gemm_fp8a8 with norm_w: the quantised `normed` rows, written by the split-K reduce itself (the fused form of
    the quantisation pass that target_forward uses for the q|k|v and gate|up inputs). */

@@ -497,8 +497,8 @@ class TargetLlama:
             cos, sin = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
         self.cos, self.sin = np.asarray(cos, np.float32), np.asarray(sin, np.float32)
         self.tree_mask = None  # [T,T] bool, installed by the loop (spec_model_ours.py:486-489)
-        self.a8_decode = False  # True (fp8 weights only): forwards on a non-empty cache — tree verify, AR steps — quantise the activations of the
-                                # q/k/v, gate/up and down projections too (Ops.linear a8=True; o_proj keeps bf16 activations); the prefill, like the product's PyTorch prefill, does not
+        self.a8_decode = False  # True (fp8 weights only; the name is historical): every forward — prefill, tree verify, AR steps — quantises the
+                                # activations of the q/k/v, gate/up and down projections too (Ops.linear a8=True; o_proj keeps bf16 activations)
 
     @property
     def lm_head(self):
@@ -526,7 +526,7 @@ class TargetLlama:
             T = self.tree_mask.shape[-1]
             allow[-T:, -T:] &= self.tree_mask.astype(bool)
         rep = c.num_heads // c.num_kv_heads
-        a8 = dict(a8=True) if (self.a8_decode and n_past > 0) else {}
+        a8 = dict(a8=True) if self.a8_decode else {}
         for i in range(c.num_layers):
             p = f"model.layers.{i}."
             h = o.rmsnorm(x, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)

@@ -127,6 +127,32 @@ def test_fp8a8_cohort_rows_are_bit_identical_to_the_single_request_rows(lib, eng
     eng8.set_wide_row_blocks(4)
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(200, 4608, 3584, True), (75, 1408, 704, False), (33, 512, 18944, False)])
+def test_fp8a8_prefill_linear_against_the_oracle(lib, M, N, K, bias):
+    """The PREFILL form of the W8A8 linears (vispec_amd/model/target.py: scaled_linear(q8=...)): activations quantised by the library's kernel
+    (vispec_quant_rows_e4m3 == the decode path's), product on the library's fp8 x fp8 GEMM (torch._scaled_mm, row-wise scales) -> the oracle's
+    Ops.linear(a8=True); the quantisation itself exact (codes and scales)."""
+    from vispec_amd.engine import quantize_fp8
+    from vispec_amd.model.target import scaled_linear
+    rng = np.random.default_rng(M + N + K)
+    w = synth.bf16_grid(rng.standard_normal((N, K), dtype=np.float32) * 0.05)
+    x = synth.bf16_grid(rng.standard_normal((M, K), dtype=np.float32))
+    b = synth.bf16_grid(rng.standard_normal(N, dtype=np.float32) * 0.1) if bias else None
+    q_u8, sc = quantize_fp8(tb(w))
+    codes = q_u8.view(torch.float8_e4m3fn).float().cpu().numpy()
+    X = tb(x)
+    qx = torch.zeros(M, K, dtype=torch.uint8, device=dev())
+    sx = torch.zeros(M, dtype=torch.float32, device=dev())
+    L.check(lib.vispec_quant_rows_e4m3(None, stream(), p(X), K, p(qx), K, p(sx), M, K))
+    torch.cuda.synchronize()
+    want_sx = (np.maximum(np.abs(x).max(axis=-1, keepdims=True), np.float32(1e-12)) / np.float32(448.0)).astype(np.float32)
+    np.testing.assert_array_equal(sx.cpu().numpy(), want_sx[:, 0])
+    np.testing.assert_array_equal(qx.view(torch.float8_e4m3fn).float().cpu().numpy(), vo.e4m3_round((x / want_sx).astype(np.float32)))
+    y = scaled_linear(X, q_u8.view(torch.float8_e4m3fn).to(torch.bfloat16), None if b is None else tb(b), sc, q_u8)
+    want = vo.Ops(bf16=True).linear(x, (codes, sc.cpu().numpy()), b, a8=True)
+    assert_bf16_close(fn(y), want, min_exact=0.9, ulps=2, scale=np.abs(want).max(axis=-1, keepdims=True) / 16)
+
+
 def _a8_model():
     """The Qwen2.5-VL-shaped tiny model of tests/test_loop_gpu.py with fp8 weights, switched to fp8 activations (product and oracle alike)."""
     sm, ot, od, IMG = build_qwen_fp8()

@@ -265,11 +265,17 @@ def test_full_width_two_layer_model_against_the_oracle_floats(kind):
     lg, hid = ot.forward(pkv, inputs_embeds=emb, position_ids=pos3)
     lg32, hid32 = ot32.forward(pkv32, inputs_embeds=emb, position_ids=pos3)
     tol = lambda want: 2.0 ** -6 * float(np.abs(want).max())
+    a8 = bool(Wd.get("a8"))  # W8A8: element-wise bars cannot hold between two correct evaluations (see step 3): mean errors + the triangulation
     got_h = hidden.float().cpu().numpy()
-    np.testing.assert_allclose(got_h, hid, rtol=0, atol=tol(hid))
     kvd = eng.target_kv.float().cpu().numpy()  # [2*NL, 1, H_kv, max_pos, hd]
     want_kv = pkv_data[0][:, 0, :, :L]
-    np.testing.assert_allclose(kvd[:, 0, :, :L], want_kv, rtol=0, atol=tol(want_kv))
+    if not a8:
+        np.testing.assert_allclose(got_h, hid, rtol=0, atol=tol(hid))
+        np.testing.assert_allclose(kvd[:, 0, :, :L], want_kv, rtol=0, atol=tol(want_kv))
+    else:
+        assert np.abs(got_h - hid).mean() <= 3e-2 * np.abs(hid).max() and np.abs(kvd[:, 0, :, :L] - want_kv).mean() <= 3e-2 * np.abs(want_kv).max()
+        e_p, e_o = np.abs(got_h - hid32), np.abs(hid - hid32)  # the prefill's own triangulation against the fp32 evaluation
+        assert e_p.mean() <= 1.25 * e_o.mean() and e_p.max() <= 1.5 * e_o.max(), "W8A8 prefill further from fp32 truth than the oracle's bf16 evaluation"
     first_tok = int(first.cpu()[0])
     top2 = np.sort(lg[-1])[-2:]
     if top2[1] - top2[0] > tol(lg[-1]):  # the first token is unambiguous at the test's tolerance
@@ -291,7 +297,6 @@ def test_full_width_two_layer_model_against_the_oracle_floats(kind):
     ot.tree_mask = ot32.tree_mask = tmask
     want_logits, want_hidden = ot.forward(pkv, input_ids=tok, position_ids=pos + L + delta)
     true_logits, true_hidden = ot32.forward(pkv32, input_ids=tok, position_ids=pos + L + delta)
-    a8 = bool(Wd.get("a8"))
     if not a8:
         np.testing.assert_allclose(got_hidden, want_hidden, rtol=0, atol=tol(want_hidden))
         np.testing.assert_allclose(got_logits, want_logits, rtol=0, atol=tol(want_logits))

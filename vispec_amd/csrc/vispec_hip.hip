@@ -1047,6 +1047,14 @@ extern "C" int vispec_gemm_fp8a8(vispec_ctx* ctx, void* stream, const void* X, i
   if (norm_w && (size_t)N <= kmax) { o.q8 = ctx->xq; o.sx8 = ctx->sx; }  // as target_forward: the normed rows leave the reduce quantised as well
   return launch_gemm_ex(ctx, s, ctx->xq, K / 2, P8, bias, rows, N, K, epilogue, o);
 }
+// Row-wise e4m3 quantisation of an activation matrix (the W8A8 arithmetic: sx[m] = max|x[m, :]| / 448, q = e4m3(x / sx)) into caller buffers:
+// what the PyTorch prefill of an fp8a8 model feeds torch._scaled_mm (the library's fp8 x fp8 GEMM) with — the same kernel as the decode path's
+extern "C" int vispec_quant_rows_e4m3(vispec_ctx*, void* stream, const void* X, int ldx, void* Q, int ldq, void* sx, int M, int K) {
+  if (!X || !Q || !sx || M < 1 || K < 8 || K % 8 || ldx < K || ldq < K || ldx % 8 || ldq % 8) return fail("quant_rows_e4m3: K, ldx, ldq multiples of 8, ld >= K");
+  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, (unsigned char*)Q, ldq, (float*)sx, K);
+  KCHK();
+  return 0;
+}
 // test hook: the ctx's W8A8 scratch (e4m3 codes [rows][K] and per-row scales) as the last quantisation left it — copied on `stream`
 extern "C" int vispec_a8_scratch_read(vispec_ctx* ctx, void* stream, void* codes_out, void* scales_out, int rows, int K) {
   if (!ctx || !ctx->xq || rows < 1 || rows > 128 || K < 1) return fail("a8_scratch_read: bad arguments");

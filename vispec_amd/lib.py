@@ -83,6 +83,7 @@ SIGNATURES = {
     "vispec_cohortn_draft_round": (c_int, [P, c_int, P]),
     "vispec_gemm_fp8a8": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float]),
     "vispec_a8_scratch_read": (c_int, [P, P, P, P, c_int, c_int]),
+    "vispec_quant_rows_e4m3": (c_int, [P, P, P, c_int, P, c_int, P, c_int, c_int]),
     "vispec_gemm_cohort": (c_int, [P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vispec_set_rope_delta": (c_int, [P, P, c_int]),
     "vispec_set_sampling": (c_int, [P, c_float, C.c_ulonglong]),

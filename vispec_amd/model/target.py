@@ -103,12 +103,26 @@ def _sdpa_try(q, k, v, gqa):
             return F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=gqa)
 
 
-def scaled_linear(x, w, b=None, scale=None):
+def scaled_linear(x, w, b=None, scale=None, q8=None):
     """nn.Linear on a row-major weight.  scale != None: `w` holds fp8 (e4m3) codes as bf16 and `scale` their per-output-channel factors —
-    bf16( (x . w^T) * scale + b ) on an fp32 accumulator, the rounding points of the library's W8A16 GEMMs (kernels.h epilogues)."""
+    bf16( (x . w^T) * scale + b ) on an fp32 accumulator, the rounding points of the library's W8A16 GEMMs (kernels.h epilogues).
+    q8 != None (W8A8, target_weight_dtype "fp8a8"): the same codes as a row-major uint8 tensor; the activations are quantised row by row
+    (vispec_quant_rows_e4m3: the decode path's kernel) and the product runs on the fp8 MFMA through the library's fp8 x fp8 GEMM
+    (torch._scaled_mm, row-wise scales): bf16( (q_x . q_w^T) * sx[m] * scale[n] + b ) — oracle: Ops.linear(a8=True)."""
     if scale is None:
         return F.linear(x, w, b)
     x2 = x.reshape(-1, x.shape[-1])
+    if q8 is not None:
+        lib = L.load()
+        M, K = x2.shape
+        x2 = x2.contiguous()
+        qx = torch.empty(M, K, dtype=torch.uint8, device=x2.device)
+        sx = torch.empty(M, 1, dtype=torch.float32, device=x2.device)
+        L.check(lib.vispec_quant_rows_e4m3(None, C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream), C.c_void_p(x2.data_ptr()), K,
+                                           C.c_void_p(qx.data_ptr()), K, C.c_void_p(sx.data_ptr()), M, K))
+        out = torch._scaled_mm(qx.view(torch.float8_e4m3fn), q8.view(torch.float8_e4m3fn).t(), scale_a=sx, scale_b=scale.reshape(1, -1).float(),
+                               bias=None if b is None else b.to(torch.bfloat16), out_dtype=torch.bfloat16)
+        return out.reshape(*x.shape[:-1], q8.shape[0])
     acc = torch.mm(x2, w.t(), out_dtype=torch.float32)
     N = w.shape[0]
     if acc.is_cuda and N % 8 == 0 and x.dtype == torch.bfloat16:  # scale, bias and the bf16 rounding in one pass (vispec_scale_bias_cast)
@@ -251,9 +265,12 @@ class TargetLM:
 
         x = x.clone() if x.data_ptr() == inputs_embeds.data_ptr() else x  # the residual stream is updated in place
         y = None  # the previous layer's down_proj output, added to the residual stream by the next norm's launch
+        # W8A8 (fp8a8): the q|k|v, gate|up and down inputs are quantised row by row like the decode forwards' and multiplied on the fp8 MFMA
+        a8 = getattr(eng, "target_weight_dtype", "bf16") == "fp8a8" and hasattr(self.w, "codes8")
         for i, lw in enumerate(self.w.layers):
+            c8 = self.w.codes8[i] if a8 else {}
             h = rmsnorm(x, lw["ln1"]) if y is None else add_rmsnorm(x, y, lw["ln1"])
-            qkv = scaled_linear(h, lw["wqkv"], lw["bqkv"], lw.get("wqkv_scale"))  # [L, QKV]
+            qkv = scaled_linear(h, lw["wqkv"], lw["bqkv"], lw.get("wqkv_scale"), c8.get("wqkv"))  # [L, QKV]
             # rotary at position m (bf16 rounding points of the reference) on q in place; k (rotated) and v -> cache rows [0, L)
             L.check(lib.vispec_rope_append(eng.h, st, p(qkv), Ln, H, Hk, hd, p(cos), p(sin), None, None, p(kv[2 * i]), p(kv[2 * i + 1]), S, None))
             if native_attn:  # causal attention of the L rows over the cache rows just written: the library's kernel (no [H, L, L] tensor,
@@ -265,10 +282,10 @@ class TargetLM:
                 q = qkv[:, : H * hd].view(Ln, H, hd).transpose(0, 1)
                 a = _sdpa(q[None], kv[2 * i, :, :, :Ln], kv[2 * i + 1, :, :, :Ln], H != Hk)[0].transpose(0, 1).reshape(Ln, H * hd)
             h = add_rmsnorm(x, scaled_linear(a, lw["wo"], None, lw.get("wo_scale")), lw["ln2"])
-            gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"))  # [L, 2I]
+            gu = scaled_linear(h, lw["wgu"], None, lw.get("wgu_scale"), c8.get("wgu"))  # [L, 2I]
             act = torch.empty(Ln, c.intermediate_size, dtype=self.dtype, device=x.device)
             L.check(lib.vispec_silu_mul(eng.h, st, p(gu), gu.shape[1], p(act), c.intermediate_size, Ln, c.intermediate_size))
-            y = scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"))
+            y = scaled_linear(act, lw["wdown"], None, lw.get("wdown_scale"), c8.get("wdown"))
         hidden = rmsnorm(x, self.w.norm) if y is None else add_rmsnorm(x, y, self.w.norm)
         logits = scaled_linear(hidden if all_logits else hidden[-1:], self.w.lm_head, None, getattr(self.w, "lm_head_scale", None)).float()
         return logits, hidden.contiguous()
