@@ -263,7 +263,8 @@ class Engine:
         GEMM_T = ("wqkv", "wo", "wgu", "wdown")
         self.target_weight_dtype = target_weight_dtype
         # "fp8a8" (round 4): fp8 weights AND fp8 (e4m3, per-row dynamic scale) activations for the target's q|k|v, gate|up and down GEMMs (not o_proj) of the
-        # verify / AR forwards, multiplied on the fp8 MFMA (vispec_set_fp8_activations); "fp8" keeps bf16 activations (W8A16)
+        # verify / AR forwards (vispec_set_fp8_activations) and of the PyTorch prefill (model/target.py: torch._scaled_mm), multiplied on the fp8 MFMA;
+        # "fp8" keeps bf16 activations (W8A16)
         fp8_w = target_weight_dtype in ("fp8", "fp8a8")
         if fp8_w:
             # BASELINE config 5: fp8 (e4m3, per-output-channel scales) target weights.  The row-major copies that the PyTorch prefill
