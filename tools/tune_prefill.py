@@ -34,17 +34,44 @@ for name, (D, QKV, I, bias, Ls) in MODELS.items():
         shapes += [(name, "qkv", L, QKV, D, bias), (name, "o_proj", L, D, D, False), (name, "gate_up", L, 2 * I, D, False), (name, "down", L, D, I, False)]
 
 
+_calls = {}
+
+
+def run(x, w, b):
+    if not FP8:
+        return F.linear(x, w, b)
+    key = (x.data_ptr(), w.data_ptr())
+    if key not in _calls:
+        _calls[key] = fp8_call(x, w, b)
+    return _calls[key]()
+
+
 def timed(x, w, b, iters=20):
     for _ in range(3):
-        F.linear(x, w, b)
+        run(x, w, b)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        F.linear(x, w, b)
+        run(x, w, b)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
+
+
+FP8 = os.environ.get("FP8", "0") == "1"  # FP8=1 python tools/tune_prefill.py /tmp/fp8.csv: ONLY the W8A8 prefill's fp8 x fp8 GEMMs (torch._scaled_mm,
+# row-wise scales: vispec_amd/model/target.py scaled_linear(q8=...)) of the Qwen2.5-VL-7B shapes, into a file of their own (its entry lines are
+# appended to the committed table by hand: the bf16 entries stay as recorded)
+if FP8:
+    shapes = [(n, k, L, N, K, b) for (n, k, L, N, K, b) in shapes if n == "qwen7b" and k != "o_proj"]
+
+
+def fp8_call(x, w, b):
+    sx = (x.float().abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / 448.0)
+    sw = (w.float().abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / 448.0)
+    qx, qw = (x.float() / sx).to(torch.float8_e4m3fn), (w.float() / sw).to(torch.float8_e4m3fn)
+    swt = sw.t().contiguous()
+    return lambda: torch._scaled_mm(qx, qw.t(), scale_a=sx, scale_b=swt, bias=b, out_dtype=torch.bfloat16)
 
 
 tensors = {}
@@ -60,7 +87,7 @@ tn.set_max_tuning_duration(30)      # ms per candidate solution
 tn.set_max_tuning_iterations(20)
 t0 = time.time()
 for k, v in tensors.items():
-    F.linear(*v)                    # first call of a shape tunes it
+    run(*v)                         # first call of a shape tunes it
 torch.cuda.synchronize()
 t_tune = time.time() - t0
 tn.tuning_enable(False)
