@@ -83,7 +83,8 @@ class SpecModel:
         tcfg, target_sd, tokenizer = load_target_dir(base_model_path)
         dcfg, draft_sd = load_draft_dir(spec_model_path, tcfg)
         model = cls.from_weights(tcfg, dcfg, target_sd, draft_sd, device=device, total_token=60 if total_token == -1 else total_token,
-                                 depth=depth, top_k=top_k, num_q=num_q, tokenizer=tokenizer)
+                                 depth=depth, top_k=top_k, num_q=num_q, tokenizer=tokenizer,
+                                 target_weight_dtype=kwargs.get("target_weight_dtype", "bf16"))  # "fp8" / "fp8a8": quantised at load (engine.py)
         if tcfg.architectures[0] not in ("LlamaForCausalLM", "Qwen2ForCausalLM"):
             # vision tower + projector of the checkpoint (PyTorch-ROCm, HF modules): SURVEY §8 A2
             from .vision import HFVisionFrontEnd
