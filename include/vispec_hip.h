@@ -269,6 +269,12 @@ int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stream);
 int vispec_get_state_host(vispec_ctx*, void* stream, int* out8_host);
 /* ... of every request of a cohort (leader first) with one synchronisation: out = n x 8 ints */
 int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void* stream, int* out8n_host);
+/* vispec_cohort_get_state_host in two halves for a host loop with one round of lookahead (no reference counterpart: the reference's loop
+   synchronises ~10 times per round, spec_model_ours.py:478-582): `enqueue` snapshots every request's state into pinned slot 0 / 1 in stream
+   order and records an event — the next round is launched right behind it; `wait` blocks on that event only and unpacks n x 8 ints as above.
+   A request that finished in the snapshot's round is frozen on the device, so the round already in flight leaves it untouched. */
+int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void* stream, int slot);
+int vispec_cohort_state_wait(vispec_ctx* const* ctxs, int n, int slot, int* out8n_host);
 /* (best_candidate, accept_length) of the last accept — what evaluate_posterior returns (utils.py:451,493); blocking */
 int vispec_get_last_accept_host(vispec_ctx*, void* stream, int* out2_host);
 /* Blocking copies of device-side logs/buffers, for the API mirror and the tests. */

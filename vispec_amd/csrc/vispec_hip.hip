@@ -53,6 +53,8 @@ struct vispec_ctx {
   bf16_t *xc, *emb_shift, *ad_kv, *ad_out, *ad_tmp, *pf_t1;  // prefill-only scratch
   int *top_idx, *pos_c, *idx_tmp, *idx_img, *scratch_int;
   int* h_pin = nullptr;  // pinned host staging for the prefill's index lists [3 * draft_max_pos]
+  void* h_state = nullptr;       // pinned: two DevState snapshots (vispec_cohort_state_enqueue / _wait: the pipelined round loop)
+  hipEvent_t st_ev[2] = {nullptr, nullptr};  // (leader) one event per snapshot slot
   float* top_logp;
   unsigned long long* causal_mask;  // [64] row i sees tail keys 0..i
   TreeBufs tb{};
@@ -286,6 +288,9 @@ static void ctx_free(vispec_ctx* ctx) {
   for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  for (hipEvent_t e : ctx->st_ev)
+    if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
@@ -2177,6 +2182,33 @@ extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int t = 0; t < n; ++t) {
     const DevState& h = *reinterpret_cast<const DevState*>(ctxs[t]->h_pin);
+    int* o = out + 8 * t;
+    o[0] = h.n_ctx; o[1] = h.new_token; o[2] = h.rounds; o[3] = h.done; o[4] = h.accept_len;
+    o[5] = h.next_token; o[6] = h.draft_len; o[7] = h.n_leaf;
+  }
+  return 0;
+}
+// The same in two halves, for a host loop that keeps one round of lookahead (model/spec_model_ours.py: specgenerate_stream): `enqueue` copies
+// every request's DevState into pinned snapshot slot `slot` (0 / 1) in stream order and records the slot's event — the next round can be
+// launched right behind it; `wait` blocks on that event only (not on the stream, which is already running the next round) and unpacks.
+extern "C" int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void* stream, int slot) {
+  if (!ctxs || n < 1 || n > 4 || slot < 0 || slot > 1) return fail("cohort_state_enqueue: 1..4 contexts, slot 0 or 1");
+  for (int t = 0; t < n; ++t) {
+    if (!ctxs[t]) return fail("null ctx");
+    if (!ctxs[t]->h_state && hipHostMalloc(&ctxs[t]->h_state, 2 * sizeof(DevState)) != hipSuccess) return fail("hipHostMalloc failed");
+    HIPCHK(hipMemcpyAsync(static_cast<DevState*>(ctxs[t]->h_state) + slot, ctxs[t]->st, sizeof(DevState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  }
+  vispec_ctx* lead = ctxs[0];
+  if (!lead->st_ev[slot]) HIPCHK(hipEventCreateWithFlags(&lead->st_ev[slot], hipEventDisableTiming));
+  HIPCHK(hipEventRecord(lead->st_ev[slot], (hipStream_t)stream));
+  return 0;
+}
+extern "C" int vispec_cohort_state_wait(vispec_ctx* const* ctxs, int n, int slot, int* out) {
+  if (!ctxs || !out || n < 1 || n > 4 || slot < 0 || slot > 1 || !ctxs[0] || !ctxs[0]->st_ev[slot]) return fail("cohort_state_wait: nothing enqueued in this slot");
+  HIPCHK(hipEventSynchronize(ctxs[0]->st_ev[slot]));
+  for (int t = 0; t < n; ++t) {
+    if (!ctxs[t] || !ctxs[t]->h_state) return fail("null ctx");
+    const DevState& h = static_cast<const DevState*>(ctxs[t]->h_state)[slot];
     int* o = out + 8 * t;
     o[0] = h.n_ctx; o[1] = h.new_token; o[2] = h.rounds; o[3] = h.done; o[4] = h.accept_len;
     o[5] = h.next_token; o[6] = h.draft_len; o[7] = h.n_leaf;

@@ -494,6 +494,24 @@ class Engine:
         k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
         return [dict(zip(k, list(out[8 * t:8 * t + 8]))) for t in range(len(hs))]
 
+    def cohort_states_enqueue(self, members, slot: int):
+        """First half of cohort_states for a loop with one round of lookahead: snapshot every request's state into pinned slot 0 / 1 in
+        stream order (no synchronisation); the next round may be launched right behind it."""
+        hs = [self] + list(members)
+        if any(x.h is None for x in hs):
+            raise L.VispecError("cohort_states_enqueue: a context of this cohort was closed")
+        arr = (C.c_void_p * len(hs))(*[x.h.value for x in hs])
+        L.check(self.lib.vispec_cohort_state_enqueue(arr, len(hs), self._stream(), int(slot)))
+
+    def cohort_states_wait(self, members, slot: int):
+        """Second half: wait for that snapshot only (not for the stream) and return the states as cohort_states does."""
+        hs = [self] + list(members)
+        arr = (C.c_void_p * len(hs))(*[x.h.value for x in hs])
+        out = (C.c_int * (8 * len(hs)))()
+        L.check(self.lib.vispec_cohort_state_wait(arr, len(hs), int(slot), out))
+        k = ("n_ctx", "new_token", "rounds", "done", "accept_len", "next_token", "draft_len", "n_leaf")
+        return [dict(zip(k, list(out[8 * t:8 * t + 8]))) for t in range(len(hs))]
+
     def last_accept(self):
         """(best_candidate, accept_length) of the last accept."""
         out = (C.c_int * 2)()

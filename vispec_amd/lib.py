@@ -94,6 +94,8 @@ SIGNATURES = {
     "vispec_cohortn_ar_step": (c_int, [P, c_int, P]),
     "vispec_get_state_host": (c_int, [P, P, P]),
     "vispec_cohort_get_state_host": (c_int, [P, c_int, P, P]),
+    "vispec_cohort_state_enqueue": (c_int, [P, c_int, P, c_int]),
+    "vispec_cohort_state_wait": (c_int, [P, c_int, c_int, P]),
     "vispec_get_last_accept_host": (c_int, [P, P, P]),
     "vispec_get_tokens_host": (c_int, [P, P, P, c_int]),
     "vispec_get_accept_log_host": (c_int, [P, P, P, c_int]),

@@ -593,16 +593,35 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
         outs[slot[t]] = (toks, st["new_token"], rnd[t] - 1, accs[t])
         slot[t] = None
 
+    # One round of LOOKAHEAD (round 4; VISPEC_STREAM_LOOKAHEAD=0 restores the lockstep loop): round k + 1 is launched before round k's states are
+    # read, so the stream never waits for the host between rounds (state snapshots travel through two pinned slots in stream order:
+    # Engine.cohort_states_enqueue / _wait).  A request that finished in round k is frozen on the device (EOS, budget and cache limits are
+    # decided there: tree_kernels.h), so the round already in flight leaves it untouched; its slot rides along idle for that one round and the
+    # refill joins from the round after.  valid_from[t] = the first launched round whose snapshot describes slot t's CURRENT request.
+    import os
+    lookahead = os.environ.get("VISPEC_STREAM_LOOKAHEAD", "1") != "0"
+    valid_from = [0] * n
+    k_enq = k_done = 0
+
+    def launch():
+        nonlocal k_enq
+        lead.engine.cohort_round(member_engines, -1)
+        lead.engine.cohort_states_enqueue(member_engines, k_enq & 1)
+        k_enq += 1
+
     for t in range(n):
         start(t)
     lockstep = request_rounds = 0
+    launch()
     while any(i is not None for i in slot):
-        lead.engine.cohort_round(member_engines, -1)
-        states = lead.engine.cohort_states(member_engines)  # the round's ONE host synchronisation
+        if lookahead and k_enq - k_done < 2:
+            launch()
+        states = lead.engine.cohort_states_wait(member_engines, k_done & 1)  # waits for that round's snapshot only
+        k, k_done = k_done, k_done + 1
         lockstep += 1
         for t in range(n):
-            if slot[t] is None:
-                continue  # an idle slot (the queue is empty): its frozen rows ride along
+            if slot[t] is None or k < valid_from[t]:
+                continue  # an idle slot (the queue is empty / its new request joins a later round): its frozen rows ride along
             st = states[t]
             rnd[t] += 1
             request_rounds += 1
@@ -616,6 +635,9 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
         for t in range(n):
             if slot[t] is None and nxt < R:
                 start(t)
+                valid_from[t] = k_enq  # it is part of the rounds launched from now on
+        if k_enq == k_done and any(i is not None for i in slot):
+            launch()
     if stats is not None:
         stats.update(rounds=lockstep, request_rounds=request_rounds)
     return outs
