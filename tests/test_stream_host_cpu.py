@@ -1,0 +1,123 @@
+"""Host logic of the continuous-batching loop (vispec_amd/model/spec_model_ours.py: specgenerate_stream) on a SIMULATED device — no GPU, no
+library: the loop launches round k + 1 before it reads round k's states (one round of lookahead), so what it must get right is bookkeeping:
+every request served exactly once and returned in request order with the tuple it would produce alone; a snapshot taken before a refilled
+slot's new request joined is never attributed to that request; a finished request's frozen round is not counted; lookahead on and off agree.
+The fake engines below execute their operations strictly in enqueue ("stream") order, like the real ones."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from vispec_amd.model import spec_model_ours as smo  # noqa: E402
+
+
+class FakeStream:
+    """The lane's stream: a FIFO of operations; `run_until(pred)` executes in order up to and including the first op satisfying pred."""
+
+    def __init__(self, n):
+        self.ops, self.n = [], n
+        self.ctx = [dict(done=1, n_ctx=0, new_token=0, accept_len=0, rounds=0, tokens=[], req=None) for _ in range(n)]
+        self.snap, self.ready = {}, {0: 0, 1: 0}  # ready[slot]: snapshots of that slot executed and not yet waited for
+        self.rounds_executed = 0
+
+    def _exec(self, op):
+        if op[0] == "begin":
+            _, t, req = op
+            self.ctx[t] = dict(done=0, n_ctx=req["L"], new_token=0, accept_len=0, rounds=0, tokens=list(range(req["L"])), req=req)
+        elif op[0] == "round":
+            self.rounds_executed += 1
+            for c in self.ctx:
+                if c["done"]:
+                    continue  # frozen: a finished request of a cohort (tree_kernels.h)
+                r = c["req"]
+                a = (r["id"] * 7 + c["rounds"] * 3) % 4  # this request's accept length in this round: a function of (request, round) only
+                c["accept_len"] = a
+                c["tokens"] += [1000 * r["id"] + c["new_token"] + i for i in range(a + 1)]
+                c["new_token"] += a + 1
+                c["n_ctx"] += a + 1
+                c["rounds"] += 1
+                if r["eos_round"] is not None and c["rounds"] == r["eos_round"]:
+                    c["done"] |= 1
+                if c["new_token"] > r["budget"]:
+                    c["done"] |= 2
+        elif op[0] == "snap":
+            self.snap[op[1]] = [dict(n_ctx=c["n_ctx"], new_token=c["new_token"], rounds=c["rounds"], done=c["done"], accept_len=c["accept_len"],
+                                     next_token=0, draft_len=0, n_leaf=0) for c in self.ctx]
+            self.ready[op[1]] += 1
+
+    def run_until(self, pred=None):
+        while self.ops:
+            op = self.ops.pop(0)
+            self._exec(op)
+            if pred is not None and pred(op):
+                return
+        assert pred is None, "waited for something that was never enqueued"
+
+
+class FakeEngine:
+    def __init__(self, stream, t, leader=None):
+        self.s, self.t, self.leader, self.device = stream, t, leader, torch.device("cpu")
+
+    def cohort_round(self, members, forced_accept=-1):
+        self.s.ops.append(("round",))
+
+    def cohort_states_enqueue(self, members, slot):
+        self.s.ops.append(("snap", slot))
+
+    def cohort_states_wait(self, members, slot):
+        if not self.s.ready[slot]:  # (a blocking copy in between may already have executed it: an event that has fired)
+            self.s.run_until(lambda op: op == ("snap", slot))
+        assert self.s.ready[slot] == 1, "a snapshot slot was overwritten before it was read"
+        self.s.ready[slot] = 0
+        return self.s.snap[slot]
+
+    def tokens(self, n):
+        self.s.run_until()  # a blocking copy on the stream
+        return np.asarray(self.s.ctx[self.t]["tokens"][:n], np.int32)
+
+
+class FakeModel:
+    def __init__(self, stream, t, leader=None):
+        self.engine = FakeEngine(stream, t, None if leader is None else leader.engine)
+        self.spec_layer = type("S", (), dict(total_tokens=29))()
+        self.current_length_data = torch.zeros(4, dtype=torch.long)
+
+    def _start_request(self, ids, inputs_embeds, kw, temperature=0.0, top_k=0.0, seed=0, max_new_tokens=512, is_llama3=False):
+        self.engine.s.ops.append(("begin", self.engine.t, dict(kw["req"], budget=max_new_tokens)))
+
+
+def alone(req, budget, rounds_cap=10 ** 9):
+    """The tuple the request produces when it runs by itself."""
+    s = FakeStream(1)
+    s._exec(("begin", 0, dict(req, budget=budget)))
+    accs = []
+    while True:
+        s._exec(("round",))
+        c = s.ctx[0]
+        accs.append(c["accept_len"])
+        if c["done"] or len(accs) >= rounds_cap:
+            return c["tokens"][:c["n_ctx"]], c["new_token"], len(accs) - 1, accs
+
+
+@pytest.mark.parametrize("lookahead", ["1", "0"])
+@pytest.mark.parametrize("n,R", [(4, 13), (3, 7), (2, 9), (4, 5)])
+def test_stream_bookkeeping_with_and_without_lookahead(monkeypatch, lookahead, n, R):
+    monkeypatch.setenv("VISPEC_STREAM_LOOKAHEAD", lookahead)
+    rng = np.random.default_rng(n * 100 + R)
+    reqs, budgets = [], []
+    for i in range(R):
+        r = dict(id=i, L=int(rng.integers(5, 40)), eos_round=(int(rng.integers(1, 12)) if i % 3 == 0 else None))
+        reqs.append((torch.zeros(1, r["L"], dtype=torch.long), dict(req=r)))
+        budgets.append(int(rng.integers(6, 60)))
+    stream = FakeStream(n)
+    lead = FakeModel(stream, 0)
+    models = [lead] + [FakeModel(stream, t, lead) for t in range(1, n)]
+    stats = {}
+    outs = smo.specgenerate_stream(models, reqs, max_new_tokens=budgets, stats=stats)
+    assert len(outs) == R
+    for i, (toks, new_token, idx, accs) in enumerate(outs):
+        w_toks, w_new, w_idx, w_accs = alone(reqs[i][1]["req"], budgets[i])
+        assert toks[0].tolist() == w_toks and (new_token, idx, accs) == (w_new, w_idx, w_accs), f"request {i}"
+    assert stats["request_rounds"] == sum(len(o[3]) for o in outs)
+    # lockstep rounds: the lookahead launches at most one round per refill generation more than the lockstep loop
+    assert stats["rounds"] <= stream.rounds_executed <= stats["rounds"] + 1
