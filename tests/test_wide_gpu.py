@@ -226,7 +226,7 @@ def test_cohorts_with_other_tree_shapes_equal_the_single_requests(n_req, tree):
 
 
 @pytest.mark.parametrize("n_slots,temperature", [(4, 0.0), (3, 0.0), (2, 0.0), (4, 6.0)])
-def test_request_stream_through_the_slots_of_a_cohort_equals_the_single_requests(golden_dir, n_slots, temperature):
+def test_request_stream_through_the_slots_of_a_cohort_equals_the_single_requests(golden_dir, monkeypatch, n_slots, temperature):
     """Continuous batching (specgenerate_stream): nine requests of ragged lengths and budgets — text and image prompts — through 2..4 request
     slots; a finished request's slot takes the next request while the others are mid-flight.  Every request returns what it returns alone
     (tokens, new_token, round count, accept lengths), greedy and sampling; fewer lockstep rounds than cohort-by-cohort execution."""
@@ -273,6 +273,14 @@ def test_request_stream_through_the_slots_of_a_cohort_equals_the_single_requests
     np.testing.assert_array_equal(two[1][0][0].cpu().numpy(), want[1][0][0].cpu().numpy())
     one = specgenerate_stream(models, reqs[2:3], max_new_tokens=budgets[2:3], seeds=seeds[2:3], **gen)
     np.testing.assert_array_equal(one[0][0][0].cpu().numpy(), want[2][0][0].cpu().numpy())
+    if n_slots == 4:  # the loop without its round of lookahead (VISPEC_STREAM_LOOKAHEAD=0: launch, read the states, then launch) returns the same
+        monkeypatch.setenv("VISPEC_STREAM_LOOKAHEAD", "0")
+        with torch.cuda.stream(side):
+            again = specgenerate_stream(models, reqs, max_new_tokens=budgets, seeds=seeds, **gen)
+            side.synchronize()
+        for t, (a, b) in enumerate(zip(again, got)):
+            np.testing.assert_array_equal(a[0][0].cpu().numpy(), b[0][0].cpu().numpy(), err_msg=f"request {t}")
+            assert a[1:] == b[1:], f"request {t}"
 
 
 def test_cohort_of_four_on_a_side_stream_with_sampling_seeds():
