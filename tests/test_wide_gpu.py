@@ -303,8 +303,8 @@ def test_cohort_of_four_on_a_side_stream_with_sampling_seeds():
 def test_member_slots_and_cohort_shape_errors():
     sm, _, _ = build(50, 60, True)
     other, _, _ = build(50, 60, True)
-    m1, m2, m3 = (sm.make_cohort_member() for _ in range(3))
-    with pytest.raises(RuntimeError, match="three members"):
+    m1, m2, m3, *_rest = [sm.make_cohort_member() for _ in range(7)]
+    with pytest.raises(RuntimeError, match="seven members"):
         sm.make_cohort_member()
     with pytest.raises(RuntimeError, match="member of the first"):
         other.engine.cohort_round([m1.engine])

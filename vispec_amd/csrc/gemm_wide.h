@@ -63,14 +63,14 @@ __device__ __forceinline__ void wide_wait_barrier() {  // own DMAs landed (N you
 
 // ---- epilogues (the arithmetic of gemm_w32_kernel's, on the sums held in registers) — shared by the two wide kernels.  D[i = n][j = m]:
 // register 4q + r of a lane is column 8q + 4hi + r of the tile for row j of the activation tile.
-template <int EPI, int W8, int NL>
+template <int EPI, int W8, int NL, int MPAD = WIDE_MPAD>
 __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int split, int j, int hi, int m_tile, int N, const bf16_t* __restrict__ bias,
                                               void* __restrict__ Yv, int ldy, const bf16_t* __restrict__ R, int ldr, const float* __restrict__ wscale,
-                                              const RopeEpi& re, const float* __restrict__ xscale = nullptr) {
+                                              const RopeEpi& re, const float* __restrict__ xscale = nullptr, int n_live = NL) {
   constexpr bool A8 = W8 == 2;  // e4m3 activations: the accumulator also takes the row's activation scale xscale[m] (after the weight scale)
 #pragma unroll
   for (int mt = 0; mt < NL; ++mt) {
-    if (j >= m_tile) continue;
+    if (j >= m_tile || mt >= n_live) continue;  // (n_live < NL: the cohort-8 kernel always computes eight tiles)
     const int m = 32 * mt + j;
     if (EPI == EPI_ROPE) {
       const PosSpec& ps_ = re.ps[mt];
@@ -147,7 +147,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
           if (A8) v[r] *= xscale[m];
         }
         if (EPI == EPI_PARTIAL) {
-          float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * WIDE_MPAD + m) * N + n;
+          float* part = reinterpret_cast<float*>(Yv) + ((size_t)split * MPAD + m) * N + n;
           *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           float o[4];

@@ -59,14 +59,19 @@ template <class T, class... Ts> static inline ArgPack<T, Ts...> make_pack(T a, T
 template <class F, class... Us> __device__ __forceinline__ void pack_apply(F f, const ArgPack<>&, Us... a) { f(a...); }
 template <class F, class T, class... Ts, class... Us>
 __device__ __forceinline__ void pack_apply(F f, const ArgPack<T, Ts...>& p, Us... a) { pack_apply(f, p.rest, a..., p.v); }
-template <class P> struct Packs4 { P p[4]; };
+#define MAX_COHORT 8  // requests that can share one weight pass (round 5: eight; gemm_c8.h)
+template <class P> struct Packs4 { P p[MAX_COHORT]; };  // (the name is round 2's: up to MAX_COHORT packs)
 template <class Fn, int TPB, class P>
 __global__ __launch_bounds__(TPB) void batch4_kernel(Packs4<P> a) {
   const int z = blockIdx.z;  // (selected with compares: a dynamically indexed kernel argument would be copied to scratch; ONE call
-  P p = a.p[0];              //  site: a body's static __shared__ arrays must not be instantiated four times)
+  P p = a.p[0];              //  site: a body's static __shared__ arrays must not be instantiated once per request)
   if (z == 1) p = a.p[1];
   else if (z == 2) p = a.p[2];
   else if (z == 3) p = a.p[3];
+  else if (z == 4) p = a.p[4];
+  else if (z == 5) p = a.p[5];
+  else if (z == 6) p = a.p[6];
+  else if (z == 7) p = a.p[7];
   pack_apply(Fn{}, p);
 }
 
@@ -141,9 +146,9 @@ struct PosSpec {  // position = *base + *base2 + add + (off ? off[m] : (row ? m 
 struct RopeEpi {
   const bf16_t* cosT = nullptr;
   const bf16_t* sinT = nullptr;
-  PosSpec ps[4];
-  bf16_t* kc[4] = {nullptr, nullptr, nullptr, nullptr};
-  bf16_t* vc[4] = {nullptr, nullptr, nullptr, nullptr};
+  PosSpec ps[MAX_COHORT];
+  bf16_t* kc[MAX_COHORT] = {};
+  bf16_t* vc[MAX_COHORT] = {};
   int s_max = 0, H = 0, H_kv = 0;
 };
 
@@ -932,7 +937,7 @@ struct AttnReq {
   float* part_ml;
   bf16_t* out;  // (reduce kernel)
 };
-struct AttnArgs { AttnReq r[4]; };  // up to four requests of a cohort per launch
+struct AttnArgs { AttnReq r[MAX_COHORT]; };  // up to eight requests of a cohort per launch
 // (assignments under uniform branches: the nested ?: form of this selection was compiled as a dynamically indexed kernel argument —
 //  the whole AttnArgs copied to scratch, 264 B per lane and 40 more SGPRs in both attention kernels: 15.7 -> 19.2 us per launch)
 __device__ __forceinline__ AttnReq attn_req(const AttnArgs& a, int rq) {
@@ -940,6 +945,10 @@ __device__ __forceinline__ AttnReq attn_req(const AttnArgs& a, int rq) {
   if (rq == 1) r = a.r[1];
   else if (rq == 2) r = a.r[2];
   else if (rq == 3) r = a.r[3];
+  else if (rq == 4) r = a.r[4];
+  else if (rq == 5) r = a.r[5];
+  else if (rq == 6) r = a.r[6];
+  else if (rq == 7) r = a.r[7];
   return r;
 }
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;

@@ -17,6 +17,7 @@
 #include "gemm_prefill.h"
 #include <mutex>
 #include "gemm_wide.h"
+#include "gemm_c8.h"
 #include "tree_kernels.h"
 
 static thread_local std::string g_err;
@@ -77,10 +78,10 @@ struct vispec_ctx {
     int n_req = 0, forced_accept = 0, total_token = 0, wide_rb = 0, u_over = 0;
     // per request of the (cohort) round, leader first.  `who` = the ctx itself: a captured graph bakes that request's pointers in
     // (state, tree, KV, selections ...), so the same leader with a DIFFERENT member set must not replay it.
-    const void* who[4] = {nullptr, nullptr, nullptr, nullptr};
-    int n_hint[4] = {-1, -1, -1, -1}, sample_top_k[4] = {0, 0, 0, 0};
-    float temperature[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned long long seed[4] = {0, 0, 0, 0};
+    const void* who[MAX_COHORT] = {};
+    int n_hint[MAX_COHORT] = {-1, -1, -1, -1, -1, -1, -1, -1}, sample_top_k[MAX_COHORT] = {};
+    float temperature[MAX_COHORT] = {};
+    unsigned long long seed[MAX_COHORT] = {};
     bool operator==(const GraphKey& o) const {
       return n_req == o.n_req && forced_accept == o.forced_accept && total_token == o.total_token && wide_rb == o.wide_rb && u_over == o.u_over &&
              memcmp(who, o.who, sizeof(who)) == 0 &&
@@ -112,8 +113,9 @@ struct vispec_ctx {
   bool u_over_on = false;
   bool zombie = false;  // a leader destroyed while members were alive: its workspaces (which the members alias) are freed with the last member
   vispec_ctx* leader = nullptr;  // non-null: a cohort member — its activation buffers are 32-row tile `slot` of the leader's
-  int slot = 0;                  // activation tile of this request inside the leader's 128-row workspaces (leader: 0, members: 1..3)
-  vispec_ctx* members[3] = {nullptr, nullptr, nullptr};  // (leader) the member that owns tile 1, 2, 3
+  int slot = 0;                  // activation tile of this request inside the leader's 256-row workspaces (leader: 0, members: 1..7)
+  vispec_ctx* members[MAX_COHORT - 1] = {};  // (leader) the member that owns tile 1 .. 7
+  bool has_members() const { for (const vispec_ctx* m : members) if (m) return true; return false; }
   float temperature = 0.f;          // > 1e-5: sampling path (spec_model_ours.py:272-277)
   int sample_top_k = 0;             // > 0: TopKLogitsWarper after the temperature (utils.py:52-53)
   unsigned long long seed = 0;
@@ -136,7 +138,7 @@ static int dalloc(vispec_ctx* ctx, T** p, size_t n) {
 extern "C" const char* vispec_last_error(void) { return g_err.c_str(); }
 extern "C" int vispec_version(void) { return 1; }
 
-#define ROWS 128  /* rows of the activation workspaces: four 32-row tiles (a cohort of up to four requests shares one weight pass) */
+#define ROWS (32 * MAX_COHORT)  /* rows of the activation workspaces: eight 32-row tiles (a cohort of up to eight requests shares one weight pass) */
 #define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
 static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
@@ -146,8 +148,8 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   if (leader && leader->c.total_token > 32) return fail("ctx_create_member: the leader's tree must fit one 32-row activation tile (total_token <= 32)");
   int slot = 0;
   if (leader) {
-    for (slot = 1; slot <= 3 && leader->members[slot - 1]; ++slot) {}
-    if (slot > 3) return fail("ctx_create_member: the leader already has three members (a cohort is at most four requests)");
+    for (slot = 1; slot < MAX_COHORT && leader->members[slot - 1]; ++slot) {}
+    if (slot >= MAX_COHORT) return fail("ctx_create_member: the leader already has seven members (a cohort is at most eight requests)");
   }
   const vispec_config& c = *cfg;
   if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
@@ -232,7 +234,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     size_t nmax = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
     if (nmax < (size_t)3 * c.hidden_size) nmax = (size_t)3 * c.hidden_size;
     if (nmax < 16384) nmax = 16384;
-    ctx->gemm_part_elems = (size_t)8 * 128 * nmax;  // [S <= 8][up to four 32-row tiles][N] fp32
+    ctx->gemm_part_elems = (size_t)8 * ROWS * nmax;  // [S <= 8][up to eight 32-row tiles][N] fp32
     if (leader) ctx->gemm_part = leader->gemm_part;  // launches of a cohort are stream-ordered: one partial workspace serves both
     else A(gemm_part, ctx->gemm_part_elems);
     A(lstk_stats, 64 * LSTK_CHUNKS * 2); A(lstk_cv, 64 * LSTK_CHUNKS * TOPK_MAX); A(lstk_ci, 64 * LSTK_CHUNKS * TOPK_MAX);
@@ -272,6 +274,15 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<0>()) != hipSuccess) (void)hipGetLastError();
     for (const void* f : wide8_fp8)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<1>()) != hipSuccess) (void)hipGetLastError();
+    // the cohort-8 form (gemm_w32_c8_kernel): 96 KiB of dynamic LDS
+#define C8_ALL_EPI(W8_)                                                                                                     \
+  (const void*)gemm_w32_c8_kernel<EPI_NONE, W8_>, (const void*)gemm_w32_c8_kernel<EPI_RESIDUAL, W8_>,                          \
+      (const void*)gemm_w32_c8_kernel<EPI_SWIGLU, W8_>, (const void*)gemm_w32_c8_kernel<EPI_PARTIAL, W8_>,                     \
+      (const void*)gemm_w32_c8_kernel<EPI_ROPE, W8_>
+    const void* c8[] = {C8_ALL_EPI(0), C8_ALL_EPI(1), C8_ALL_EPI(2)};
+#undef C8_ALL_EPI
+    for (const void* f : c8)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, C8_LDS_BYTES) != hipSuccess) (void)hipGetLastError();
   }
   if (leader) leader->members[slot - 1] = ctx;
   *out = ctx;
@@ -301,11 +312,11 @@ extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
     // the leader's cached cohort graphs bake this member's buffers in, and a later member may be allocated at this very address
     // (the graph key compares ctx pointers): drop them with the member
     for (auto* g : {&ld->g_cverify, &ld->g_cdraft, &ld->g_car}) g->clear();
-    if (ld->zombie && !ld->members[0] && !ld->members[1] && !ld->members[2]) ctx_free(ld);  // the last member of a destroyed leader
+    if (ld->zombie && !ld->has_members()) ctx_free(ld);  // the last member of a destroyed leader
   }
   // A member's GEMM workspaces ARE rows of its leader's (ctx_create_impl, AL): a leader destroyed while members are alive keeps its
   // allocations until the last of them is gone (the members stay usable as single requests; the destroyed leader handle must not be used)
-  if (ctx->members[0] || ctx->members[1] || ctx->members[2]) {
+  if (ctx->has_members()) {
     for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
     ctx->zombie = true;
     return;
@@ -378,7 +389,7 @@ static void prof_end(hipStream_t) {
 template <class Fn, int TPB, class P>
 static void launch_batch(hipStream_t s, dim3 grid, size_t lds, const P* packs, int n) {
   Packs4<P> a;
-  for (int t = 0; t < 4; ++t) a.p[t] = packs[t < n ? t : 0];
+  for (int t = 0; t < MAX_COHORT; ++t) a.p[t] = packs[t < n ? t : 0];
   grid.z = n;
   hipLaunchKernelGGL((batch4_kernel<Fn, TPB, P>), grid, dim3(TPB), lds, s, a);
 }
@@ -671,17 +682,108 @@ static int launch_gemm_wide(vispec_ctx* ctx, hipStream_t s, const void* X, int l
   return 0;
 }
 
-// m_tile > 0: cohort mode, M = 32 (n_req - 1) + m_tile with n_req in [2,4] requests of m_tile rows each (tile t = request t)
+// Five to eight requests per weight pass (csrc/gemm_c8.h): tile t of X / Y / R (rows 32t ..) belongs to request t, rows 32t .. 32t + m_tile - 1
+// are live.  ONE accumulator chain per output element over the split's K range ("the c8 order"): a row does not depend on what shares its
+// launch, but differs from the single-request kernel's four-quarter order in fp32 rounding.  Split-K factor = the single-request policy's.
+static int launch_gemm_c8(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int n_req, int N, int K,
+                          int epi, const GemmOut& o, int force_split, const RopeEpi* re = nullptr) {
+  if (n_req < 5 || n_req > MAX_COHORT || o.m_tile < 1 || o.m_tile > 32) return fail("gemm_c8: 5..8 requests of 1..32 rows");
+  if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_c8: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
+  if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_c8: residual epilogue without R");
+  const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
+  if (o.xscale && (!o.wscale || K % 64)) return fail("gemm_c8: fp8 activations need fp8 weights and K %% 64 == 0");
+  const int tiles = epi == EPI_SWIGLU ? N / 16 : (N + 31) / 32, KS = K / (o.xscale ? 64 : (o.wscale ? 32 : 16));
+  const int M = 32 * (n_req - 1) + o.m_tile;
+  static const int c8_force_small = getenv("VISPEC_C8_SMALL") ? atoi(getenv("VISPEC_C8_SMALL")) : 0;  // tests: the fragment-shaped form at every size
+#define C8_L(EPI_, W8_, YPTR, LDY, SPLITS)                                                                                              \
+  do {                                                                                                                                  \
+    if (c8_fast_ok(K, SPLITS, W8_) && !c8_force_small)                                                                                  \
+      PLAUNCH((gemm_w32_c8_kernel<EPI_, W8_>), dim3((tiles + 7) / 8, SPLITS), dim3(512), C8_LDS_BYTES, s, x, ldx, w, b, YPTR, LDY, r, o.ldr,  \
+              o.m_tile, n_req, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles, o.xscale);                                           \
+    else                                                                                                                                \
+      PLAUNCH((gemm_w32_c8_small_kernel<EPI_, W8_>), dim3(tiles, SPLITS), dim3(64), 0, s, x, ldx, w, b, YPTR, LDY, r, o.ldr, o.m_tile,    \
+              n_req, N, K, SPLITS, o.wscale, re ? *re : RopeEpi{}, tiles, o.xscale);                                                     \
+  } while (0)
+#define C8_D(EPI_, YPTR, LDY, SPLITS)                                                                         \
+  do {                                                                                                        \
+    if (o.xscale) C8_L(EPI_, 2, YPTR, LDY, SPLITS);                                                           \
+    else if (o.wscale) C8_L(EPI_, 1, YPTR, LDY, SPLITS);                                                      \
+    else C8_L(EPI_, 0, YPTR, LDY, SPLITS);                                                                    \
+  } while (0)
+  if (epi == EPI_ROPE) {
+    if (!re) return fail("gemm_c8: rope epilogue without its arguments");
+    prof_begin(s, PROF_QKV_ROPE, (double)N * K * (o.wscale ? 1.0 : 2.0));
+    C8_D(EPI_ROPE, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  if (epi == EPI_SWIGLU) {
+    if (N % 16) return fail("gemm_c8: SwiGLU needs N %% 16 == 0");
+    if (o.norm_w) return fail("gemm_c8: no fused norm after SwiGLU");
+    prof_begin(s, 2, (double)N * K * (o.wscale ? 2.0 : 4.0));
+    C8_D(EPI_SWIGLU, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  int S = 1;
+  if (tiles < 256 || o.norm_w) {
+    S = choose_split(tiles, KS, (double)32 * K * (o.wscale ? 1.0 : 2.0), o.norm_w != nullptr);
+    if (!ctx) S = 1;
+  }
+  if (force_split > 0) S = force_split;
+  if (S == 1 && !o.norm_w) {
+    prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
+    if (epi == EPI_RESIDUAL) C8_D(EPI_RESIDUAL, o.Y, o.ldy, 1); else C8_D(EPI_NONE, o.Y, o.ldy, 1);
+    KCHK();
+    prof_end(s);
+    return 0;
+  }
+  if (!ctx) return fail("gemm_c8: split-K needs a ctx (partial workspace)");
+  if ((size_t)S * C8_MPAD * N > ctx->gemm_part_elems) return fail("gemm_c8: partial workspace too small");
+  prof_begin(s, 3, (double)N * K * (o.wscale ? 1.0 : 2.0));
+  {
+    const bf16_t* b_keep = b;
+    b = nullptr;  // bias belongs to the reduce
+    C8_D(EPI_PARTIAL, ctx->gemm_part, 0, S);
+    b = b_keep;
+  }
+#undef C8_D
+#undef C8_L
+  KCHK();
+  prof_end(s);
+  prof_begin(s, 4, 0.0);
+  static const int red_threads = getenv("VISPEC_REDUCE_THREADS") ? atoi(getenv("VISPEC_REDUCE_THREADS")) : 512;
+  PLAUNCH(splitk_reduce_kernel, dim3(M), dim3(N >= 2048 ? red_threads : 256), o.normed ? sizeof(float) * N : 0, s, ctx->gemm_part, S, C8_MPAD, N, b,
+          epi == EPI_RESIDUAL ? r : nullptr, o.ldr, (bf16_t*)o.Y, o.ldy, (const bf16_t*)o.norm_w, (bf16_t*)o.normed, o.ldn, o.eps, o.m_tile,
+          o.normed ? o.q8 : nullptr, o.sx8);
+  KCHK();
+  prof_end(s);
+  return 0;
+}
+
+// m_tile > 0: cohort mode, M = 32 (n_req - 1) + m_tile with n_req in [2,8] requests of m_tile rows each (tile t = request t)
 static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split = -1) {
   if (o.m_tile < 0) {  // slab mode: the requests' <= 8 live rows share one activation tile
     const int rows = -o.m_tile, n_req = (M - rows) / 8 + 1;
-    if (rows > 8 || (M - rows) % 8 || n_req < 2 || n_req > 4) return fail("gemm_skinny: slab mode wants M = 8 (n - 1) + rows, rows <= 8, n in [2,4]");
+    if (rows > 8 || (M - rows) % 8 || n_req < 2 || n_req > MAX_COHORT) return fail("gemm_skinny: slab mode wants M = 8 (n - 1) + rows, rows <= 8, n in [2,8]");
+    if (n_req > 4) {  // five to eight requests: two slabs (requests 0..3, then 4..n-1 at rows 128.. of X / Y / R / normed), each the single-tile launch
+      if (o.q8 || o.xscale) return fail("gemm_skinny: no fp8-activation slab form");
+      if (launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, 24 + rows, N, K, epi, o, force_split)) return -1;
+      GemmOut o2 = o;
+      if (o.Y) o2.Y = (bf16_t*)o.Y + (size_t)128 * o.ldy;
+      if (o.R) o2.R = (const bf16_t*)o.R + (size_t)128 * o.ldr;
+      if (o.normed) o2.normed = (bf16_t*)o.normed + (size_t)128 * o.ldn;
+      return launch_gemm_mt<1>(ctx, s, (const bf16_t*)X + (size_t)128 * ldx, ldx, P, bias, 8 * (n_req - 5) + rows, N, K, epi, o2, force_split);
+    }
     return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   }
   if (o.m_tile > 0) {
     const int n_req = (M - o.m_tile) / 32 + 1;
-    if (o.m_tile > 32 || (M - o.m_tile) % 32 || n_req < 2 || n_req > 4) return fail("gemm_skinny: cohort mode wants M = 32 (n - 1) + m_tile, n in [2,4]");
+    if (o.m_tile > 32 || (M - o.m_tile) % 32 || n_req < 2 || n_req > MAX_COHORT) return fail("gemm_skinny: cohort mode wants M = 32 (n - 1) + m_tile, n in [2,8]");
+    if (n_req > 4) return launch_gemm_c8(ctx, s, X, ldx, P, bias, n_req, N, K, epi, o, force_split);
     if (n_req > 2) return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, epi, o, force_split);
   }
   if (M <= 32) return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
@@ -783,15 +885,21 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
       if (launch_rope(s, (bf16_t*)qkv + (size_t)32 * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
     return 0;
   }
-  if (M < 1 || Mk > 128 || (n_req == 1 && M > 64) || (n_req > 1 && M > 32)) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
+  if (M < 1 || Mk > ROWS || (n_req == 1 && M > 64) || (n_req > 1 && M > 32)) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
+  if (slab && n_req > 4) {  // five to eight requests in slab form: two single-tile launches (requests 0..3, then 4..n-1 at rows 128..)
+    if (launch_qkv_rope(ctx, s, X, ldx, P, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, rq, 4, s_max, true, xscale)) return -1;
+    return launch_qkv_rope(ctx, s, (const bf16_t*)X + (size_t)128 * ldx, ldx, P, bias, wscale, (bf16_t*)qkv + (size_t)128 * N, M, H, H_kv, K, cosT, sinT, rq + 4,
+                           n_req - 4, s_max, n_req - 4 >= 2, xscale);
+  }
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
   for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
-  if (n_req > 2 && !slab) {  // three or four requests: the wide-cohort kernel
+  if (n_req > 2 && !slab) {  // three or four requests: the wide-cohort kernel; five to eight: the cohort-8 kernel
     GemmOut o;
     o.wscale = (const float*)wscale; o.xscale = xscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
+    if (n_req > 4) return launch_gemm_c8(ctx, s, X, ldx, P, bias, n_req, N, K, EPI_ROPE, o, -1, &re);
     return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_req, N, K, EPI_ROPE, o, -1, &re);
   }
   prof_begin(s, PROF_QKV_ROPE, (double)N * K * (wscale ? 1.0 : 2.0));
@@ -954,7 +1062,7 @@ static int launch_lstopk_cohort(vispec_ctx* const* x, int n, hipStream_t s, int 
     auto p1 = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, chunk, x[t]->lstk_stats); };
     auto p2 = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, chunk, k, (const float*)x[t]->lstk_stats, x[t]->lstk2_cand); };
     auto p3 = [&](int t) { return make_pack((const unsigned long long*)x[t]->lstk2_cand, C, k, x[t]->top_idx, x[t]->top_logp); };
-    decltype(p1(0)) a1[4]; decltype(p2(0)) a2[4]; decltype(p3(0)) a3[4];
+    decltype(p1(0)) a1[MAX_COHORT]; decltype(p2(0)) a2[MAX_COHORT]; decltype(p3(0)) a3[MAX_COHORT];
     for (int t = 0; t < n; ++t) { a1[t] = p1(t); a2[t] = p2(t); a3[t] = p3(t); }
 #define LSTK2N(NV_)                                                                            \
   do {                                                                                         \
@@ -970,7 +1078,7 @@ static int launch_lstopk_cohort(vispec_ctx* const* x, int n, hipStream_t s, int 
   }
   if (n > 1 && V % 8 == 0 && V <= 1024 * 8 * 20 && V <= row_max_v && V <= chunk_min_v) {
     auto pr = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, k, x[t]->top_idx, x[t]->top_logp); };
-    decltype(pr(0)) a[4];
+    decltype(pr(0)) a[MAX_COHORT];
     for (int t = 0; t < n; ++t) a[t] = pr(t);
     if (V <= 1024 * 8 * 4) launch_batch<lstk_row_fn<4>, 1024>(s, dim3(M), 0, a, n);
     else if (V <= 1024 * 8 * 8) launch_batch<lstk_row_fn<8>, 1024>(s, dim3(M), 0, a, n);
@@ -1024,7 +1132,7 @@ extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, 
 extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* wscale, const void* bias, void* Y,
                                   int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue) {
   if (epilogue < 0 || epilogue > 2) return fail("gemm_cohort: bad epilogue");
-  if (n_req < 2 || n_req > 4 || m_tile == 0 || m_tile > 32 || m_tile < -8) return fail("gemm_cohort: 2..4 requests of 1..32 rows (slab mode: -8..-1)");
+  if (n_req < 2 || n_req > MAX_COHORT || m_tile == 0 || m_tile > 32 || m_tile < -8) return fail("gemm_cohort: 2..8 requests of 1..32 rows (slab mode: -8..-1)");
   if (m_tile < 0)  // slab mode: the requests' rows share one activation tile
     return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 8 * (n_req - 1) - m_tile, N, K, epilogue, wscale, m_tile);
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, 32 * (n_req - 1) + m_tile, N, K, epilogue, wscale, m_tile);
@@ -1036,7 +1144,7 @@ extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, 
 extern "C" int vispec_gemm_fp8a8(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P8, const void* wscale, const void* bias, void* Y, int ldy,
                                  const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps) {
   if (!ctx || !wscale || epilogue < 0 || epilogue > 2 || K % 64 || ldx != K) return fail("gemm_fp8a8: needs a ctx, weight scales, K %% 64 == 0 and a dense X (ldx == K)");
-  if (n_req < 1 || n_req > 4 || (n_req > 1 && (m_tile < 1 || m_tile > 32)) || (n_req == 1 && (M < 1 || M > 64))) return fail("gemm_fp8a8: bad row layout");
+  if (n_req < 1 || n_req > MAX_COHORT || (n_req > 1 && (m_tile < 1 || m_tile > 32)) || (n_req == 1 && (M < 1 || M > 64))) return fail("gemm_fp8a8: bad row layout");
   const size_t kmax = (size_t)std::max(std::max((int)ctx->c.hidden_size, (int)(ctx->c.num_heads * ctx->c.head_dim)), (int)ctx->c.intermediate_size);
   if ((size_t)K > kmax) return fail("gemm_fp8a8: K exceeds the ctx's quantisation scratch (max of hidden, heads x head_dim, intermediate size)");
   hipStream_t s = (hipStream_t)stream;
@@ -1062,7 +1170,7 @@ extern "C" int vispec_quant_rows_e4m3(vispec_ctx*, void* stream, const void* X, 
 }
 // test hook: the ctx's W8A8 scratch (e4m3 codes [rows][K] and per-row scales) as the last quantisation left it — copied on `stream`
 extern "C" int vispec_a8_scratch_read(vispec_ctx* ctx, void* stream, void* codes_out, void* scales_out, int rows, int K) {
-  if (!ctx || !ctx->xq || rows < 1 || rows > 128 || K < 1) return fail("a8_scratch_read: bad arguments");
+  if (!ctx || !ctx->xq || rows < 1 || rows > ROWS || K < 1) return fail("a8_scratch_read: bad arguments");
   if (hipMemcpyAsync(codes_out, ctx->xq, (size_t)rows * K, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
       hipMemcpyAsync(scales_out, ctx->sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
     return fail("a8_scratch_read: copy failed");
@@ -1098,6 +1206,14 @@ extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* strea
 #define V(NWV, UN)                                                                                                              \
   hipLaunchKernelGGL((gemm_w32_kernel<1, EPI_PARTIAL, UN, NWV>), dim3(tiles, S), dim3(NWV * 64), (gemm_w32_lds_bytes<1, UN, NWV>()), s, x, \
                      ldx, w, 0, nullptr, ctx->gemm_part, 0, nullptr, 0, M, N, K, S, nullptr, RopeEpi{}, 0, (const float*)nullptr)
+  if (M > 128 && dbg == 8) {  // 9xxxx at M > 128: the cohort-8 kernel (eight requests, one accumulator chain per element), kernel alone
+    if (M > ROWS || (size_t)S * C8_MPAD * N > ctx->gemm_part_elems) return fail("tune: c8 needs M <= 256 and a partial workspace of S*256*N");
+    if (!c8_fast_ok(K, S, 0)) return fail("tune: c8 needs K %% 64 == 0 and a group per split");
+    hipLaunchKernelGGL((gemm_w32_c8_kernel<EPI_PARTIAL, 0>), dim3((tiles + 7) / 8, S), dim3(512), C8_LDS_BYTES, s, x, ldx, w, nullptr, ctx->gemm_part, 0, nullptr,
+                       0, 30, 8, N, K, S, nullptr, RopeEpi{}, tiles, (const float*)nullptr);
+    KCHK();
+    return 0;
+  }
   if (M > 64 && dbg == 8) {  // 9xxxx: the wide-cohort kernel (16 waves = 4 row blocks x 4 K-quarters sharing staged activations), kernel alone
     if (M > 128 || (size_t)S * 128 * N > ctx->gemm_part_elems) return fail("tune: wide needs M <= 128 and a partial workspace of S*128*N");
     if (M > 96 && unc == 5) {  // 9xxx5: EIGHT row blocks per workgroup, K walked quarter by quarter (gemm_w32_wide8_kernel)
@@ -1442,7 +1558,7 @@ extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* pr
 static const bool g_draft_slab = !(getenv("VISPEC_DRAFT_SLAB") && atoi(getenv("VISPEC_DRAFT_SLAB")) == 0);
 struct Cohort {
   int n;
-  vispec_ctx* c[4];
+  vispec_ctx* c[MAX_COHORT];
   vispec_ctx* lead() const { return c[0]; }
   int mt(int rows) const { return n >= 2 ? rows : 0; }                    // m_tile argument
   int M(int rows) const { return n >= 2 ? 32 * (n - 1) + rows : rows; }  // M argument of a shared GEMM
@@ -1452,7 +1568,7 @@ struct Cohort {
   int dmt(int rows) const { return slab(rows) ? -rows : mt(rows); }
   int dM(int rows) const { return slab(rows) ? 8 * (n - 1) + rows : M(rows); }
 };
-static Cohort solo_cohort(vispec_ctx* ctx) { return Cohort{1, {ctx, nullptr, nullptr, nullptr}}; }
+static Cohort solo_cohort(vispec_ctx* ctx) { Cohort co{}; co.n = 1; co.c[0] = ctx; return co; }
 
 // bcast_g: (re)write the right half of dx1 with the current global image feature g.  g changes only inside the draft prefill (one new
 // g per image run); vispec_draft_prefill leaves dx1[:, D:2D] = final g for all rows, so the decode rounds never touch it.
@@ -1463,7 +1579,7 @@ static int draft_fuse(const Cohort& co, hipStream_t s, int rows, void* out, int 
   if (bcast_g) {
     if (co.n > 1) {
       auto pk = [&](int t) { return make_pack((const bf16_t*)co.c[t]->dg, co.c[t]->dx1 + D, 2 * D, D); };
-      decltype(pk(0)) a[4];
+      decltype(pk(0)) a[MAX_COHORT];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
       launch_batch<bcast_row_fn, 256>(s, dim3(rows), 0, a, co.n);
       KCHK();
@@ -1500,7 +1616,7 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
   vispec_ctx* ctx = co.lead();
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, Hd = c.draft_heads, k = c.top_k;
-  QkvReq rq[4];
+  QkvReq rq[MAX_COHORT];
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* x = co.c[t];
     PosSpec& ps = rq[t].ps;
@@ -1521,7 +1637,7 @@ static int draft_layer(const Cohort& co, hipStream_t s, int rows, int level) {
                       co.n, c.draft_max_pos, co.slab(rows)))
     return -1;
   {
-    AttnCall calls[4];
+    AttnCall calls[MAX_COHORT];
     int max_keys = 1;
     for (int t = 0; t < co.n; ++t) {
       vispec_ctx* x = co.c[t];
@@ -1550,7 +1666,7 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
       vispec_ctx* x = co.c[t];
       return make_pack(x->tb, (const int*)x->top_idx, (const float*)x->top_logp, k, (const bf16_t*)x->dlast, (const bf16_t*)ctx->dw.embed, x->dx1, x->dx2, D);
     };
-    decltype(pk(0)) a[4];
+    decltype(pk(0)) a[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) a[t] = pk(t);
     launch_batch<tree_init_fn, 1024>(s, dim3(1), 0, a, co.n);
   } else {
@@ -1569,7 +1685,7 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
         vispec_ctx* x = co.c[t];
         return make_pack(x->tb, lvl, k, (const int*)x->top_idx, (const float*)x->top_logp, (const bf16_t*)x->dout, (const bf16_t*)ctx->dw.embed, x->dx1, x->dx2, D);
       };
-      decltype(pk(0)) a[4];
+      decltype(pk(0)) a[MAX_COHORT];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
       launch_batch<tree_level_fn, 1024>(s, dim3(1), 0, a, co.n);
     } else {
@@ -1581,7 +1697,7 @@ static int draft_grow_tree(const Cohort& co, hipStream_t s) {
   // sampling: retrieve rows sorted (cnets_ours.py:1215-1224)
   if (co.n > 1) {
     auto pk = [&](int t) { vispec_ctx* x = co.c[t]; return make_pack(x->tb, x->st, k, c.depth, c.total_token - 1, x->temperature > 1e-5f ? 1 : 0); };
-    decltype(pk(0)) a[4];
+    decltype(pk(0)) a[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) a[t] = pk(t);
     launch_batch<tree_finalize_fn, 256>(s, dim3(1), 0, a, co.n);
   } else {
@@ -1601,7 +1717,7 @@ static int draft_round_body(const Cohort& co, hipStream_t s) {
   if (draft_layer(co, s, MC, -1)) return -1;
   if (co.n > 1) {  // + dlast = out_hidden[:, -1]
     auto pk = [&](int t) { vispec_ctx* x = co.c[t]; return make_pack(x->st, (const bf16_t*)x->dout, x->dlast, D); };
-    decltype(pk(0)) a[4];
+    decltype(pk(0)) a[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) a[t] = pk(t);
     launch_batch<draft_advance_fn, 256>(s, dim3(1), 0, a, co.n);
   } else {
@@ -1783,7 +1899,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
   const int D = c.hidden_size, H = c.num_heads, Hk = c.num_kv_heads, V = c.vocab_size, I = c.intermediate_size;
   const int QKV = (H + 2 * Hk) * 128;
   const size_t slab = (size_t)Hk * c.max_pos * 128;
-  QkvReq rq[4];
+  QkvReq rq[MAX_COHORT];
   for (int t = 0; t < co.n; ++t) {
     vispec_ctx* x = co.c[t];
     if (!x->target_kv) return fail("target KV not set");
@@ -1804,7 +1920,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
       vispec_ctx* x = co.c[t];
       return make_pack((const bf16_t*)ctx->tm.embed, (const int*)x->tb.tree_tokens, x->xa, (const bf16_t*)ctx->layers[0].ln1, x->xn, D, c.rms_eps);
     };
-    decltype(pk(0)) a[4];
+    decltype(pk(0)) a[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) a[t] = pk(t);
     launch_batch<embed_rmsnorm_fn, 256>(s, dim3(T), 0, a, co.n);
     KCHK();
@@ -1832,7 +1948,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
     } else if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
       return -1;
     {
-      AttnCall calls[4];
+      AttnCall calls[MAX_COHORT];
       int max_keys = 1;
       for (int t = 0; t < co.n; ++t) {
         vispec_ctx* x = co.c[t];
@@ -1877,7 +1993,7 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
     return -1;
   if (co.n > 1) {
     auto pk = [&](int t) { return make_pack((const bf16_t*)co.c[t]->logits, V, V, co.c[t]->am); };
-    decltype(pk(0)) a[4];
+    decltype(pk(0)) a[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) a[t] = pk(t);
     launch_batch<argmax_rows_fn, 1024>(s, dim3(T), 0, a, co.n);
   } else {
@@ -1907,7 +2023,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
         return make_pack(x->tb, x->st, (const bf16_t*)x->logits, c.vocab_size, x->temperature, x->sample_top_k, x->seed, x->tokens, x->tokens_cap, x->sel,
                          x->accept_log, x->log_cap, x->draft_ids, (const float*)(x->u_over_on ? x->u_over : nullptr), 1);
       };
-      decltype(pk(0)) a[4];
+      decltype(pk(0)) a[MAX_COHORT];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
       launch_batch<verify_accept_sample_fn, 1024>(s, dim3(1), 0, a, co.n);
     } else {
@@ -1915,7 +2031,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
         vispec_ctx* x = co.c[t];
         return make_pack(x->tb, x->st, (const int*)x->am, x->tokens, x->tokens_cap, x->sel, x->accept_log, x->log_cap, forced_accept, x->draft_ids, 1);
       };
-      decltype(pk(0)) a[4];
+      decltype(pk(0)) a[MAX_COHORT];
       for (int t = 0; t < co.n; ++t) a[t] = pk(t);
       launch_batch<verify_accept_fn, 64>(s, dim3(1), 0, a, co.n);
     }
@@ -1925,7 +2041,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
       return make_pack(x->target_kv, c.max_pos, n_kv, (const DevState*)x->st, (const int*)x->sel, (const bf16_t*)x->hidden_new, x->accept_hidden,
                        (const int*)x->draft_ids, dembed, x->dx1, x->dx2, D);
     };
-    decltype(pp(0)) b[4];
+    decltype(pp(0)) b[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) b[t] = pp(t);
     launch_batch<post_accept_fn, 256>(s, dim3(n_kv + TREE_RET_W), 0, b, co.n);
     KCHK();
@@ -1968,7 +2084,7 @@ extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
 
 // ---- cohort rounds: two to four requests (leader + member ctxs), one weight pass ------------------------------------------------------
 static int cohort_check(vispec_ctx* const* ctxs, int n, Cohort* co) {
-  if (!ctxs || n < 2 || n > 4) return fail("cohort: 2..4 requests");
+  if (!ctxs || n < 2 || n > MAX_COHORT) return fail("cohort: 2..8 requests");
   for (int t = 0; t < n; ++t)
     if (!ctxs[t]) return fail("null ctx");
   vispec_ctx* a = ctxs[0];
@@ -1976,7 +2092,7 @@ static int cohort_check(vispec_ctx* const* ctxs, int n, Cohort* co) {
   if (a->zombie) return fail("cohort: the leader was destroyed (vispec_ctx_destroy); its members can only run as single requests");
   if (a->c.total_token > 32) return fail("cohort: every request needs a tree of <= 32 nodes (one activation tile each)");
   co->n = n;
-  for (int t = 0; t < 4; ++t) co->c[t] = nullptr;
+  for (int t = 0; t < MAX_COHORT; ++t) co->c[t] = nullptr;
   co->c[0] = a;
   // request t of the round sits in activation tile t: the members must own tiles 1 .. n-1 (any order of creation, no tile twice)
   for (int t = 1; t < n; ++t) {
@@ -2152,7 +2268,7 @@ extern "C" int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stre
   vispec_ctx* a = co.c[0];
   return run_graphed(a, s, a->g_car, graph_key_n(co.c, n, -1, false), [&]() {
     auto pk = [&](int t) { return make_pack(co.c[t]->tb, co.c[t]->st); };
-    decltype(pk(0)) b[4];
+    decltype(pk(0)) b[MAX_COHORT];
     for (int t = 0; t < co.n; ++t) b[t] = pk(t);
     launch_batch<tree_single_fn, 64>(s, dim3(1), 0, b, co.n);
     KCHK();
@@ -2174,7 +2290,7 @@ extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
 // The same for every request of a cohort with ONE stream synchronisation (the per-request form costs a blocking round trip each: four per
 // lockstep round): the states travel through each ctx's pinned staging buffer.  out = n x 8 ints, laid out as above.
 extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void* stream, int* out) {
-  if (!ctxs || !out || n < 1 || n > 4) return fail("cohort_get_state: 1..4 contexts");
+  if (!ctxs || !out || n < 1 || n > MAX_COHORT) return fail("cohort_get_state: 1..8 contexts");
   for (int t = 0; t < n; ++t) {
     if (!ctxs[t] || !ctxs[t]->h_pin) return fail("null ctx");
     HIPCHK(hipMemcpyAsync(ctxs[t]->h_pin, ctxs[t]->st, sizeof(DevState), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -2192,7 +2308,7 @@ extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void
 // every request's DevState into pinned snapshot slot `slot` (0 / 1) in stream order and records the slot's event — the next round can be
 // launched right behind it; `wait` blocks on that event only (not on the stream, which is already running the next round) and unpacks.
 extern "C" int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void* stream, int slot) {
-  if (!ctxs || n < 1 || n > 4 || slot < 0 || slot > 1) return fail("cohort_state_enqueue: 1..4 contexts, slot 0 or 1");
+  if (!ctxs || n < 1 || n > MAX_COHORT || slot < 0 || slot > 1) return fail("cohort_state_enqueue: 1..8 contexts, slot 0 or 1");
   for (int t = 0; t < n; ++t) {
     if (!ctxs[t]) return fail("null ctx");
     if (!ctxs[t]->h_state && hipHostMalloc(&ctxs[t]->h_state, 2 * sizeof(DevState)) != hipSuccess) return fail("hipHostMalloc failed");
@@ -2204,7 +2320,7 @@ extern "C" int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void*
   return 0;
 }
 extern "C" int vispec_cohort_state_wait(vispec_ctx* const* ctxs, int n, int slot, int* out) {
-  if (!ctxs || !out || n < 1 || n > 4 || slot < 0 || slot > 1 || !ctxs[0] || !ctxs[0]->st_ev[slot]) return fail("cohort_state_wait: nothing enqueued in this slot");
+  if (!ctxs || !out || n < 1 || n > MAX_COHORT || slot < 0 || slot > 1 || !ctxs[0] || !ctxs[0]->st_ev[slot]) return fail("cohort_state_wait: nothing enqueued in this slot");
   HIPCHK(hipEventSynchronize(ctxs[0]->st_ev[slot]));
   for (int t = 0; t < n; ++t) {
     if (!ctxs[t] || !ctxs[t]->h_state) return fail("null ctx");
