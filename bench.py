@@ -483,7 +483,7 @@ def main():
     ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
     ap.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling path (README T=1 rows); 0 = greedy (headline)")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent batch-1 replicas per GPU sharing one copy of the weights")
-    ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4),
+    ap.add_argument("--cohort", type=int, default=4, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
                          "independent batch-1 requests; tokens of each request are those of a run on its own)")
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
@@ -748,8 +748,8 @@ def main():
                 rep_c.pop("gemm_prefill_mfma", None)
                 _, gemm_c, dom_c = price(rep_c)
                 rb_timed = WIDE_RB if WIDE_RB >= 0 else (0 if R == 1 else 84)
-                wide8 = CO >= 3 and (rb_timed == 8 or (rb_timed == 84 and (not fp8 or "a8" in MODEL)))  # (vispec_set_wide_row_blocks(84): W8A16 stays on four)
-                keys_c = (PROF_KERNEL_KEYS_WIDE8 if wide8 else PROF_KERNEL_KEYS_WIDE) if CO >= 3 else PROF_KERNEL_KEYS_PAIRED
+                wide8 = 3 <= CO <= 4 and (rb_timed == 8 or (rb_timed == 84 and (not fp8 or "a8" in MODEL)))  # (vispec_set_wide_row_blocks(84): W8A16 stays on four)
+                keys_c = PROF_KERNEL_KEYS_C8 if CO >= 5 else ((PROF_KERNEL_KEYS_WIDE8 if wide8 else PROF_KERNEL_KEYS_WIDE) if CO >= 3 else PROF_KERNEL_KEYS_PAIRED)
                 extra["roofline"] = roofline_of(rep_c, gemm_c, dom_c, keys_c,
                                                 f"{CO} requests per launch (one cohort of the timed region, un-graphed for the timestamps, ALONE on the GPU): "
                                                 f"algorithmic bytes = the weight once, whatever the number of requests it serves"
@@ -763,7 +763,7 @@ def main():
                         extra["roofline"]["deployed"] = dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device)
                     except Exception as e:
                         extra["roofline"]["deployed"] = f"not measured: {type(e).__name__}: {e}"[:200]
-                if CO >= 3 and rb_timed != 0:
+                if 3 <= CO <= 4 and rb_timed != 0:
                     # The instrumented cohort runs ALONE on the GPU with the launch shapes of the timed configuration, which are chosen for R lanes
                     # sharing the GPU (fewer, larger workgroups: a launch costs CU-time in proportion to the bytes it ingests).  The same cohort with
                     # the shapes a single lane would pick (vispec_set_wide_row_blocks(0)) shows what each kernel does when it has the GPU to itself.
@@ -903,6 +903,9 @@ PROF_KERNEL_KEYS_WIDE = {"gemm_none": "gemm_w32_wide_kernel<0,", "gemm_residual"
 PROF_KERNEL_KEYS_WIDE8 = {"gemm_none": "gemm_w32_wide8_kernel<0,", "gemm_residual": "gemm_w32_wide8_kernel<1,", "gemm_swiglu": "gemm_w32_wide8_kernel<2,",
                           "gemm_splitk_partial": "gemm_w32_wide8_kernel<3,", "gemm_qkv_rope": "gemm_w32_wide8_kernel<4,",
                           "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
+PROF_KERNEL_KEYS_C8 = {"gemm_none": "gemm_w32_c8_kernel<0,", "gemm_residual": "gemm_w32_c8_kernel<1,", "gemm_swiglu": "gemm_w32_c8_kernel<2,",
+                       "gemm_splitk_partial": "gemm_w32_c8_kernel<3,", "gemm_qkv_rope": "gemm_w32_c8_kernel<4,",
+                       "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}
 PROF_KERNEL_KEYS_PAIRED = {"gemm_none": "gemm_w32_kernel<2, 0,", "gemm_residual": "gemm_w32_kernel<2, 1,", "gemm_swiglu": "gemm_w32_kernel<2, 2,",
                            "gemm_splitk_partial": "gemm_w32_kernel<2, 3,", "gemm_qkv_rope": "gemm_w32_kernel<2, 4,",
                            "attn_partial": "tree_attn2_partial_kernel", "attn_reduce": "tree_attn_reduce_kernel"}

@@ -1,0 +1,222 @@
+"""Cohorts of five to eight requests (csrc/gemm_c8.h: eight activation tiles per weight pass, ONE accumulator chain per output element).
+The c8 kernel gives up the bit-identity of a cohort row with the single-request kernel (whose K range is summed as four separately rounded
+quarters): its rows differ from the single-request rows in fp32 rounding.  What these tests hold instead:
+  * every epilogue against the fp64 product, rounded where the epilogues round, within the float bar of every other kernel (2^-6 of scale);
+  * a request's rows are BIT-IDENTICAL whatever shares its weight pass: other tile, other cohort size, other live-row count;
+  * whole loops: a request of a cohort of 5..8 returns the tokens it returns in any other cohort of 5..8, the speculative and the AR form of
+    such a cohort agree token for token, and on the confident models of the loop tests those are also the single-request tokens and the
+    oracle's."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from helpers import T, vo  # noqa: E402
+from vispec_amd import lib as L, synth  # noqa: E402
+from vispec_amd.model.spec_model_ours import baseline_generate_cohort, specgenerate_cohort, specgenerate_stream  # noqa: E402
+
+from test_kernels_gpu import dev, engine, lib, p, packed, stream, tb  # noqa: E402,F401
+from test_loop_gpu import IMG_TOK, build  # noqa: E402
+
+# whole groups / an odd number of groups per split (11008 = 172 groups, S = 4: 43) / one group (K = 64) / a ragged last workgroup
+# (1008 rows = 31.5 tiles, 96 rows = 3 tiles) / K not a multiple of a group (the fragment-shaped kernel) / the real layer shapes
+C8_SHAPES = [(256, 256), (256, 704), (1008, 256), (96, 11008), (64, 64), (256, 144), (4096, 4096), (12288, 4096), (4096, 11008), (22016 // 2, 4096),
+             (4608, 3584), (3584, 18944), (32064, 512)]
+
+
+def bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+def want_of(X, Wn, B, R, N, epi):
+    acc = X.double() @ Wn.double().T + B.double()
+    if epi == 0:
+        return bf(acc)
+    if epi == 1:
+        return bf(R.double() + bf(acc))
+    y, u = bf(acc[:, :N]), bf(acc[:, N:])
+    return bf(bf(y / (1 + torch.exp(-y))) * u)
+
+
+def c8_cases():
+    out = []
+    for N, K in C8_SHAPES:
+        for n_req, m_tile in [(8, 30), (5, 30), (7, 1), (6, 32), (8, 8)]:
+            for epi in (0, 1, 2):
+                if epi == 2 and N % 16:
+                    continue
+                if N * K > 2e7 and ((n_req, m_tile) != (8, 30) or epi == 1):
+                    continue
+                out.append((N, K, n_req, m_tile, epi))
+    return out
+
+
+@pytest.mark.parametrize("N,K,n_req,m_tile,epi", c8_cases())
+def test_c8_gemm_against_the_fp64_product(lib, engine, N, K, n_req, m_tile, epi):
+    rng = np.random.default_rng(N + 3 * K + 17 * n_req + m_tile + epi)
+    rows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    X, W, B, R = tb(x), packed(w, swiglu=(epi == 2)), tb(b), tb(r)
+    for t in range(n_req):
+        X[32 * t + m_tile:32 * t + 32] = float("nan")  # rows outside a request's live rows may hold anything
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(W), None, p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+    torch.cuda.synchronize()
+    live = torch.zeros(32 * n_req, dtype=torch.bool, device=dev())
+    for t in range(n_req):
+        live[32 * t:32 * t + m_tile] = True
+    want = want_of(torch.nan_to_num(X), tb(w), B, R, N, epi)
+    err = (Y.double() - want)[live].abs().max().item()
+    scale = want[live].abs().max().item()
+    assert err <= scale * 2.0 ** -6, (err, scale)  # one bf16 ulp of the tensor's largest magnitude: the float bar of every GEMM test
+    assert (Y[~live].float() == 7.0).all(), "padding rows of a tile must stay untouched"
+
+
+@pytest.mark.parametrize("N,K", [(256, 704), (1008, 256), (4096, 4096), (512, 11008), (64, 64), (256, 144)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_c8_rows_do_not_depend_on_what_shares_the_weight_pass(lib, engine, N, K, epi):
+    """The same 30 rows as tile 2 of eight, as tile 4 of five next to other neighbours, and its first row as a one-row tile 6 of seven
+    (the AR step's shape): bit for bit the same outputs."""
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    rng = np.random.default_rng(N + K + epi)
+    rows = 2 * N if epi == 2 else N
+    mine = synth.bf16_grid(rng.standard_normal((32, K), dtype=np.float32))
+    rmine = synth.bf16_grid(rng.standard_normal((32, N), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    W, B = packed(w, swiglu=(epi == 2)), tb(b)
+    outs = []
+    for n_req, tile, m_tile in [(8, 2, 30), (5, 4, 30), (7, 6, 1), (8, 7, 30)]:
+        x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+        r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+        x[32 * tile:32 * tile + 32] = mine
+        r[32 * tile:32 * tile + 32] = rmine
+        X, R = tb(x), tb(r)
+        Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+        L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(W), None, p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+        torch.cuda.synchronize()
+        outs.append(Y[32 * tile:32 * tile + m_tile].view(torch.int16).cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[3])
+    np.testing.assert_array_equal(outs[0][:1], outs[2])
+
+
+@pytest.mark.parametrize("N,K,epi", [(N, K, e) for N, K in [(256, 704), (4096, 3584), (1024, 18944), (96, 11008), (4608, 3584), (256, 256), (256, 160)]
+                                     for e in (0, 1, 2) if not (e == 2 and N % 16)])
+@pytest.mark.parametrize("n_req", [5, 8])
+def test_c8_gemm_fp8_weights_against_the_fp64_product(lib, engine, N, K, n_req, epi):
+    """W8A16 (e4m3 weights up-converted exactly, per-output-channel scale on the fp32 accumulator): against the fp64 product of the
+    DEQUANTISED weights."""
+    from vispec_amd.engine import pack_weight_fp8, quantize_fp8, swiglu_order
+    m_tile = 30
+    rng = np.random.default_rng(N + K + n_req + epi)
+    rows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((rows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    q_u8, sc = quantize_fp8(tb(w))
+    P8 = pack_weight_fp8(swiglu_order(q_u8) if epi == 2 else q_u8)
+    X, B, R = tb(x), tb(b), tb(r)
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, n_req, m_tile, N, K, epi))
+    torch.cuda.synchronize()
+    wq = q_u8.view(torch.float8_e4m3fn).double() * sc.double()[:, None]
+    acc = (X.double() @ wq.T) + B.double()
+    if epi == 0:
+        want = bf(acc)
+    elif epi == 1:
+        want = bf(R.double() + bf(acc))
+    else:
+        y, u = bf(acc[:, :N]), bf(acc[:, N:])
+        want = bf(bf(y / (1 + torch.exp(-y))) * u)
+    live = torch.zeros(32 * n_req, dtype=torch.bool, device=dev())
+    for t in range(n_req):
+        live[32 * t:32 * t + m_tile] = True
+    err = (Y.double() - want)[live].abs().max().item()
+    scale = want[live].abs().max().item()
+    assert err <= scale * 2.0 ** -6, (err, scale)
+    assert (Y[~live].float() == 7.0).all()
+
+
+def single(sm, ids, kw, **gen):
+    return sm.specgenerate(ids, log=True, return_acceptance_len=True, **gen, **kw)
+
+
+def make_requests(golden_dir, n, seed=91):
+    rng = np.random.default_rng(seed)
+    g = np.load(os.path.join(golden_dir, "g8_loop.npz"))
+    reqs = [(torch.from_numpy(g["succ0_ids"])[None], {}), (torch.from_numpy(g["succ1_ids"])[None], {})]
+    for i, ln in enumerate((17, 9, 23, 12, 20, 7, 15, 11, 14, 19)):
+        if i % 3 == 1:  # an image prompt every third request
+            n_img = 11 + i
+            ids = np.concatenate([rng.integers(3, IMG_TOK, 4), np.full(n_img, IMG_TOK), rng.integers(3, IMG_TOK, ln)])
+            feats = synth.bf16_grid(rng.standard_normal((n_img, T["D"]), dtype=np.float32) * 0.05)
+            reqs.append((torch.from_numpy(ids)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda())))
+        else:
+            reqs.append((torch.from_numpy(rng.integers(3, IMG_TOK, size=ln))[None], {}))
+    return reqs[:n], g
+
+
+@pytest.mark.parametrize("n_req", [5, 8])
+def test_cohort_of_five_and_eight_whole_loops(golden_dir, n_req):
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    models = [sm] + [sm.make_cohort_member() for _ in range(7)]
+    reqs, g = make_requests(golden_dir, n_req)
+    budgets = [30, 22, 41, 17, 26, 35, 12, 29][:n_req]  # ragged: the requests finish in different rounds and freeze one after the other
+    got = specgenerate_cohort(models[:n_req], reqs, max_new_tokens=budgets)
+    # (1) the cohort's composition does not matter: the requests in reverse order, through other tiles, next to other neighbours
+    rev = specgenerate_cohort(models[:n_req], reqs[::-1], max_new_tokens=budgets[::-1])[::-1]
+    for t, (a, b) in enumerate(zip(got, rev)):
+        np.testing.assert_array_equal(a[0][0].cpu().numpy(), b[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert a[1:] == b[1:], f"request {t}"
+    if n_req == 8:  # ... and the first five of them in a cohort of five
+        five = specgenerate_cohort(models[:5], reqs[:5], max_new_tokens=budgets[:5])
+        for t, (a, b) in enumerate(zip(got[:5], five)):
+            np.testing.assert_array_equal(a[0][0].cpu().numpy(), b[0][0].cpu().numpy(), err_msg=f"request {t}")
+            assert a[1:] == b[1:]
+    # (2) speculative == greedy AR at the same batching, token for token
+    ar = baseline_generate_cohort(models[:n_req], reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), a) in enumerate(zip(got, ar)):
+        n = min(toks.shape[1], a.shape[1])
+        assert n >= reqs[t][0].shape[1] + budgets[t]
+        np.testing.assert_array_equal(toks[0, :n].cpu().numpy(), a[0, :n].cpu().numpy(), err_msg=f"request {t}: speculative != AR")
+    # (3) on these (confident) models the c8 rounding changes no decision: the single-request tokens, accept lengths, round counts
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    # ... and request 0 is the oracle's / the reference fixture's stream
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, g["succ0_ids"], max_new_tokens=30, max_pos=T["max_pos"])
+    np.testing.assert_array_equal(got[0][0][0].cpu().numpy(), o_out)
+    assert got[0][3] == o_acc
+
+
+@pytest.mark.parametrize("n_slots,temperature", [(8, 0.0), (6, 0.0), (8, 6.0)])
+def test_request_stream_through_eight_slots(golden_dir, n_slots, temperature):
+    """Continuous batching over 6 / 8 slots: twelve ragged requests (text and image prompts), greedy and sampling; each returns what it returns
+    alone, and the graphs are replayed."""
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    models = [sm] + [sm.make_cohort_member() for _ in range(n_slots - 1)]
+    reqs, g = make_requests(golden_dir, 12, seed=97)
+    budgets = [30, 12, 41, 8, 25, 33, 5, 19, 27, 16, 22, 9]
+    seeds = list(range(40, 52))
+    gen = dict(temperature=temperature, top_k=8) if temperature > 0 else {}
+    want = [single(sm, *r, max_new_tokens=b, seed=sd, **gen) for r, b, sd in zip(reqs, budgets, seeds)]
+    st = {}
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got = specgenerate_stream(models, reqs, max_new_tokens=budgets, seeds=seeds, stats=st, **gen)
+        side.synchronize()
+    assert sm.engine.graph_stats()["replays"] > 0
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3]), f"request {t}"

@@ -224,7 +224,7 @@ class Engine:
                  top_k=8, num_q=2, kv_max_pos: Optional[int] = None, draft_max_pos: Optional[int] = None, eager_scores=None,
                  target_weight_dtype: str = "bf16", leader: Optional["Engine"] = None):
         """leader: build this engine as a COHORT MEMBER of `leader` (same configs and weights): its activation workspaces alias one
-        32-row tile of the leader's (up to three members per leader), so `leader.cohort_round([members...])` runs all their rounds on one
+        32-row tile of the leader's (up to seven members per leader), so `leader.cohort_round([members...])` runs all their rounds on one
         weight pass."""
         if eager_scores is None:
             eager_scores = tcfg.attn_impl == "eager"
@@ -399,7 +399,7 @@ class Engine:
         L.check(self.lib.vispec_draft_round(self.h, self._stream()))
 
     def cohort_round(self, members, forced_accept: int = -1):
-        """One draft-and-verify round of 2..4 requests (this engine's and its members', created with leader=self) on one weight pass."""
+        """One draft-and-verify round of 2..8 requests (this engine's and its members', created with leader=self) on one weight pass."""
         members = [members] if isinstance(members, Engine) else list(members)
         hs = [self] + members
         if any(e.h is None for e in hs):

@@ -437,14 +437,14 @@ class SpecModel:
 
 @torch.no_grad()
 def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=2048, stats=None):
-    """The AR baseline (gen_baseline_answer_coco_caption.py:34-133) for two to four requests in LOCKSTEP on one weight pass: what
+    """The AR baseline (gen_baseline_answer_coco_caption.py:34-133) for two to eight requests in LOCKSTEP on one weight pass: what
     specgenerate_cohort is to specgenerate.  models / requests as there; max_new_tokens may be a list.  Returns one [1, L + new] id tensor
     per request — the tokens `m.baseline_generate(ids, ...)` returns for that request alone (every row keeps the single-request
     arithmetic; a request that reaches EOS or its budget freezes on the device while the others go on).  The speed-up bench.py prints
     divides a cohort's speculative tokens/s by THIS rate: like by like (speed.py:56-97)."""
     n = len(models)
-    if not 2 <= n <= 4 or len(requests) != n:
-        raise ValueError("a cohort is 2..4 models (leader, members...) and one request per model")
+    if not 2 <= n <= 8 or len(requests) != n:
+        raise ValueError("a cohort is 2..8 models (leader, members...) and one request per model")
     lead = models[0]
     for m in models[1:]:
         if m.engine.leader is not lead.engine:
@@ -471,7 +471,7 @@ def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=204
 @torch.no_grad()
 def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
                         forced_accept=None, stats=None):
-    """Two to four independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
+    """Two to eight independent requests through SpecModel.specgenerate's loop (spec_model_ours.py:247-582) in LOCKSTEP on one weight pass.
 
     models   = [leader, member, ...]  (members built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
     requests = [(input_ids [1,L], specgenerate kwargs), ...] one per model; max_new_tokens may be a list (one budget per request)
@@ -481,8 +481,8 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
     first is frozen on the device while the others complete.  `stats` (a dict, optional) receives the wall time of the round loop
     (`decode_s`, bracketed by synchronisations like specgenerate's return_decode_time) and the number of lockstep rounds (`rounds`)."""
     n = len(models)
-    if not 2 <= n <= 4 or len(requests) != n:
-        raise ValueError("a cohort is 2..4 models (leader, members...) and one request per model")
+    if not 2 <= n <= 8 or len(requests) != n:
+        raise ValueError("a cohort is 2..8 models (leader, members...) and one request per model")
     lead = models[0]
     for m in models[1:]:
         if m.engine.leader is not lead.engine:
