@@ -733,6 +733,8 @@ static int launch_gemm_c8(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
     if (!ctx) S = 1;
   }
   if (force_split > 0) S = force_split;
+  static const int c8_s_env = getenv("VISPEC_C8_SPLIT") ? atoi(getenv("VISPEC_C8_SPLIT")) : 0;  // experiments: the split factor of the split-K GEMMs
+  if (c8_s_env > 0 && S > 1 && force_split <= 0) S = std::min(c8_s_env, std::max(1, KS / 8));
   if (S == 1 && !o.norm_w) {
     prof_begin(s, epi == EPI_RESIDUAL ? 1 : 0, (double)N * K * (o.wscale ? 1.0 : 2.0));
     if (epi == EPI_RESIDUAL) C8_D(EPI_RESIDUAL, o.Y, o.ldy, 1); else C8_D(EPI_NONE, o.Y, o.ldy, 1);
