@@ -220,3 +220,32 @@ def test_request_stream_through_eight_slots(golden_dir, n_slots, temperature):
     for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
         np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
         assert (new_token, idx, acc) == (w[1], w[2], w[3]), f"request {t}"
+
+
+@pytest.mark.parametrize("N,K", [(256, 256), (256, 704), (1008, 256), (96, 11008), (4096, 4096), (64, 64), (32064, 512)])
+@pytest.mark.parametrize("n_req,rows", [(8, 8), (5, 5), (7, 1), (6, 8)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_two_tile_slab_rows_are_bit_identical_to_the_single_request_kernel(lib, engine, N, K, n_req, rows, epi):
+    """The draft's GEMMs of a cohort of 5..8 (gemm_w32_kernel SLAB with two activation tiles: tile row 8 t + i is row 32 t + i of X / Y / R):
+    the slab form keeps the single-request kernel's summation order, so its rows are that kernel's rows bit for bit."""
+    if epi == 2 and N % 16:
+        pytest.skip("SwiGLU needs N % 16 == 0")
+    rng = np.random.default_rng(N + 3 * K + 17 * n_req + rows + epi)
+    nrows = 2 * N if epi == 2 else N
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    w = synth.bf16_grid(rng.standard_normal((nrows, K), dtype=np.float32) * 0.05)
+    b = synth.bf16_grid(rng.standard_normal(nrows, dtype=np.float32))
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    X, W, B, R = tb(x), packed(w, swiglu=(epi == 2)), tb(b), tb(r)
+    for t in range(n_req):
+        X[32 * t + rows:32 * t + 32] = float("nan")
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_cohort(engine.h, stream(), p(X), K, p(W), None, p(B), p(Y), N, p(R), N, n_req, -rows, N, K, epi))
+    for t in range(n_req):
+        Y1 = torch.full((32, N), 7.0, dtype=torch.bfloat16, device=dev())
+        Xt, Rt = X[32 * t:32 * t + 32].contiguous(), R[32 * t:32 * t + 32].contiguous()
+        L.check(lib.vispec_gemm_skinny(engine.h, stream(), p(Xt), K, p(W), p(B), p(Y1), N, p(Rt), N, rows, N, K, epi))
+        torch.cuda.synchronize()
+        got, want = Y[32 * t:32 * t + 32].view(torch.int16).cpu().numpy(), Y1.view(torch.int16).cpu().numpy()
+        np.testing.assert_array_equal(got[:rows], want[:rows], err_msg=f"request {t}")
+        assert (Y[32 * t + rows:32 * t + 32].float() == 7.0).all(), "rows outside the live rows must stay untouched"

@@ -297,7 +297,7 @@ constexpr int gemm_w32_lds_bytes() {
                                                                                            : (NW * NT * MT * 4096);
 }
 
-// SLAB (MT = 1, m_tile < 0; the draft GEMMs of a cohort, whose requests have at most 8 live rows each — top_k rows of a tree level, depth + 2
+// SLAB (m_tile < 0, MT = 1: up to four requests, MT = 2 (round 5): five to eight; the draft GEMMs of a cohort, whose requests have at most 8 live rows each — top_k rows of a tree level, depth + 2
 // catch-up rows, one root row): the ONE activation tile holds up to four requests, tile row m = 8 t + i is row i of request t, which lives
 // at row 32 t + i of X / Y / R (the cohort members' tile-aliased workspaces, unchanged).  The weight pass then costs what a single request's
 // costs — one 32-row activation block per workgroup instead of the 128 rows of the wide form — and a row is the same dot products in the
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
   constexpr bool A8 = W8 == 2;
   // m_tile > 0 ("cohort"): the MT activation tiles belong to different requests, rows 32 mt .. 32 mt + m_tile - 1 of each are valid
   // (instead of the contiguous rows 0 .. M-1); the weights are still streamed once for all of them
-  static_assert(!SLAB || MT == 1, "slab mode packs the requests into one activation tile");
+  static_assert(!SLAB || MT <= 2, "slab mode packs up to four requests into each activation tile (MT = 2: five to eight requests)");
   auto row_ok = [&](int m) { return SLAB ? ((m & 7) < -m_tile && m < M) : (m_tile > 0 ? ((m & 31) < m_tile) : (m < M)); };
   auto grow = [&](int m) { return SLAB ? ((m >> 3) << 5) + (m & 7) : m; };  // row of X / Y / R that tile row m stands for
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
     const int tile_b = tile + tb * tile2_off;
     for (int mt = 0; mt < MT; ++mt) {
       const int m = 32 * mt + j;
-      const int rq = SLAB ? (j >> 3) : (m_tile > 0 ? mt : 0);  // request owning this tile (slab mode: this tile row)
+      const int rq = SLAB ? (m >> 3) : (m_tile > 0 ? mt : 0);  // request owning this tile (slab mode: this tile row)
       const int mr = SLAB ? (j & 7) : (m_tile > 0 ? j : m);    // row index inside the request
       if (wave < 2 * NT && row_ok(m)) {
         const int qq = wave & 1;
@@ -547,6 +547,12 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES 
           if (rq == 1) { ps_s = re.ps[1]; kc_s = re.kc[1]; vc_s = re.vc[1]; }
           if (rq == 2) { ps_s = re.ps[2]; kc_s = re.kc[2]; vc_s = re.vc[2]; }
           if (rq == 3) { ps_s = re.ps[3]; kc_s = re.kc[3]; vc_s = re.vc[3]; }
+          if (MT == 2) {
+            if (rq == 4) { ps_s = re.ps[4]; kc_s = re.kc[4]; vc_s = re.vc[4]; }
+            if (rq == 5) { ps_s = re.ps[5]; kc_s = re.kc[5]; vc_s = re.vc[5]; }
+            if (rq == 6) { ps_s = re.ps[6]; kc_s = re.kc[6]; vc_s = re.vc[6]; }
+            if (rq == 7) { ps_s = re.ps[7]; kc_s = re.kc[7]; vc_s = re.vc[7]; }
+          }
         }
         const PosSpec& ps_ = SLAB ? ps_s : re.ps[rq];
         bf16_t* const kc_ = SLAB ? kc_s : re.kc[rq];

@@ -483,7 +483,7 @@ template <int MT>
 static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, int M, int N, int K,
                           int epi, const GemmOut& o, int force_split) {
   if (M < 1 || M > 32 * MT) return fail("gemm_skinny: M out of range");
-  if (o.m_tile < 0 && MT != 1) return fail("gemm_skinny: slab mode is a one-tile launch");
+  if (o.m_tile < 0 && o.xscale) return fail("gemm_skinny: no fp8-activation slab form");
   if (N % 8 || K % 16 || (o.wscale && K % 32)) return fail("gemm_skinny: N %% 8 == 0 and K %% 16 (fp8: 32) == 0 required");
   if (epi == EPI_RESIDUAL && !o.R) return fail("gemm_skinny: residual epilogue without R");
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P, *b = (const bf16_t*)bias, *r = (const bf16_t*)o.R;
@@ -491,9 +491,9 @@ static int launch_gemm_mt(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   const int tiles = (N + 31) / 32, KS = K / (o.xscale ? 64 : (o.wscale ? 32 : 16));
 #define VISPEC_GEMM(NT_, EPI_, W8_, GRID, T2OFF, BIAS, YPTR, LDY, RPTR, LDR, SPLITS, SCALE)                                               \
   do {                                                                                                                                    \
-    if (MT == 1 && o.m_tile < 0)                                                                                                          \
-      PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT, (MT == 1)>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
-              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile, o.xscale);                                  \
+    if (o.m_tile < 0)                                                                                                                     \
+      PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, ((W8_) == 2 ? 1 : (W8_)), MT, true>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w, \
+              T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile, (const float*)nullptr);                      \
     else                                                                                                                                  \
       PLAUNCH((gemm_w32_kernel<NT_, EPI_, 4, 4, 0, W8_, MT>), GRID, dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, MT>()), s, x, ldx, w,       \
               T2OFF, BIAS, YPTR, LDY, RPTR, LDR, M, N, K, SPLITS, SCALE, RopeEpi{}, o.m_tile, o.xscale);                                  \
@@ -771,15 +771,7 @@ static int launch_gemm_ex(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx
   if (o.m_tile < 0) {  // slab mode: the requests' <= 8 live rows share one activation tile
     const int rows = -o.m_tile, n_req = (M - rows) / 8 + 1;
     if (rows > 8 || (M - rows) % 8 || n_req < 2 || n_req > MAX_COHORT) return fail("gemm_skinny: slab mode wants M = 8 (n - 1) + rows, rows <= 8, n in [2,8]");
-    if (n_req > 4) {  // five to eight requests: two slabs (requests 0..3, then 4..n-1 at rows 128.. of X / Y / R / normed), each the single-tile launch
-      if (o.q8 || o.xscale) return fail("gemm_skinny: no fp8-activation slab form");
-      if (launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, 24 + rows, N, K, epi, o, force_split)) return -1;
-      GemmOut o2 = o;
-      if (o.Y) o2.Y = (bf16_t*)o.Y + (size_t)128 * o.ldy;
-      if (o.R) o2.R = (const bf16_t*)o.R + (size_t)128 * o.ldr;
-      if (o.normed) o2.normed = (bf16_t*)o.normed + (size_t)128 * o.ldn;
-      return launch_gemm_mt<1>(ctx, s, (const bf16_t*)X + (size_t)128 * ldx, ldx, P, bias, 8 * (n_req - 5) + rows, N, K, epi, o2, force_split);
-    }
+    if (n_req > 4) return launch_gemm_mt<2>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);  // five to eight requests: two slab tiles, one weight pass
     return launch_gemm_mt<1>(ctx, s, X, ldx, P, bias, M, N, K, epi, o, force_split);
   }
   if (o.m_tile > 0) {
@@ -888,11 +880,7 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
     return 0;
   }
   if (M < 1 || Mk > ROWS || (n_req == 1 && M > 64) || (n_req > 1 && M > 32)) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
-  if (slab && n_req > 4) {  // five to eight requests in slab form: two single-tile launches (requests 0..3, then 4..n-1 at rows 128..)
-    if (launch_qkv_rope(ctx, s, X, ldx, P, bias, wscale, qkv, M, H, H_kv, K, cosT, sinT, rq, 4, s_max, true, xscale)) return -1;
-    return launch_qkv_rope(ctx, s, (const bf16_t*)X + (size_t)128 * ldx, ldx, P, bias, wscale, (bf16_t*)qkv + (size_t)128 * N, M, H, H_kv, K, cosT, sinT, rq + 4,
-                           n_req - 4, s_max, n_req - 4 >= 2, xscale);
-  }
+
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
@@ -915,7 +903,14 @@ static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ld
   PLAUNCH((gemm_w32_kernel<NT_, EPI_ROPE, 4, 4, 0, W8_, 1, true>), dim3(N / 32 / NT_, 1), dim3(256), (gemm_w32_lds_bytes<NT_, 4, 4, 1>()), s, \
                      (const bf16_t*)X, ldx, (const bf16_t*)P, (NT_ == 2 ? N / 64 : 0), (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,    \
                      (const float*)wscale, re, m_tile, (const float*)nullptr)
-    if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV_SLAB(true, 2); else if (wscale) VISPEC_QKV_SLAB(true, 1); else VISPEC_QKV_SLAB(false, 1);
+    if (n_req > 4) {  // five to eight requests: two slab tiles (N %% 128 == 0: the tile count is even -> the paired form)
+#define VISPEC_QKV_SLAB2(W8_)                                                                                                              \
+  PLAUNCH((gemm_w32_kernel<2, EPI_ROPE, 4, 4, 0, W8_, 2, true>), dim3(N / 64, 1), dim3(256), (gemm_w32_lds_bytes<2, 4, 4, 2>()), s,             \
+                     (const bf16_t*)X, ldx, (const bf16_t*)P, N / 64, (const bf16_t*)bias, qkv, N, nullptr, 0, Mk, N, K, 1,                  \
+                     (const float*)wscale, re, m_tile, (const float*)nullptr)
+      if (wscale) VISPEC_QKV_SLAB2(true); else VISPEC_QKV_SLAB2(false);
+#undef VISPEC_QKV_SLAB2
+    } else if (wscale && VISPEC_W8_PAIR_MT1 && !g_mt2_single_block) VISPEC_QKV_SLAB(true, 2); else if (wscale) VISPEC_QKV_SLAB(true, 1); else VISPEC_QKV_SLAB(false, 1);
 #undef VISPEC_QKV_SLAB
   } else if (xscale) {  // e4m3 activations: the paired form (two row blocks per workgroup), one or two activation tiles
     if (Mk <= 32) VISPEC_QKV(2, 1, 2); else VISPEC_QKV(2, 2, 2);
