@@ -249,3 +249,51 @@ def test_two_tile_slab_rows_are_bit_identical_to_the_single_request_kernel(lib, 
         got, want = Y[32 * t:32 * t + 32].view(torch.int16).cpu().numpy(), Y1.view(torch.int16).cpu().numpy()
         np.testing.assert_array_equal(got[:rows], want[:rows], err_msg=f"request {t}")
         assert (Y[32 * t + rows:32 * t + 32].float() == 7.0).all(), "rows outside the live rows must stay untouched"
+
+
+@pytest.fixture(scope="module")
+def eng8():
+    """An engine whose quantisation scratch is wide enough for the test shapes (K up to 18944): Qwen-tiny with a wide MLP."""
+    from vispec_amd.engine import DraftConfig, DraftWeightsDev, Engine, TargetConfig, TargetWeights
+    D, H, I, V, NL = 512, 4, 18944, 1024, 1
+    tcfg = TargetConfig(hidden_size=D, num_heads=H, num_kv_heads=2, intermediate_size=I, vocab_size=V, num_layers=NL, max_position_embeddings=512)
+    dcfg = DraftConfig(hidden_size=D, num_heads=H, intermediate_size=704, vocab_size=V, max_position_embeddings=512)
+    tw = TargetWeights.from_state_dict(tcfg, synth.make_target_weights(D, H, I, V, NL, seed=0, H_kv=2), dev())
+    dw = DraftWeightsDev.from_state_dict(dcfg, synth.make_draft_weights(D, H, 704, V, seed=1), 2, dev())
+    return Engine(tcfg, dcfg, tw, dw)
+
+
+@pytest.mark.parametrize("N,K", [(4608, 3584), (3584, 18944), (256, 704), (1008, 256), (96, 11008), (256, 256), (256, 128), (256, 192)])
+@pytest.mark.parametrize("n_req,m_tile", [(8, 30), (5, 30), (7, 1)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_c8_gemm_fp8_activations_against_the_oracle(lib, eng8, N, K, n_req, m_tile, epi):
+    """W8A8 on the cohort-8 kernel (v_mfma_scale_f32_32x32x64_f8f6f4, one accumulator chain): the oracle's Ops.linear(a8=True) per request,
+    with the tolerance of tests/test_fp8a8_gpu.py's unit test."""
+    from test_fp8a8_gpu import _weights
+    from test_kernels_gpu import assert_bf16_close, fn
+    if epi == 2 and N % 16:
+        N = N // 16 * 16
+    rng = np.random.default_rng(N + K + n_req + epi)
+    P8, sc, Wt, rows = _weights(N, K, epi, rng)
+    x = synth.bf16_grid(rng.standard_normal((32 * n_req, K), dtype=np.float32))
+    b = synth.bf16_grid(rng.standard_normal(rows, dtype=np.float32) * 0.1)
+    r = synth.bf16_grid(rng.standard_normal((32 * n_req, N), dtype=np.float32))
+    X, B, R = tb(x), tb(b), tb(r)
+    Y = torch.full((32 * n_req, N), 7.0, dtype=torch.bfloat16, device=dev())
+    L.check(lib.vispec_gemm_fp8a8(eng8.h, stream(), p(X), K, p(P8), p(sc), p(B), p(Y), N, p(R), N, n_req, m_tile, 0, N, K, epi, None, None, C.c_float(0)))
+    torch.cuda.synchronize()
+    o = vo.Ops(bf16=True)
+    for t in range(n_req):
+        xt, rt = x[32 * t:32 * t + m_tile], r[32 * t:32 * t + m_tile]
+        if epi == 2:
+            gu = o.linear(xt, Wt, b, a8=True)
+            want = o.silu_mul(gu[:, :N], gu[:, N:])
+        else:
+            want = o.linear(xt, Wt, b, a8=True)
+            if epi == 1:
+                want = o.add(rt, want)
+        floor = np.abs(want).max(axis=-1, keepdims=True) / 16
+        # (outlier_frac: one element of a 30 x 1008 SwiGLU tile where the gate's and the up value's roundings both flip is 3.3e-5 of the tile)
+        assert_bf16_close(fn(Y[32 * t:32 * t + m_tile]), want, min_exact=0.9, ulps=1 if epi == 0 else 2, outlier_frac=1e-4,
+                          scale=floor if epi != 1 else np.maximum(floor, np.maximum(np.abs(rt), np.abs(want))))
+        assert (Y[32 * t + m_tile:32 * t + 32].float() == 7.0).all()
