@@ -74,7 +74,7 @@ def resolve_weights(args):
     base, spec = args.base_model_path, args.spec_model_path
     root = args.weights_dir or os.environ.get("VISPEC_WEIGHTS")
     if not (base and spec) and root:
-        names = HUB_NAMES.get(MODEL.replace("-hires", "").replace("-fp8", ""))
+        names = HUB_NAMES.get(MODEL.split("-")[0])  # ("qwen7b-fp8a8", "qwen7b-hires" ... share the bf16 checkpoint pair)
         if names:
             cand = [os.path.join(root, n) for n in names]
             cand_flat = [os.path.join(root, n.split("/")[-1]) for n in names]
@@ -441,9 +441,18 @@ def dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device, iters=24):
     wall_ms = max(e0.elapsed_time(e) for e in ends)
     nbytes = 2 * I * D * (1 if fp8 else 2)
     ach = iters * R * nbytes / (wall_ms * 1e-3) / 1e9
+    a8_note = (" — NOTE: this model's timed region runs the W8A8 instantiation (e4m3 activations + its quantisation pass); this leg launches the W8A16 "
+               "kernel on the same weights (bf16 activations): not the timed region's kernel") if MODEL.endswith("fp8a8") else ""
     return dict(what=f"gate|up + SwiGLU for {CO} requests launched on all {R} lanes' streams at once (vispec_gemm_cohort, the timed region's launch shape; every "
-                     f"launch on another layer's weights), {iters} launches per lane", streams=R, launches=iters * R,
+                     f"launch on another layer's weights), {iters} launches per lane" + a8_note, streams=R, launches=iters * R,
                 us_per_launch_per_stream=round(1e3 * wall_ms / iters, 2), achieved=round(ach, 1), unit="GB/s", frac=round(ach / 8000.0, 4))
+
+
+def prefill_gemm_mode():
+    """Which library kernels ran the prefill GEMMs: "recorded" = the committed TunableOp table matched this PyTorch / ROCm / GPU; anything else
+    names why the libraries' defaults ran (+10 % prefill time, measured in round 4)."""
+    from vispec_amd.model.target import prefill_gemm_selection
+    return prefill_gemm_selection()
 
 
 def self_launch(n):
@@ -888,7 +897,8 @@ def main():
                                    if REAL_WEIGHTS else
                                    f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
                                    f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)"),
-                       "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)"},
+                       "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)",
+                       "prefill_gemms": prefill_gemm_mode()},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }
         line.update(extra)

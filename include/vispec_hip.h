@@ -74,9 +74,12 @@ const char* vispec_last_error(void);
 int  vispec_version(void);
 
 int  vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out);
-/* Cohort member: another request context whose activation workspaces are one 32-row tile of `leader`'s 128-row workspaces (the first
-   member owns tile 1, the second tile 2, the third tile 3; a fourth is refused), so that the cohort round functions below can launch
-   every GEMM once for all requests (same config as the leader; destroy it before the leader).
+/* Cohort member: another request context whose activation workspaces are one 32-row tile of `leader`'s 256-row workspaces (the first
+   member owns tile 1, the second tile 2, ... the seventh tile 7; an eighth is refused), so that the cohort round functions below can launch
+   every GEMM once for all requests (same config as the leader).  Lifetime: destroy the members before the leader; a leader destroyed
+   while members are alive keeps its allocations until its last member is destroyed (the members stay usable as single requests) and its
+   HANDLE IS INVALID from that call on — every entry point refuses it while a member is alive, and it must not be passed anywhere (not
+   even to vispec_ctx_destroy again) once the last member is gone.
    A member is otherwise an ordinary ctx: own round state, tree, KV caches (vispec_set_kv), prefill calls. */
 int  vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out);
 void vispec_ctx_destroy(vispec_ctx* ctx);
@@ -111,7 +114,7 @@ int vispec_gemm_skinny(vispec_ctx*, void* stream, const void* X, int ldx, const 
 int vispec_gemm_skinny_norm(vispec_ctx*, void* stream, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
                             const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M, int N, int K);
 /* W8A8 (vispec_set_fp8_activations) at unit level (tests): Y = bf16((q_x . q_w^T) * wscale[n] * sx[m] + b) [+ epilogue], X bf16 quantised per
-   row inside (sx = max|x| / 448, q = e4m3(x / sx)).  n_req = 1: M <= 64 rows; n_req = 2..4: vispec_gemm_cohort's row layout.  norm_w != NULL:
+   row inside (sx = max|x| / 448, q = e4m3(x / sx)).  n_req = 1: M <= 64 rows; n_req = 2..8: vispec_gemm_cohort's row layout.  norm_w != NULL:
    + residual and the fused RMSNorm of the split-K reduce (o_proj / down_proj form), written to `normed` (ld N).  No reference counterpart. */
 int vispec_gemm_fp8a8(vispec_ctx*, void* stream, const void* X, int ldx, const void* P8, const void* wscale_f32, const void* bias, void* Y, int ldy,
                       const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps);
@@ -123,7 +126,9 @@ int vispec_quant_rows_e4m3(vispec_ctx*, void* stream, const void* X, int ldx, vo
    device on `stream`.  After vispec_gemm_fp8a8 with norm_w: the quantised `normed` rows, written by the split-K reduce itself (the fused form of
    the quantisation pass that target_forward uses for the q|k|v and gate|up inputs). */
 int vispec_a8_scratch_read(vispec_ctx*, void* stream, void* codes_out, void* scales_out, int rows, int K);
-/* The GEMM of a cohort round at unit level (tests): n_req = 2..4 requests of m_tile <= 32 rows each; request t's rows are rows
+/* The GEMM of a cohort round at unit level (tests): n_req = 2..8 requests of m_tile <= 32 rows each (2..4: rows bit-identical to the
+   single-request kernel's; 5..8: csrc/gemm_c8.h's kernel — one accumulator chain per output element, rows independent of what shares the
+   launch but not bit-identical to the single-request order; m_tile < 0, the slab form, keeps the single-request order at every n_req); request t's rows are rows
    32t .. 32t + m_tile - 1 of X / Y / R (which therefore span 32 n_req rows; rows beyond m_tile of a tile are neither read for results
    nor written).  Same epilogues as vispec_gemm_skinny (0 none, 1 +R, 2 SwiGLU).  Row for row bit-identical to vispec_gemm_skinny on the
    request's own rows.  m_tile in [-8, -1] = the draft's slab form: the requests have -m_tile <= 8 live rows each (top_k rows of a tree
@@ -224,7 +229,11 @@ int vispec_draft_round(vispec_ctx*, void* stream);
    bit.  A request that has finished (done != 0) is frozen on the device while its partner completes.  total_token <= 32. */
 int vispec_cohort_verify_accept(vispec_ctx* leader, vispec_ctx* member, void* stream, int forced_accept);
 int vispec_cohort_draft_round(vispec_ctx* leader, vispec_ctx* member, void* stream);
-/* The same for n = 2..4 requests: ctxs[0] = the leader, the others its members owning activation tiles 1 .. n-1 (any order).  With
+/* The same for n = 2..8 requests: ctxs[0] = the leader, the others its members owning activation tiles 1 .. n-1 (any order).  Five to
+   eight requests (round 5): the target's GEMMs run on csrc/gemm_c8.h's kernel (8 weight row blocks x 8 request tiles per workgroup, ONE
+   accumulator chain per output element: a request's tokens do not depend on what shares its weight pass, its logits differ from the
+   single-request kernel's in fp32 summation order only — tests/test_c8_gpu.py, tests/test_full_size_gpu.py), the draft's in the two-tile
+   slab form (single-request order), attention / per-request kernels as one launch for all eight.  With
    three or four requests the GEMMs run on csrc/gemm_wide.h's kernel (16 waves = 4 weight row blocks x 4 K-quarters sharing each staged
    activation group; per-row arithmetic identical to the single-request kernel), attention takes all requests in one partial + one
    reduce launch.  Same guarantees: every request's tokens are those of the same request alone, bit for bit. */
@@ -259,7 +268,7 @@ int vispec_set_uniform_override_host(vispec_ctx*, void* stream, const float* u, 
 int vispec_set_next_token(vispec_ctx*, void* stream, const int* token_dev);
 /* Plain autoregressive step of the target with the same kernels (gen_baseline_answer_coco_caption.py:111-129). */
 int vispec_ar_step(vispec_ctx*, void* stream);
-/* The same for the n = 2..4 requests of a cohort (ctxs as for vispec_cohortn_verify_accept) on ONE weight pass: the AR baseline at the
+/* The same for the n = 2..8 requests of a cohort (ctxs as for vispec_cohortn_verify_accept) on ONE weight pass: the AR baseline at the
    batching of the speculative run it is compared with (speed.py:56-97 divides like by like).  Row for row vispec_ar_step's arithmetic:
    a request's AR tokens do not depend on its cohort; a finished request (done != 0) freezes while the others go on. */
 int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stream);
@@ -287,10 +296,12 @@ int vispec_set_graphs(vispec_ctx*, int on);
 /* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"; the reference has no fp8 path): with fp8 target weights, also take the ACTIVATIONS of the
    target's q|k|v, gate|up and down GEMMs (modeling_qwen2_5_vl_kv.py:1065-1170; o_proj keeps bf16 activations) in e4m3 — one dynamic scale per row —
    and multiply on v_mfma_scale_f32_32x32x64_f8f6f4 (W8A8) instead of up-converting the weight codes for the bf16 MFMA (W8A16, the default).
-   A different arithmetic ("same accepted tokens or documented divergence"); lm_head, draft and prefill unchanged. */
+   A different arithmetic ("same accepted tokens or documented divergence"); lm_head and draft unchanged.  This switch
+   covers the library's verify / AR forwards; the Python prefill of a target_weight_dtype="fp8a8" model (vispec_amd/model/target.py) quantises
+   the same three GEMM inputs with vispec_quant_rows_e4m3 and runs them on the library's fp8 x fp8 GEMM (torch._scaled_mm) as well. */
 int vispec_set_fp8_activations(vispec_ctx*, int on);
 int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, direct runs} */
-/* Launch shape of the GEMMs of a three- or four-request cohort round (no reference counterpart: the reference is batch-1 only,
+/* Launch shape of the GEMMs of a three- or four-request cohort round (five to eight requests always run gemm_c8.h's one shape) (no reference counterpart: the reference is batch-1 only,
    spec_model_ours.py:247-582): weight row blocks per workgroup — 4 (default: one byte of activations per weight byte; for a GPU that
    several request lanes keep busy), 3 or 2 (more, smaller workgroups), 0 (the smallest of {2, 3, 4} whose grid still runs in one round
    of CUs: a single lane), 8 (round 4: eight row blocks per workgroup, the K range walked quarter by quarter by every wave — half the

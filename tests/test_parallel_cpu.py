@@ -95,6 +95,10 @@ def test_bench_resolves_real_checkpoint_directories(tmp_path, monkeypatch):
     bench.MODEL = "qwen7b-fp8"  # the fp8 / high-res variants use the Qwen2.5-VL-7B pair
     assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(flat))) == (
         str(flat / "Qwen2.5-VL-7B-Instruct"), str(flat / "ViSpec-Qwen2.5-VL-7B-Instruct"))
+    for variant in ("qwen7b-fp8a8", "qwen7b-hires"):  # (round-4 advice: "-fp8a8" used to leave "qwen7ba8" and fall back to synthetic weights silently)
+        bench.MODEL = variant
+        assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(flat))) == (
+            str(flat / "Qwen2.5-VL-7B-Instruct"), str(flat / "ViSpec-Qwen2.5-VL-7B-Instruct"))
     bench.MODEL = "llava13b"  # not in this directory: synthetic
     assert bench.resolve_weights(NS(base_model_path=None, spec_model_path=None, weights_dir=str(flat))) is None
     bench.MODEL = "llava7b"

@@ -142,6 +142,7 @@ extern "C" int vispec_version(void) { return 1; }
 #define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
 static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
+  if (leader && leader->zombie) return fail("ctx_create_member: the leader was destroyed");
   if (leader && (leader->leader || memcmp(&leader->c, cfg, sizeof(vispec_config)) != 0))
     return fail("ctx_create_member: the leader must be an ordinary ctx created with the same config");
   if (leader && cfg->total_token > 32) return fail("ctx_create_member: a cohort member owns one 32-row activation tile: total_token <= 32");
@@ -1381,7 +1382,7 @@ extern "C" int vispec_gemm_qkv_rope(vispec_ctx* ctx, void* stream, const void* X
 extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* q, int ldq, const void* k_cache,
                                      const void* v_cache, int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev,
                                      int tail, const uint64_t* mask_dev, void* out, int ldo, int eager_scores) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   if (hd != 128) return fail("tree_attention: head_dim must be 128");
   return launch_attention(ctx, (hipStream_t)stream, q, ldq, k_cache, v_cache, s_max, H, H_kv, M, prefix_dev, tail,
                           (const unsigned long long*)mask_dev, out, ldo, eager_scores, s_max);
@@ -1481,24 +1482,25 @@ extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
   return 0;
 }
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   if (row_blocks != 0 && row_blocks != 8 && row_blocks != 84 && (row_blocks < 2 || row_blocks > 4))
     return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 for bf16 weights, 4 for fp8: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
   return 0;
 }
 // fp8 (e4m3) ACTIVATIONS for the target's q|k|v, gate|up and down GEMMs (o_proj stays W8A16) of the verify / AR forwards (BASELINE config 5, "CDNA4 fp8 MFMA"): each GEMM
-// input is quantised per row (dynamic scale) and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4.  Needs fp8 target weights; the lm_head,
-// the draft and the PyTorch prefill keep bf16 activations.  Set it on every ctx of a cohort.  (Cached graphs are dropped.)
+// input is quantised per row (dynamic scale) and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4.  Needs fp8 target weights; the lm_head
+// and the draft keep bf16 activations (the PyTorch prefill of an "fp8a8" model quantises the same three GEMM inputs itself and runs the library's
+// fp8 x fp8 GEMM: model/target.py).  Set it on every ctx of a cohort.  (Cached graphs are dropped.)
 extern "C" int vispec_set_fp8_activations(vispec_ctx* ctx, int on) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   if (on && (ctx->c.hidden_size % 64 || ctx->c.intermediate_size % 64)) return fail("fp8 activations need hidden and intermediate sizes that are multiples of 64");
   ctx->a8 = on != 0;
   for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
   return 0;
 }
 extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   ctx->use_graphs = on != 0;
   return 0;
 }
@@ -1529,7 +1531,7 @@ __global__ void set_first_token_kernel(DevState* st, const int* tok, int draft_l
 }
 
 extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* prompt_ids_host, int L, int max_new_tokens) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   if (L < 1 || L + c.total_token + 8 > c.max_pos) return fail("prompt does not fit the KV cache");
@@ -1724,7 +1726,7 @@ static int draft_round_body(const Cohort& co, hipStream_t s) {
   return draft_grow_tree(co, s);
 }
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipStream_t s = (hipStream_t)stream;
   const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(co, s); });
@@ -1732,7 +1734,7 @@ extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
 
 extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* hidden, const void* embeds,
                                     const uint8_t* image_mask_host, int L, const int* first_token_dev) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
@@ -2062,7 +2064,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
 }
 
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipStream_t s = (hipStream_t)stream;
   const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_verify, graph_key(ctx, forced_accept, true), [&]() {
@@ -2071,11 +2073,11 @@ extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_ac
   });
 }
 extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   return target_forward(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token);
 }
 extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   return target_accept(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token, forced_accept);
 }
 
@@ -2165,7 +2167,7 @@ extern "C" int vispec_set_retrieve_host(vispec_ctx* ctx, void* stream, const int
 // multinomial) from a host table instead of the counter-based generator — the way the reference's RECORDED draws (tests/golden g7) are fed
 // to verify_accept_sample_kernel.  u = [n_leaf, max_depth] row-major; u == NULL switches the override off.  Blocking.
 extern "C" int vispec_set_uniform_override_host(vispec_ctx* ctx, void* stream, const float* u, int n_leaf, int max_depth, float u_final) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   if (!u) { ctx->u_over_on = false; return 0; }
   if (n_leaf < 1 || n_leaf > TREE_MAX_T || max_depth < 1 || max_depth > TREE_RET_W) return fail("uniform_override: bad shape");
   std::vector<float> tab(TREE_MAX_T * TREE_RET_W + 1, 2.0f);  // (2 = never accepted)
@@ -2183,7 +2185,7 @@ __global__ void set_stop2_kernel(DevState* st, int tok) {
 }
 // is_llama3: "<|eot_id|>" among the generated ids also ends the request (spec_model_ours.py:268-269, 540-542); after begin_request
 extern "C" int vispec_set_stop_token(vispec_ctx* ctx, void* stream, int token_id) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipLaunchKernelGGL(set_stop2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, token_id);
   KCHK();
   return 0;
@@ -2193,7 +2195,7 @@ __global__ void set_rope_delta_kernel(DevState* st, int delta) {
 }
 // spec_model_ours.py:179-201 changes the tree size after construction (`model.spec_layer.total_tokens = total_token - 1`)
 extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   const vispec_config& c = ctx->c;
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
@@ -2205,7 +2207,7 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   return 0;
 }
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipLaunchKernelGGL(set_rope_delta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, delta);
   KCHK();
   return 0;
@@ -2213,7 +2215,7 @@ extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
 
 // temperature <= 1e-5: greedy (utils.py:438-451); > 1e-5: sampling (utils.py:453-493) with the counter-based uniforms of `seed`.
 extern "C" int vispec_set_sampling(vispec_ctx* ctx, float temperature, unsigned long long seed) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   ctx->temperature = temperature;
   ctx->seed = seed;
   ctx->sample_top_k = 0;
@@ -2243,7 +2245,7 @@ extern "C" int vispec_set_next_token(vispec_ctx* ctx, void* stream, const int* t
 }
 
 extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
-  if (!ctx) return fail("null ctx");
+  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
   hipStream_t s = (hipStream_t)stream;
   return run_graphed(ctx, s, ctx->g_ar, graph_key(ctx, -1, false), [&]() {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);

@@ -638,6 +638,13 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
                 valid_from[t] = k_enq  # it is part of the rounds launched from now on
         if k_enq == k_done and any(i is not None for i in slot):
             launch()
+    # the round launched ahead of the last snapshot (lookahead) is still in flight: wait for its snapshot too, so that nothing of this call is
+    # running on the stream when it returns.  (A request ended by the HOST-only rule `rnd >= rounds_cap` (:484) is not frozen on the device: the
+    # round in flight may advance it once more — harmless, finish() took its tokens up to the snapshot's n_ctx, which that round does not
+    # rewrite, and the slot's next _start_request resets the device state in stream order.)
+    while k_done < k_enq:
+        lead.engine.cohort_states_wait(member_engines, k_done & 1)
+        k_done += 1
     if stats is not None:
         stats.update(rounds=lockstep, request_rounds=request_rounds)
     return outs

@@ -39,6 +39,9 @@ def prefill_gemm_selection():
                                                $VISPEC_PREFILL_GEMM_FILE): a shape in the table runs the recorded rocBLAS / hipBLASLt solution,
                                                any other shape — and every shape when the table's validators do not match this PyTorch /
                                                ROCm / GPU — runs the libraries' own default.  Deterministic; nothing is timed at run time.
+                                               (TunableOp is a process-wide switch of torch: in this mode every torch GEMM of the process does
+                                               one table lookup; shapes outside the table are untouched.  A host application that minds sets
+                                               VISPEC_PREFILL_GEMMS=default.)
       VISPEC_PREFILL_GEMMS=default             TunableOp stays off.
       VISPEC_PREFILL_GEMMS=tune                tuning on, results written to the file (tools/tune_prefill.py: offline, one process, idle GPU)."""
     if _gemm_state["mode"] is not None:
@@ -63,11 +66,17 @@ def prefill_gemm_selection():
                     tn.set_filename(path)
                     if not tn.read_file(path):  # validators of another stack: the libraries' defaults, and say so once
                         tn.enable(False)
-                        mode = "default (the recorded table does not match this PyTorch / ROCm / GPU)"
-                        import warnings
-                        warnings.warn(f"{path}: recorded prefill GEMM solutions ignored (validator mismatch); re-run tools/tune_prefill.py")
+                        # (no warning at import time of a host application — round-4 advice; the mode string says it, bench.py prints it in
+                        #  its line's config and VISPEC_PREFILL_GEMMS_STRICT=1 makes it an error)
+                        mode = "default (the recorded table does not match this PyTorch / ROCm / GPU: re-run tools/tune_prefill.py)"
+                        if os.environ.get("VISPEC_PREFILL_GEMMS_STRICT") == "1":
+                            raise RuntimeError(f"{path}: recorded prefill GEMM solutions do not match this PyTorch / ROCm / GPU (VISPEC_PREFILL_GEMMS_STRICT=1)")
                 else:
                     mode = "default (no recorded table)"
+            except RuntimeError as e:
+                if "VISPEC_PREFILL_GEMMS_STRICT" in str(e):
+                    raise
+                mode = f"default (TunableOp unavailable: {type(e).__name__})"
             except Exception as e:  # TunableOp is an optimisation: never lose a run to it
                 mode = f"default (TunableOp unavailable: {type(e).__name__})"
         _gemm_state["mode"] = mode
