@@ -310,7 +310,7 @@ def cpu_baseline_leg(sm, tcfg, req, host, rounds=6, ar_steps=4, budget_s=20.0):
     t_round = (sum(r["verify_s"]) + sum(r["draft_s"])) / rounds
     tau = float(np.mean(r["accept_lengths"]))
     t_ar = float(np.mean(r["ar_s"]))
-    return dict(value=round((tau + 1) / t_round, 3), unit="tokens/s", cores=cores, kind="port",
+    return dict(value=round((tau + 1) / t_round, 3), unit=f"tokens/s ({cores} threads of {os.cpu_count()} host cores)", cores=cores, kind="port",
                 ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar=round((tau + 1) / t_round * t_ar, 3), tau_measured=round(tau, 3),
                 seconds_per_round=round(t_round, 3), verify_s=round(float(np.mean(r["verify_s"])), 3), draft_s=round(float(np.mean(r["draft_s"])), 3),
                 draft_prefill_s=round(r["draft_prefill_s"], 2), host_cores=os.cpu_count(),
@@ -448,6 +448,42 @@ def dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device, iters=24):
                 us_per_launch_per_stream=round(1e3 * wall_ms / iters, 2), achieved=round(ach, 1), unit="GB/s", frac=round(ach / 8000.0, 4))
 
 
+def pin_to_gpu_numa_node(local):
+    """One rank per GPU, `lanes` host threads per rank (each issues hipGraph launches and waits on events): keep them on the cores of the NUMA
+    node the GPU hangs off, so that eight ranks on a two-socket node do not launch across the socket link (host-side launch
+    contention is the one scaling risk of a replicas-only design).  PCI address from the device properties -> /sys/bus/pci/devices/<addr>/numa_node
+    -> that node's cpulist -> os.sched_setaffinity (threads started later inherit it).  Anything missing (no NUMA information, a container that
+    hides /sys, VISPEC_BENCH_AFFINITY=0): no pinning, and the returned string says why.  -> description for the bench line."""
+    if os.environ.get("VISPEC_BENCH_AFFINITY", "1") == "0":
+        return "off (VISPEC_BENCH_AFFINITY=0)"
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return f"none (GPU {addr}: numa_node = -1, single-node host or no NUMA information)"
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"none (NUMA node {node} of GPU {addr} has no CPU this process may run on)"
+        os.sched_setaffinity(0, cpus)
+        return f"NUMA node {node} of GPU {addr}: {len(cpus)} CPUs"
+    except Exception as e:
+        return f"none ({type(e).__name__}: {e})"[:160]
+
+
+def host_usage():
+    """(process CPU seconds user + system, peak resident set size in GB) of this rank."""
+    import resource
+    t = os.times()
+    return t.user + t.system, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+
+
 def prefill_gemm_mode():
     """Which library kernels ran the prefill GEMMs: "recorded" = the committed TunableOp table matched this PyTorch / ROCm / GPU; anything else
     names why the libraries' defaults ran (+10 % prefill time, measured in round 4)."""
@@ -534,6 +570,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    affinity = pin_to_gpu_numa_node(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -632,10 +669,13 @@ def main():
     run_lanes([lane_fn(l, 0, W) for l in range(R)])
     lock[:] = [0] * R
     barrier()
+    cpu0, _ = host_usage()
     t0 = time.time()
     res = run_lanes([lane_fn(l, W, W + K) for l in range(R)])
     barrier()
     dt = time.time() - t0
+    cpu1, rss_gb = host_usage()
+    host_cpu_s, rank_wall_s = cpu1 - cpu0, dt  # what this rank's host side cost during the timed region (lane threads + launches + event waits)
     tokens = sum(r[0] for r in res)
     rounds = sum(r[1] for r in res)
     accs = [a for r in res for a in r[2]]
@@ -647,8 +687,12 @@ def main():
                            replicate_mode=os.environ.get("VISPEC_REPLICATE", "broadcast"),
                            backend=None if dist is None else dist.get_backend(), timed_request_ids=sorted(i for lane in plan for st_ in lane[W:W + K] for i in st_),
                            warmup_request_ids=sorted(i for lane in plan for st_ in lane[:W] for i in st_), tokens=int(tokens), rounds=int(rounds),
-                           wall_s=round(dt, 4)), f)
+                           wall_s=round(dt, 4), host_cpu_s=round(host_cpu_s, 3), host_cpu_per_wall=round(host_cpu_s / dt, 3), peak_rss_GB=round(rss_gb, 2),
+                           affinity=affinity, lanes=R), f)
     stats = torch.tensor([dt, tokens, rounds, sum(accs)], dtype=torch.float64, device=device)
+    host_mx = torch.tensor([host_cpu_s / rank_wall_s, rss_gb], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(host_mx, op=dist.ReduceOp.MAX)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -810,6 +854,17 @@ def main():
                                       algorithmic_GB_per_request_round=round(b_req_round / 1e9, 2),
                                       streamed_GBps_per_gpu=round(b_req_round * rounds / world / dt / 1e9, 1),
                                       frac_of_8TBps=round(b_req_round * rounds / world / dt / 8e12, 4))
+            if isinstance(extra.get("roofline"), dict):  # the line's roofline object also describes the TIMED REGION, not only one kernel alone
+                extra["roofline"].update(
+                    achieved_region=extra["aggregate"]["streamed_GBps_per_gpu"], frac_region=extra["aggregate"]["frac_of_8TBps"],
+                    request_rounds_per_s_per_gpu=extra["aggregate"]["request_rounds_per_s_per_gpu"],
+                    region_note="achieved_region / frac_region = algorithmic bytes of the whole timed region (weights / cohort + own KV per request-round) "
+                                "per second per GPU over 8 TB/s; `achieved` / `frac` above = the dominant kernel alone on the GPU")
+                bk = extra["roofline"].get("by_kernel", {})
+                tot = {k: v["launches"] * v["avg_launch_us"] for k, v in bk.items() if k.startswith("gemm")}
+                if tot:
+                    kmax = max(tot, key=tot.get)
+                    extra["roofline"]["largest_total_time_gemm"] = dict(kernel=kmax, share_of_gemm_time=round(tot[kmax] / sum(tot.values()), 3), **bk[kmax])
             if sum(lock):  # continuous batching: share of the (lockstep round x slot) grid that carried a live request (rank 0's lanes)
                 extra["aggregate"]["slot_utilisation"] = round(sum(r[1] for r in res) / (CO * sum(lock)), 4)
             # ---- AR baseline legs (gen_baseline_answer_coco_caption.py): same requests, same kernels at T=1, whole-request wall time;
@@ -899,6 +954,10 @@ def main():
                                    f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)"),
                        "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)",
                        "prefill_gemms": prefill_gemm_mode()},
+            # what one rank costs the HOST during the timed region (max over ranks): R lane threads issuing one hipGraph launch per phase and one
+            # event wait per round.  host_cpu_per_wall = busy host cores per rank; x 8 ranks must stay well below the node's cores.
+            "host": {"cpu_s_per_wall_s": round(float(host_mx[0]), 3), "rank0_cpu_s": round(host_cpu_s, 2), "rank0_wall_s": round(rank_wall_s, 3),
+                     "peak_rss_GB": round(float(host_mx[1]), 2), "lane_threads": R, "host_cores": os.cpu_count(), "affinity": affinity},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }
         line.update(extra)

@@ -55,8 +55,20 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
   static_assert(LA == 2, "the group bodies below are written for two groups of lookahead");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
-  const int split = blockIdx.y;
-  const int tile_raw = blockIdx.x * 8 + wave;
+  // Split-K launches: the workgroups of one split read the same [256, K / S] slice of X.  Workgroups go to the XCDs round-robin by linear id
+  // (id % 8, MI355X_MICROARCH.md: observed, for speed only), so with the plain (blockIdx.x, blockIdx.y) mapping every XCD's L2 fetches the
+  // WHOLE X (8 x X bytes over the fabric per launch: 1.47 x the algorithmic bytes of the o_proj / down launches at eight requests,
+  // profiles/r05_pmc_fetch_size.json).  Remapped: a split's workgroups share 8 / S XCDs, each L2 holds only its splits' slices.
+  int split = blockIdx.y, bx = blockIdx.x;
+#ifndef VISPEC_C8_XCD_SWIZZLE
+#define VISPEC_C8_XCD_SWIZZLE 1
+#endif
+  if (VISPEC_C8_XCD_SWIZZLE && (S == 2 || S == 4 || S == 8) && gridDim.x % (8 / S) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, r = lin >> 3, xps = 8 / S;
+    split = xcd / xps;
+    bx = r * xps + xcd % xps;
+  }
+  const int tile_raw = bx * 8 + wave;
   const bool tile_ok = tile_raw < tiles;
   const int tile = tile_ok ? tile_raw : 0;  // a ragged last workgroup streams tile 0 again and stores nothing
   const int KG = K / GK;
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
     for (int i = 0; i < 4; ++i) z[threadIdx.x + 512 * i] = make_uint4(0, 0, 0, 0);
   }
   // stand-in weight source: tile 0 of the workgroup's first row block, every 1 KiB load at the same bytes (offsets cancelled)
-  const long wstand_off = ((long)min((int)blockIdx.x * 8, tiles - 1) - tile) * (K / KSTEP) * (TPS * 1024) - (long)g_lo * (TL * 1024);  // (relative to wsrc)
+  const long wstand_off = ((long)min(bx * 8, tiles - 1) - tile) * (K / KSTEP) * (TPS * 1024) - (long)g_lo * (TL * 1024);  // (relative to wsrc)
   __syncthreads();  // (the zero buffer is written; nothing else touches LDS before the first DMA lands)
   // ---- prologue: groups 0 and 1 in the steady-state order [D(0), W(0, *), D(1), W(1, *)]
   C8_DMA(0, 0)

@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvispec_hip.so")
+if os.environ.get("VISPEC_LIB_VARIANT"):  # same-box A/Bs of compile-time switches (tools/): another in-tree build of the SAME sources, e.g. libvispec_hip_noswz.so
+    LIB_PATH = os.path.join(_HERE, f"libvispec_hip_{os.environ['VISPEC_LIB_VARIANT']}.so")
 
 c_void_p, c_int, c_float = C.c_void_p, C.c_int, C.c_float
 
