@@ -202,6 +202,9 @@ def make_request(tcfg, req_id, device):
     n, seed = kw["pixel_values"]
     from vispec_amd.model.target import SyntheticVision
     kw["pixel_values"] = SyntheticVision(tcfg.hidden_size).features(int(n), int(seed), device, torch.bfloat16)
+    if FRONT_END is not None:  # the front-end runs inside specgenerate: the request carries its pixels as well
+        pixels, sizes = FRONT_END.pixels(req_id)
+        kw["pixel_values"] = VisionInput(pixels, kw["pixel_values"], sizes)
     return ids, kw
 
 
@@ -352,13 +355,11 @@ def cpu_config0_leg(sm, tcfg, host, rounds=6, ar_steps=2, budget_s=8.0):
                 ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar_decode=round(new_tok / t_dec * t_ar, 3), cores=cores)
 
 
-def vision_tower_leg(tcfg, device, n_img, iters=5):
-    """The reference harness brackets the WHOLE specgenerate call, vision tower included (gen_spec_answer_coco_caption.py:221-232), for the
-    speculative and the AR run alike.  The timed region above starts from the projected image features (no vision checkpoint exists on
-    the box), so this leg times the front-end the request would have gone through — HF's own modules at the published architecture
-    (LLaVA-1.6: CLIP ViT-L/14-336, 5 anyres tiles of a 640x427 image -> 2144 tokens (672x672 -> 2928), 2-layer projector, unpad + image_newline
-    packing; Qwen2.5-VL: its 32-layer window-attention tower + patch merger), random-initialised in bf16, on PyTorch-ROCm as the north star
-    prescribes — and `speedpy_comparable.with_vision_tower` adds that time to both walls.  -> (seconds per image set, description)"""
+def build_front_end(tcfg, device, n_img):
+    """The vision front-end a request of this model goes through in the reference (spec_model_ours.py:339-356, 391-396) — HF's own modules at the
+    published architecture (LLaVA-1.6: CLIP ViT-L/14-336, 5 anyres tiles of a 640x427 image -> 2144 tokens (672x672 -> 2928), 2-layer projector,
+    unpad + image_newline packing; Qwen2.5-VL: its 32-layer window-attention tower + patch merger), random-initialised in bf16 (no vision checkpoint
+    exists on the box), on PyTorch-ROCm as the north star prescribes.  -> (HFVisionFrontEnd, description, pixels(req_id) -> (pixel tensor, image_sizes))"""
     from vispec_amd.model.vision import HFVisionFrontEnd
     dt = torch.bfloat16
     if MODEL.startswith("qwen"):
@@ -370,8 +371,11 @@ def vision_tower_leg(tcfg, device, n_img, iters=5):
         grids = [(1, 32, 32)] * 4 if MODEL == "qwen7b" else [(1, 68, 92)]
         fe = HFVisionFrontEnd("Qwen2_5_VLForConditionalGeneration", SimpleNamespace(vision_config=vc), Visual._from_config(vc).to(device, dt).eval(), None, None)
         n_patch = sum(t * h * w for t, h, w in grids)
-        pix = torch.randn(n_patch, vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2, device=device, dtype=dt)
-        call = lambda: fe.features(pix, image_grid_thw=torch.tensor(grids, device=device))
+        width = vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2
+
+        def pixels(req_id):
+            g = torch.Generator(device="cpu").manual_seed(5000 + int(req_id))
+            return torch.randn(n_patch, width, generator=g).to(device, dt), None
         what = f"Qwen2.5-VL vision tower ({vc.depth} layers, hidden {vc.hidden_size}), grids {grids}"
     else:
         from transformers import AutoModel, LlavaNextConfig
@@ -383,11 +387,84 @@ def vision_tower_leg(tcfg, device, n_img, iters=5):
             raise ValueError(f"no anyres image size known for {n_img} image tokens")
         fe = HFVisionFrontEnd("LlavaNextForConditionalGeneration", c, AutoModel.from_config(c.vision_config).to(device, dt).eval(),
                               LlavaNextMultiModalProjector(c).to(device, dt).eval(), torch.zeros(tcfg.hidden_size, device=device, dtype=dt))
-        pix = torch.randn(1, 5, 3, c.vision_config.image_size, c.vision_config.image_size, device=device, dtype=dt)
         sizes = torch.tensor([list(size)])
-        call = lambda: fe.features(pix, image_sizes=sizes)
         vc = c.vision_config
+
+        def pixels(req_id):
+            g = torch.Generator(device="cpu").manual_seed(5000 + int(req_id))
+            return torch.randn(1, 5, 3, vc.image_size, vc.image_size, generator=g).to(device, dt), sizes
         what = f"CLIP ViT-L/{vc.patch_size}-{vc.image_size} ({vc.num_hidden_layers} layers) on 5 anyres tiles of a {size[1]}x{size[0]} image + projector + unpad/newline packing"
+    return fe, what + " (random-initialised HF modules, bf16, PyTorch-ROCm)", pixels
+
+
+class VisionInput:
+    """What a bench request carries as `pixel_values` when the front end runs inside the timed region: the image's pixels (input of the tower)
+    and the request's SURVEY §8(d) synthetic features (what the target and the draft see, whatever tower weights are on the box)."""
+    __slots__ = ("pixels", "features", "image_sizes", "ready")
+
+    def __init__(self, pixels, features, image_sizes):
+        self.pixels, self.features, self.image_sizes = pixels, features, image_sizes
+        self.ready = None  # (features, event) once InLoopFrontEnd.prefetch has run the front-end ahead of the request's start
+
+
+class InLoopFrontEnd:
+    """`base_model.vision` of the bench's models (TargetLM.get_image_features routes every request through `.features`): the HF front-end's
+    whole arithmetic runs on the request's pixels INSIDE specgenerate — the reference's wall clock brackets it, gen_spec_answer_coco_caption.py:
+    221-232 — and the embeddings handed on are the request's synthetic features + 0 x the tower's output (a random-initialised tower's features
+    would not be the workload SURVEY §8(d) defines; the dependency keeps its launches on the request's critical path)."""
+    tower = True
+
+    def __init__(self, fe, what, pixels):
+        import threading
+        self.fe, self.what, self.pixels = fe, what, pixels
+        self._tls = threading.local()  # one side stream per lane thread
+
+    @torch.no_grad()
+    def _run(self, pv, image_grid_thw):
+        out = self.fe.features(pv.pixels, image_sizes=pv.image_sizes, image_grid_thw=image_grid_thw)
+        if tuple(out.shape) != tuple(pv.features.shape):
+            raise ValueError(f"vision front-end produced {tuple(out.shape)}, the request's features are {tuple(pv.features.shape)}")
+        return pv.features + out.mul(0).nan_to_num()
+
+    def features(self, pv, image_sizes=None, image_grid_thw=None, **kw):
+        if pv.ready is not None:  # computed ahead on the lane's side stream (prefetch): order this stream behind it
+            out, ev = pv.ready
+            pv.ready = None
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            out.record_stream(cur)
+            return out
+        return self._run(pv, image_grid_thw)
+
+    def prefetch(self, request):
+        """The front-end of the lane's NEXT request on the lane's side stream, while its slots decode (specgenerate_stream calls this when a
+        request starts): same launches, same wall clock — off the critical path of the lane's lockstep rounds."""
+        ids, kw = request
+        pv = kw.get("pixel_values")
+        if not isinstance(pv, VisionInput) or pv.ready is not None or os.environ.get("VISPEC_BENCH_VISION_PREFETCH", "1") == "0":
+            return
+        side = getattr(self._tls, "stream", None)
+        if side is None:
+            side = self._tls.stream = torch.cuda.Stream(pv.features.device)
+        with torch.cuda.stream(side):
+            out = self._run(pv, kw.get("image_grid_thw"))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pv.ready = (out, ev)
+
+
+FRONT_END = None  # main(): the InLoopFrontEnd when HF's modules can be built (then every timed specgenerate call includes it)
+
+
+def vision_tower_leg(tcfg, device, n_img, iters=5):
+    """Seconds per image set of the front-end ALONE on the GPU (information: with FRONT_END it is already inside every wall clock of the line;
+    without, `speedpy_comparable.with_vision_tower` adds it to both walls).  -> (seconds, description)"""
+    fe, what, pixels = (FRONT_END.fe, FRONT_END.what, FRONT_END.pixels) if FRONT_END is not None else build_front_end(tcfg, device, n_img)
+    pix, sizes = pixels(0)
+    grids = None
+    if MODEL.startswith("qwen"):
+        grids = torch.tensor([(1, 32, 32)] * 4 if MODEL == "qwen7b" else [(1, 68, 92)], device=device)
+    call = lambda: fe.features(pix, image_sizes=sizes, image_grid_thw=grids)
     for _ in range(2):
         f = call()
     if f.shape[0] != n_img:
@@ -536,6 +613,9 @@ def main():
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, "
                          "84 (eight for bf16 weights and W8A8, four for W8A16) with several")
+    ap.add_argument("--no-vision-in-loop", action="store_true",
+                    help="start every request from its projected image features (rounds 1-4) instead of running the HF vision front-end inside the timed "
+                         "specgenerate call")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -591,6 +671,19 @@ def main():
     CO = args.cohort
     sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R, CO)
     pairs = sms if CO >= 2 else None
+    global FRONT_END
+    vision_note = "not in the timed region (--no-vision-in-loop): the requests start from projected image features resident in HBM"
+    if not args.no_vision_in_loop:
+        try:  # the vision front-end inside every timed specgenerate call, like the reference harness's wall clock (gen_spec_answer_coco_caption.py:221-232)
+            n_img_model = {"qwen7b": 1024, "qwen7b-hires": 1564, "qwen7b-fp8": 1564, "qwen7b-fp8a8": 1564}.get(MODEL, N_IMG)
+            FRONT_END = InLoopFrontEnd(*build_front_end(tcfg, device, n_img_model))
+            for grp in (sms if CO >= 2 else [[m] for m in sms]):
+                for m in grp:
+                    m.base_model.vision = FRONT_END
+            vision_note = "IN the timed region, once per request: " + FRONT_END.what + "; its output enters as 0 x (the embeddings are the request's synthetic features)"
+        except Exception as e:
+            FRONT_END = None
+            vision_note = f"not in the timed region (HF vision modules could not be built: {type(e).__name__}: {e})"[:300]
     sms = [p[0] for p in sms] if CO >= 2 else sms  # the leaders double as the single-request models of the annotation legs
     sm = sms[0]
     eng = sm.engine
@@ -627,7 +720,7 @@ def main():
                     mine = [i for s_ in range(lo, hi) for i in plan[lane][s_]]
                     st_s = {}
                     outs = specgenerate_stream(pairs[lane], [get_req(i) for i in mine], max_new_tokens=MAX_NEW, temperature=args.temperature,
-                                               seeds=mine, stats=st_s)
+                                               seeds=mine, stats=st_s, prefetch=None if FRONT_END is None else FRONT_END.prefetch)
                     for o, new_token, idx, acc in outs:
                         tok += int(new_token)
                         rnd += idx + 1
@@ -882,9 +975,13 @@ def main():
                            published_speedup=None, ar_roofline_frac_of_8TBps=round(b_ar * (n_ar / t_ar) / 8e12, 4))
                 try:  # the reference's wall clock also holds the vision tower, in both runs (see vision_tower_leg)
                     t_vis, vis_what = vision_tower_leg(tcfg, device, n_img)
-                    spc["with_vision_tower"] = dict(vision_s=round(t_vis, 4), front_end=vis_what + " (random-initialised HF modules, bf16, PyTorch-ROCm)",
-                                                    tokens_per_s=round(int(new_token) / (t_req + t_vis), 2), ar_tokens_per_s=round(n_ar / (t_ar + t_vis), 2),
-                                                    speedup_vs_ar=round((int(new_token) / (t_req + t_vis)) / (n_ar / (t_ar + t_vis)), 3))
+                    if FRONT_END is not None:  # already inside t_req and t_ar (and inside every request of the timed region)
+                        spc["with_vision_tower"] = dict(vision_s=round(t_vis, 4), front_end=vis_what, in_the_walls_above=True,
+                                                        tokens_per_s=spc["tokens_per_s"], ar_tokens_per_s=spc["ar_tokens_per_s"], speedup_vs_ar=spc["speedup_vs_ar"])
+                    else:
+                        spc["with_vision_tower"] = dict(vision_s=round(t_vis, 4), front_end=vis_what, in_the_walls_above=False,
+                                                        tokens_per_s=round(int(new_token) / (t_req + t_vis), 2), ar_tokens_per_s=round(n_ar / (t_ar + t_vis), 2),
+                                                        speedup_vs_ar=round((int(new_token) / (t_req + t_vis)) / (n_ar / (t_ar + t_vis)), 3))
                 except Exception as e:
                     spc["with_vision_tower"] = f"not measured: {type(e).__name__}: {e}"[:200]
                 # greedy invariance at full size: speculative tokens == AR tokens of the same target
@@ -953,7 +1050,7 @@ def main():
                                    f"synthetic: N(0,0.02) layers + successor-structured embed/lm_head (rho={RHO[MODEL]}: measured tau vs the "
                                    f"reference's published {TAU_PUBLISHED[MODEL]} for this model, README T=0 average)"),
                        "parallelism": f"dp{world} x {R} lanes/GPU x cohort {CO} (independent requests, one-time RCCL weight replication {t_rep:.2f}s)",
-                       "prefill_gemms": prefill_gemm_mode()},
+                       "prefill_gemms": prefill_gemm_mode(), "vision_front_end": vision_note},
             # what one rank costs the HOST during the timed region (max over ranks): R lane threads issuing one hipGraph launch per phase and one
             # event wait per round.  host_cpu_per_wall = busy host cores per rank; x 8 ranks must stay well below the node's cores.
             "host": {"cpu_s_per_wall_s": round(float(host_mx[0]), 3), "rank0_cpu_s": round(host_cpu_s, 2), "rank0_wall_s": round(rank_wall_s, 3),
