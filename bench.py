@@ -400,11 +400,10 @@ def build_front_end(tcfg, device, n_img):
 class VisionInput:
     """What a bench request carries as `pixel_values` when the front end runs inside the timed region: the image's pixels (input of the tower)
     and the request's SURVEY §8(d) synthetic features (what the target and the draft see, whatever tower weights are on the box)."""
-    __slots__ = ("pixels", "features", "image_sizes", "ready")
+    __slots__ = ("pixels", "features", "image_sizes")
 
     def __init__(self, pixels, features, image_sizes):
         self.pixels, self.features, self.image_sizes = pixels, features, image_sizes
-        self.ready = None  # (features, event) once InLoopFrontEnd.prefetch has run the front-end ahead of the request's start
 
 
 class InLoopFrontEnd:
@@ -415,9 +414,7 @@ class InLoopFrontEnd:
     tower = True
 
     def __init__(self, fe, what, pixels):
-        import threading
         self.fe, self.what, self.pixels = fe, what, pixels
-        self._tls = threading.local()  # one side stream per lane thread
 
     @torch.no_grad()
     def _run(self, pv, image_grid_thw):
@@ -427,30 +424,7 @@ class InLoopFrontEnd:
         return pv.features + out.mul(0).nan_to_num()
 
     def features(self, pv, image_sizes=None, image_grid_thw=None, **kw):
-        if pv.ready is not None:  # computed ahead on the lane's side stream (prefetch): order this stream behind it
-            out, ev = pv.ready
-            pv.ready = None
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            out.record_stream(cur)
-            return out
         return self._run(pv, image_grid_thw)
-
-    def prefetch(self, request):
-        """The front-end of the lane's NEXT request on the lane's side stream, while its slots decode (specgenerate_stream calls this when a
-        request starts): same launches, same wall clock — off the critical path of the lane's lockstep rounds."""
-        ids, kw = request
-        pv = kw.get("pixel_values")
-        if not isinstance(pv, VisionInput) or pv.ready is not None or os.environ.get("VISPEC_BENCH_VISION_PREFETCH", "1") == "0":
-            return
-        side = getattr(self._tls, "stream", None)
-        if side is None:
-            side = self._tls.stream = torch.cuda.Stream(pv.features.device)
-        with torch.cuda.stream(side):
-            out = self._run(pv, kw.get("image_grid_thw"))
-            ev = torch.cuda.Event()
-            ev.record(side)
-        pv.ready = (out, ev)
 
 
 FRONT_END = None  # main(): the InLoopFrontEnd when HF's modules can be built (then every timed specgenerate call includes it)
@@ -720,7 +694,7 @@ def main():
                     mine = [i for s_ in range(lo, hi) for i in plan[lane][s_]]
                     st_s = {}
                     outs = specgenerate_stream(pairs[lane], [get_req(i) for i in mine], max_new_tokens=MAX_NEW, temperature=args.temperature,
-                                               seeds=mine, stats=st_s, prefetch=None if FRONT_END is None else FRONT_END.prefetch)
+                                               seeds=mine, stats=st_s)
                     for o, new_token, idx, acc in outs:
                         tok += int(new_token)
                         rnd += idx + 1

@@ -283,6 +283,19 @@ __global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16_t* __re
 #ifndef VISPEC_MT2_MINWAVES
 #define VISPEC_MT2_MINWAVES 3
 #endif
+// W8A16 two-tile instantiations (fp8 cohorts of two, 33..64-node trees, and since round 5 the two-tile slab of the draft's fp8 lm_head in a cohort
+// of 5..8): the up-conversion temporaries do not fit the register budget of the bf16 forms.  NT = 1: 16..28 B of scratch at 3 waves per SIMD ->
+// 2 waves per SIMD, no scratch.  NT = 2 (the paired form): 80..92 B of scratch at 2 waves per SIMD; at ONE wave per SIMD it has none (222 VGPRs +
+// 80 AGPRs) but the large grids lose their latency hiding — same box, Qwen2.5-VL-7B W8A16, 4 lanes x cohort 8 (the draft's 545 MB lm_head runs
+// this kernel four times a round): 2429 tok/s with the scratch, 2281 without; cohorts of two 1264 / 1291 (profiles/r05_w8_two_tile_bounds_ab.txt).
+// The scratch stays for NT = 2 (-DVISPEC_W8_MT2NT2_MINWAVES=1 builds the other form); converting one weight tile at a time instead of both moved
+// it from 92 to 84 B: the pressure is the double-buffered staging registers, not the conversion.
+#ifndef VISPEC_W8_MT2_MINWAVES
+#define VISPEC_W8_MT2_MINWAVES 2
+#endif
+#ifndef VISPEC_W8_MT2NT2_MINWAVES
+#define VISPEC_W8_MT2NT2_MINWAVES 2
+#endif
 #ifndef VISPEC_MT2NT2_LDSBUF
 #define VISPEC_MT2NT2_LDSBUF 1
 #endif
@@ -303,7 +316,7 @@ constexpr int gemm_w32_lds_bytes() {
 // costs — one 32-row activation block per workgroup instead of the 128 rows of the wide form — and a row is the same dot products in the
 // same order as in the single-request launch (split-K partials are indexed by the tile row m).
 template <int NT, int EPI, int UNROLL, int NW, int DBG = 0, int W8 = 0 /* 0 bf16 weights, 1 e4m3 weights x bf16 activations, 2 e4m3 x e4m3 */, int MT = 1, bool SLAB = false>  // DBG (tools/gemm_bench.py only): 1 = no activation loads, 2 = no epilogue, 3 = only tile 0's activations loaded (wrong results: traffic upper bound)
-__global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? VISPEC_MT2_MINWAVES : 2) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
+__global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? (W8 == 1 ? VISPEC_W8_MT2_MINWAVES : VISPEC_MT2_MINWAVES) : (W8 == 1 ? VISPEC_W8_MT2NT2_MINWAVES : 2)) : 1)) void gemm_w32_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ P,
                                                            int tile2_off, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
                                                            int ldy, const bf16_t* __restrict__ R, int ldr, int M, int N, int K,
                                                            int S, const float* __restrict__ wscale, RopeEpi re, int m_tile,

@@ -530,7 +530,7 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
 
 
 def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_tokens=512, max_length=2048, is_llama3=False, seeds=None,
-                        stats=None, prefetch=None):
+                        stats=None):
     """Any number of independent requests through the request SLOTS of one cohort (continuous batching): `models` = [leader, member, ...]
     as for specgenerate_cohort, `requests` = [(input_ids [1,L], specgenerate kwargs), ...] in arrival order.  The first len(models)
     requests start together; every lockstep round serves all slots on one weight pass, and the moment a request finishes (EOS, its
@@ -539,9 +539,7 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
     request by request (specgenerate_cohort) executes max(rounds of its requests) lockstep rounds; the stream executes ≈ mean(rounds).
     Every request keeps the reference's batch-1 semantics: it returns exactly the (input_ids, new_token, idx, acceptance_len) tuple of
     `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` run alone (spec_model_ours.py:247-582), in request order.
-    `stats` (dict, optional): `rounds` = lockstep rounds executed, `request_rounds` = rounds summed over the requests.
-    `prefetch` (callable, optional): called with the NEXT request of the queue each time a request starts — a serving front end uses it to run
-    that request's vision tower on a side stream while the slots decode (bench.py: InLoopFrontEnd.prefetch)."""
+    `stats` (dict, optional): `rounds` = lockstep rounds executed, `request_rounds` = rounds summed over the requests."""
     n, R = len(models), len(requests)
     seeds = list(seeds) if seeds is not None else [0] * R
     budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * R
@@ -587,8 +585,6 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
         models[t]._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=seeds[i], max_new_tokens=budgets[i],
                                  is_llama3=is_llama3)
         slot[t], rnd[t], accs[t] = i, 0, []
-        if prefetch is not None and nxt < R:
-            prefetch(requests[nxt])
 
     def finish(t, st):
         m, n_ctx = models[t], st["n_ctx"]
