@@ -954,7 +954,8 @@ struct AttnReq {
   const unsigned long long* mask;
   float* part_o;
   float* part_ml;
-  bf16_t* out;  // (reduce kernel)
+  bf16_t* out;  // (reduce kernel / the fused merge)
+  int* cnt;     // arrival counters [H_kv * NQT] of the fused merge (zero between launches), or nullptr: separate reduce launch
 };
 struct AttnArgs { AttnReq r[MAX_COHORT]; };  // up to eight requests of a cohort per launch
 // (assignments under uniform branches: the nested ?: form of this selection was compiled as a dynamically indexed kernel argument —
@@ -970,12 +971,14 @@ __device__ __forceinline__ AttnReq attn_req(const AttnArgs& a, int rq) {
   else if (rq == 7) r = a.r[7];
   return r;
 }
+__device__ __forceinline__ void tree_attn_reduce_body(const AttnReq& R, float* __restrict__ sh, int head, int mt, int dpart, int H, int H_kv, int M,
+                                                      int tail, int keys_per_wg, int nsplit, int ldo);  // (below, next to its stand-alone kernel)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int att_vswz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 3) << 6)); }
 
 template <bool EAGER>
 __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs args, int ldq, int s_max, int H, int H_kv, int M, int tail,
-                                                                    int keys_per_wg, int nsplit, int NQT) {
+                                                                    int keys_per_wg, int nsplit, int NQT, int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + ATT2_CHUNK * 256;
@@ -1158,15 +1161,57 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
   const size_t pidx = ((size_t)(kvh * NQT + qt) * nsplit + split);
   float4* po = reinterpret_cast<float4*>(R.part_o + pidx * (128 * 32));
   const float4* s4 = reinterpret_cast<const float4*>(sO);
+  const bool fused = R.cnt != nullptr;  // fused merge: the partial is published with write-through (sc1) stores — see below
 #pragma unroll
   for (int e = threadIdx.x; e < 1024; e += 256) {
     const float4 a = s4[e], b = s4[1024 + e], c = s4[2048 + e], d = s4[3072 + e];
-    po[e] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    const float4 v = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    if (fused) {
+      const f32x4 vv = {v.x, v.y, v.z, v.w};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(po + e), "v"(vv) : "memory");
+    } else {
+      po[e] = v;
+    }
   }
   if (threadIdx.x < 32) {
     const int q = threadIdx.x;
-    R.part_ml[pidx * 64 + q] = fmaxf(fmaxf(sM[q], sM[32 + q]), fmaxf(sM[64 + q], sM[96 + q]));
-    R.part_ml[pidx * 64 + 32 + q] = (sM[128 + q] + sM[160 + q]) + (sM[192 + q] + sM[224 + q]);
+    const float pm = fmaxf(fmaxf(sM[q], sM[32 + q]), fmaxf(sM[64 + q], sM[96 + q]));
+    const float pl = (sM[128 + q] + sM[160 + q]) + (sM[192 + q] + sM[224 + q]);
+    if (fused) {
+      __hip_atomic_store(&R.part_ml[pidx * 64 + q], pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (4-byte agent-scope stores are sc1 stores)
+      __hip_atomic_store(&R.part_ml[pidx * 64 + 32 + q], pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      R.part_ml[pidx * 64 + q] = pm;
+      R.part_ml[pidx * 64 + 32 + q] = pl;
+    }
+  }
+  // ---- fused merge (round 5; OFF by default — measured slower, see launch_attention_n): the LAST workgroup to arrive for this (request, kv head, q-tile) merges the key splits itself — the arithmetic
+  // of tree_attn_reduce_kernel, element for element — instead of a separate launch (4.6 us alone, 15-25 us when it queues behind other lanes'
+  // GEMMs: profiles/r05_kernel_stats_4lanes_cohort8_first.csv).  Publish / acquire as MI355X_MICROARCH.md §inter-workgroup visibility
+  // prescribes for tens of KB per workgroup: write-through (sc1) stores -> every wave drains vmcnt -> barrier -> relaxed agent ticket; the
+  // last arriver: agent acquire -> barrier -> plain loads.  (First form: plain stores + a lane-0 agent RELEASE fence per workgroup — the L2
+  // write-back of 16 KB of fresh partial per workgroup, 1 792 times a launch: 3252 -> 2556 tok/s, profiles/r05_ab_attention_fused_merge.txt.)
+  // The ticket counter returns to zero with the last arriver (graph replays start from zero).
+  if (!fused) return;
+  const int ns_act = max(1, min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg));  // workgroups that did not take the early exit above
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(&R.cnt[kvh * NQT + qt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == ns_act - 1;
+    if (last) {
+      __hip_atomic_store(&R.cnt[kvh * NQT + qt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float* sh = reinterpret_cast<float*>(smem);  // (the K / V image and the wave-merge scratch are dead)
+  for (int dpart = 0; dpart < 4; ++dpart) {
+    tree_attn_reduce_body(R, sh, head, qt % MT, dpart, H, H_kv, M, tail, keys_per_wg, nsplit, ldo);
+    __syncthreads();
   }
 }
 
@@ -1363,24 +1408,23 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
   }
 }
 
-// merge partials over splits: grid (H*MT), 256 threads
-__global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, int H, int H_kv, int M, int tail,
-                                                               int keys_per_wg, int nsplit, int ldo) {
-  // blockIdx.z = request of a cohort (0 otherwise)
-  const AttnReq R = attn_req(args, blockIdx.z);
+// merge partials over splits — the body: (head, m-tile) of request R, d-rows [32 dpart, +32); 256 threads; `sh` = 10.5 KB of LDS scratch
+// (wgt[64][32], smax[8][32], ssum[8][32], linv[32] floats).  One arithmetic for the stand-alone kernel and for the fused merge below.
+#define ATT_RED_LDS_FLOATS (64 * 32 + 8 * 32 + 8 * 32 + 32)
+__device__ __forceinline__ void tree_attn_reduce_body(const AttnReq& R, float* __restrict__ sh, int head, int mt, int dpart, int H, int H_kv, int M,
+                                                      int tail, int keys_per_wg, int nsplit, int ldo) {
   const float* __restrict__ part_o = R.part_o;
   const float* __restrict__ part_ml = R.part_ml;
   const int* __restrict__ prefix_dev = R.prefix_dev;
   bf16_t* __restrict__ out = R.out;
   // Latency-bound (a few hundred KB per launch): every load of a phase is issued before the first use, with clamped
   // (always valid) addresses instead of guards, so the dependent chain is prefix -> {m,l and the first 16 partial tiles} -> out.
-  __shared__ float wgt[64][32];
-  __shared__ float smax[8][32], ssum[8][32];
-  __shared__ float linv[32];
+  float(*wgt)[32] = reinterpret_cast<float(*)[32]>(sh);
+  float(*smax)[32] = reinterpret_cast<float(*)[32]>(sh + 64 * 32);
+  float(*ssum)[32] = reinterpret_cast<float(*)[32]>(sh + 64 * 32 + 8 * 32);
+  float* linv = sh + 64 * 32 + 16 * 32;
   const int G = H / H_kv, MT = (M + 31) >> 5, NQT = G * MT;
-  const int head = blockIdx.x / MT, mt = blockIdx.x % MT;
   const int kvh = head / G, qt = (head % G) * MT + mt;
-  const int dpart = blockIdx.y;  // 4 blocks per (head, m-tile): 32 d-rows each
   const int n_total = (prefix_dev ? *prefix_dev : 0) + tail;
   const int ns = max(1, min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg));
   const size_t base = (size_t)(kvh * NQT + qt) * nsplit;
@@ -1439,6 +1483,16 @@ __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, in
     const int m = mt * 32 + q4 + i;
     if (m < M) out[(size_t)m * ldo + head * 128 + d] = f2bf(o[i]);
   }
+}
+
+// merge partials over splits, stand-alone: grid (H*MT, 4, requests), 256 threads
+__global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, int H, int H_kv, int M, int tail,
+                                                               int keys_per_wg, int nsplit, int ldo) {
+  // blockIdx.z = request of a cohort (0 otherwise)
+  const AttnReq R = attn_req(args, blockIdx.z);
+  __shared__ float sh[ATT_RED_LDS_FLOATS];
+  const int MT = (M + 31) >> 5;
+  tree_attn_reduce_body(R, sh, blockIdx.x / MT, blockIdx.x % MT, blockIdx.y, H, H_kv, M, tail, keys_per_wg, nsplit, ldo);
 }
 
 // x <- bf16(x + r) (the residual add of the decoder layer, modeling_llama_kv.py:742-756) and y = RMSNorm(x) * w in ONE pass over the row:

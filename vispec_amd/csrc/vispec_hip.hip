@@ -61,6 +61,7 @@ struct vispec_ctx {
   TreeBufs tb{};
   // attention partials
   float *part_o, *part_ml;
+  int* att_cnt = nullptr;  // arrival counters of the fused attention merge (tree_attn2_partial_kernel): zero between launches
   float *lstk_stats = nullptr, *lstk_cv = nullptr;  // log-softmax/top-k scratch [64 rows][LSTK_CHUNKS]...
   int* lstk_ci = nullptr;
   unsigned long long* lstk2_cand = nullptr;  // chunked form (large vocabularies): [64 rows][<= 64 chunks][TOPK_MAX] keys; statistics in lstk_stats
@@ -230,6 +231,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
     ctx->part_cap_tiles = (size_t)heads * 2 * (nsplit > 64 ? 64 : nsplit);
     A(part_o, ctx->part_cap_tiles * 128 * 32);
     A(part_ml, ctx->part_cap_tiles * 64);
+    A(att_cnt, 512);
   }
   {
     size_t nmax = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
@@ -961,6 +963,13 @@ static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int l
   // bit-identical to the same request alone at every context length
   while ((s_max + kpw - 1) / kpw > 64) kpw *= 2;
   const int nsplit = (max_keys + kpw - 1) / kpw;
+  // Round 5 built the merge of a (request, head, q-tile)'s key splits by the LAST workgroup of the partial launch to arrive (one launch per
+  // attention call less; the stand-alone kernel's arithmetic, element for element: every test passes in both forms) — and measured it
+  // SLOWER on the same box, twice: with a release fence per workgroup 3252 -> 2556 tok/s (one request's round 4.97 -> 5.27 ms), with
+  // write-through (sc1) partial stores 3254 -> 3062 tok/s (4.98 -> 5.14 ms): publishing 16 KB per workgroup 1 792 times a launch costs more
+  // than the 5 us launch it removes (profiles/r05_ab_attention_fused_merge.txt).  Off; VISPEC_ATT_FUSED_MERGE=1 runs it.
+  static const bool fused_merge = getenv("VISPEC_ATT_FUSED_MERGE") && atoi(getenv("VISPEC_ATT_FUSED_MERGE")) != 0;
+  if (fused_merge && H_kv * NQT > 512) return fail("tree_attention: more (head, q-tile) pairs than merge counters");
   AttnArgs args{};
   for (int t = 0; t < n; ++t) {
     if ((size_t)H_kv * NQT * nsplit > calls[t].ctx->part_cap_tiles) return fail("tree_attention: partial workspace too small");
@@ -968,13 +977,15 @@ static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int l
     r.Q = (const bf16_t*)calls[t].q; r.Kc = (const bf16_t*)calls[t].kc; r.Vc = (const bf16_t*)calls[t].vc;
     r.prefix_dev = calls[t].prefix_dev; r.mask = calls[t].mask; r.part_o = calls[t].ctx->part_o; r.part_ml = calls[t].ctx->part_ml;
     r.out = (bf16_t*)calls[t].out;
+    r.cnt = fused_merge ? calls[t].ctx->att_cnt : nullptr;
   }
   dim3 grid(nsplit, H_kv, NQT * n), block(256);
   prof_begin(s, eager ? PROF_ATT_PARTIAL : PROF_ATT_PARTIAL_DRAFT, 0.0);
-  if (eager) PLAUNCH(tree_attn2_partial_kernel<true>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT);
-  else PLAUNCH(tree_attn2_partial_kernel<false>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT);
+  if (eager) PLAUNCH(tree_attn2_partial_kernel<true>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT, ldo);
+  else PLAUNCH(tree_attn2_partial_kernel<false>, grid, block, ATT2_LDS_BYTES, s, args, ldq, s_max, H, H_kv, M, tail, kpw, nsplit, NQT, ldo);
   KCHK();
   prof_end(s);
+  if (fused_merge) return 0;
   prof_begin(s, eager ? PROF_ATT_REDUCE : PROF_ATT_REDUCE_DRAFT, 0.0);
   PLAUNCH(tree_attn_reduce_kernel, dim3(H * MT, 4, n), dim3(256), 0, s, args, H, H_kv, M, tail, kpw, nsplit, ldo);
   KCHK();
