@@ -976,6 +976,20 @@ __device__ __forceinline__ void tree_attn_reduce_body(const AttnReq& R, float* _
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int att_vswz(int row, int colbyte) { return row * 256 + (colbyte ^ ((row & 3) << 6)); }
 
+// K / V rows are read once per launch by one workgroup: loaded non-temporal (like the weight streams) they do not displace what IS re-read
+// (activations, split-K and attention partials) from the L2 / Infinity Cache.  Same box, 4 lanes x cohort 8: 3340 / 3344 -> 3405 / 3413 tok/s
+// (+2.0 %), one request's round 4.98 -> 4.90 ms (profiles/r05_ab_attention_kv_nontemporal.txt; -DVISPEC_ATT_KV_NT=0 = plain loads)
+#ifndef VISPEC_ATT_KV_NT
+#define VISPEC_ATT_KV_NT 1
+#endif
+__device__ __forceinline__ uint4 att_ld_kv(const uint4* p) {
+#if VISPEC_ATT_KV_NT
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 template <bool EAGER>
 __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs args, int ldq, int s_max, int H, int H_kv, int M, int tail,
                                                                     int keys_per_wg, int nsplit, int NQT, int ldo) {
@@ -1021,8 +1035,8 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
 #define ATT2_G1(kk, vv, p, ch)                                                              \
   {                                                                                         \
     const int key_ = min(key0 + (ch) * ATT2_CHUNK + srow + 16 * (p), last_key);             \
-    kk = *reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8);               \
-    vv = *reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8);               \
+    kk = att_ld_kv(reinterpret_cast<const uint4*>(Kh + (size_t)key_ * 128 + sc16 * 8));     \
+    vv = att_ld_kv(reinterpret_cast<const uint4*>(Vh + (size_t)key_ * 128 + sc16 * 8));     \
   }
 #define ATT2_GLOAD(ch)                                                                      \
   ATT2_G1(k0r, v0r, 0, ch) ATT2_G1(k1r, v1r, 1, ch) ATT2_G1(k2r, v2r, 2, ch) ATT2_G1(k3r, v3r, 3, ch) \
