@@ -879,6 +879,10 @@ def main():
                                                    "the activation traffic) — alone it fills about a third of the CUs, each at the CU's ingest cap; `deployed` "
                                                    "times the same kernel the way the timed region runs it" if wide8 else ""))
                 extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
+                # one launch serves CO requests with ONE pass over the weight: `achieved` counts those bytes once (the roofline the kernel is held to);
+                # what the CO requests would have streamed one by one is CO times that — the figure to compare across cohort sizes
+                extra["roofline"]["requests_per_launch"] = CO
+                extra["roofline"]["weight_bytes_delivered_to_requests_GBps"] = round(CO * extra["roofline"]["achieved"], 1)
                 extra["roofline"]["wide_row_blocks"] = rb_timed
                 if CO >= 3 and R >= 2:
                     try:

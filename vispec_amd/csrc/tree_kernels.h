@@ -487,6 +487,7 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
   __shared__ int s_eq[TREE_MAX_T];
   __shared__ int accept_cand[TREE_RET_W];
   __shared__ int removed[TREE_MAX_T];
+  __shared__ int s_seen[TREE_MAX_T];
   __shared__ int sh[8];  // 0 accept_length, 1 best, 2 adjust, 3 nrem, 4 fi, 5 accepted-this-level
   __shared__ float s_f[16];
   __shared__ double s_d[1025 + 17];
@@ -538,7 +539,7 @@ __device__ __forceinline__ void verify_accept_sample_body(TreeBufs tb, DevState*
     if (tid == 0) {
       float rm = 0.f;
       int nrem = 0, nseen = 0;
-      int seen[TREE_MAX_T];
+      int* seen = s_seen;  // (thread 0 only; a dynamically indexed local array is 256 B of scratch per lane for all 1024 threads)
       for (int j = 0; j < nl; ++j) {
         if (!s_eq[j]) continue;
         const int x = cand[j][i];
