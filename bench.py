@@ -35,6 +35,9 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from vispec_amd.evaluation.bench_launch import host_usage, pin_to_gpu_numa_node, request_plan, run_lanes, self_launch  # noqa: E402,F401
+from vispec_amd.evaluation.bench_vision import InLoopFrontEnd, VisionInput, build_front_end  # noqa: E402,F401
+
 N_PRE, N_IMG, N_POST = 48, 2144, 512
 MAX_NEW = 512
 # Acceptance is measured on a synthetic successor pair whose draft disagrees with the target on a fraction rho of the vocabulary.
@@ -154,44 +157,6 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         lead.engine.set_wide_row_blocks(WIDE_RB if WIDE_RB >= 0 else (0 if lanes == 1 else 84))
         sms.append([lead] + [lead.make_cohort_member() for _ in range(cohort - 1)] if cohort >= 2 else lead)
     return sms, tcfg, t_rep
-
-
-def request_plan(n_requests, rank, world, lanes, cohort, n_steps):
-    """plan[lane][step] = ids of the requests that lane of this rank runs in that step (a lane takes them `cohort` at a time on one
-    weight pass).  n_requests > 0: BASELINE config 4's fixed batch, request i -> replica i mod world (parallel.shard_requests), then
-    lane by lane ("strong" scaling: the batch is fixed); 0: every (rank, lane) runs `cohort` requests of its own per step ("weak")."""
-    from vispec_amd import parallel
-    if n_requests > 0:
-        mine = parallel.shard_requests(n_requests, rank, world)
-        # fill cohorts before opening lanes: 8 requests on a rank are 2 lanes x cohorts of 4 (one weight pass per four requests), not
-        # 4 lanes x pairs; the lanes that stay without requests do nothing
-        used = max(1, min(lanes, -(-len(mine) // max(1, cohort))))
-        return [[[i + s * n_requests for i in (mine[lane::used] if lane < used else [])] for s in range(n_steps)] for lane in range(lanes)], "strong"
-    return [[[((rank * lanes + lane) + s * world * lanes) * cohort + j for j in range(cohort)] for s in range(n_steps)]
-            for lane in range(lanes)], "weak"
-
-
-def run_lanes(fns):
-    """Run one callable per lane concurrently (one host thread + one HIP stream per lane); returns their results."""
-    import threading
-    out = [None] * len(fns)
-    err = []
-
-    def work(i):
-        try:
-            out[i] = fns[i]()
-        except BaseException as e:  # surface worker failures in the main thread
-            err.append(e)
-
-    if len(fns) == 1:
-        work(0)
-    else:
-        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-    if err:
-        raise err[0]
-    return out
 
 
 def make_request(tcfg, req_id, device):
@@ -355,85 +320,13 @@ def cpu_config0_leg(sm, tcfg, host, rounds=6, ar_steps=2, budget_s=8.0):
                 ar_tokens_per_s=round(1.0 / t_ar, 3), speedup_vs_ar_decode=round(new_tok / t_dec * t_ar, 3), cores=cores)
 
 
-def build_front_end(tcfg, device, n_img):
-    """The vision front-end a request of this model goes through in the reference (spec_model_ours.py:339-356, 391-396) — HF's own modules at the
-    published architecture (LLaVA-1.6: CLIP ViT-L/14-336, 5 anyres tiles of a 640x427 image -> 2144 tokens (672x672 -> 2928), 2-layer projector,
-    unpad + image_newline packing; Qwen2.5-VL: its 32-layer window-attention tower + patch merger), random-initialised in bf16 (no vision checkpoint
-    exists on the box), on PyTorch-ROCm as the north star prescribes.  -> (HFVisionFrontEnd, description, pixels(req_id) -> (pixel tensor, image_sizes))"""
-    from vispec_amd.model.vision import HFVisionFrontEnd
-    dt = torch.bfloat16
-    if MODEL.startswith("qwen"):
-        from transformers import Qwen2_5_VLConfig
-        from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel as Visual
-        vc = Qwen2_5_VLConfig().vision_config
-        # the published 7B checkpoint's vision_config (HF's class defaults are not it): 32 blocks of width 1280 / MLP 3420, merger to 3584
-        vc.hidden_size, vc.intermediate_size, vc.num_heads, vc.depth, vc.out_hidden_size = 1280, 3420, 16, 32, tcfg.hidden_size
-        grids = [(1, 32, 32)] * 4 if MODEL == "qwen7b" else [(1, 68, 92)]
-        fe = HFVisionFrontEnd("Qwen2_5_VLForConditionalGeneration", SimpleNamespace(vision_config=vc), Visual._from_config(vc).to(device, dt).eval(), None, None)
-        n_patch = sum(t * h * w for t, h, w in grids)
-        width = vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2
-
-        def pixels(req_id):
-            g = torch.Generator(device="cpu").manual_seed(5000 + int(req_id))
-            return torch.randn(n_patch, width, generator=g).to(device, dt), None
-        what = f"Qwen2.5-VL vision tower ({vc.depth} layers, hidden {vc.hidden_size}), grids {grids}"
-    else:
-        from transformers import AutoModel, LlavaNextConfig
-        from transformers.models.llava_next.modeling_llava_next import LlavaNextMultiModalProjector
-        c = LlavaNextConfig()
-        c.text_config.hidden_size = tcfg.hidden_size
-        size = {2144: (427, 640), 2928: (672, 672), 2340: (480, 640)}.get(n_img)
-        if size is None:
-            raise ValueError(f"no anyres image size known for {n_img} image tokens")
-        fe = HFVisionFrontEnd("LlavaNextForConditionalGeneration", c, AutoModel.from_config(c.vision_config).to(device, dt).eval(),
-                              LlavaNextMultiModalProjector(c).to(device, dt).eval(), torch.zeros(tcfg.hidden_size, device=device, dtype=dt))
-        sizes = torch.tensor([list(size)])
-        vc = c.vision_config
-
-        def pixels(req_id):
-            g = torch.Generator(device="cpu").manual_seed(5000 + int(req_id))
-            return torch.randn(1, 5, 3, vc.image_size, vc.image_size, generator=g).to(device, dt), sizes
-        what = f"CLIP ViT-L/{vc.patch_size}-{vc.image_size} ({vc.num_hidden_layers} layers) on 5 anyres tiles of a {size[1]}x{size[0]} image + projector + unpad/newline packing"
-    return fe, what + " (random-initialised HF modules, bf16, PyTorch-ROCm)", pixels
-
-
-class VisionInput:
-    """What a bench request carries as `pixel_values` when the front end runs inside the timed region: the image's pixels (input of the tower)
-    and the request's SURVEY §8(d) synthetic features (what the target and the draft see, whatever tower weights are on the box)."""
-    __slots__ = ("pixels", "features", "image_sizes")
-
-    def __init__(self, pixels, features, image_sizes):
-        self.pixels, self.features, self.image_sizes = pixels, features, image_sizes
-
-
-class InLoopFrontEnd:
-    """`base_model.vision` of the bench's models (TargetLM.get_image_features routes every request through `.features`): the HF front-end's
-    whole arithmetic runs on the request's pixels INSIDE specgenerate — the reference's wall clock brackets it, gen_spec_answer_coco_caption.py:
-    221-232 — and the embeddings handed on are the request's synthetic features + 0 x the tower's output (a random-initialised tower's features
-    would not be the workload SURVEY §8(d) defines; the dependency keeps its launches on the request's critical path)."""
-    tower = True
-
-    def __init__(self, fe, what, pixels):
-        self.fe, self.what, self.pixels = fe, what, pixels
-
-    @torch.no_grad()
-    def _run(self, pv, image_grid_thw):
-        out = self.fe.features(pv.pixels, image_sizes=pv.image_sizes, image_grid_thw=image_grid_thw)
-        if tuple(out.shape) != tuple(pv.features.shape):
-            raise ValueError(f"vision front-end produced {tuple(out.shape)}, the request's features are {tuple(pv.features.shape)}")
-        return pv.features + out.mul(0).nan_to_num()
-
-    def features(self, pv, image_sizes=None, image_grid_thw=None, **kw):
-        return self._run(pv, image_grid_thw)
-
-
 FRONT_END = None  # main(): the InLoopFrontEnd when HF's modules can be built (then every timed specgenerate call includes it)
 
 
 def vision_tower_leg(tcfg, device, n_img, iters=5):
     """Seconds per image set of the front-end ALONE on the GPU (information: with FRONT_END it is already inside every wall clock of the line;
     without, `speedpy_comparable.with_vision_tower` adds it to both walls).  -> (seconds, description)"""
-    fe, what, pixels = (FRONT_END.fe, FRONT_END.what, FRONT_END.pixels) if FRONT_END is not None else build_front_end(tcfg, device, n_img)
+    fe, what, pixels = (FRONT_END.fe, FRONT_END.what, FRONT_END.pixels) if FRONT_END is not None else build_front_end(MODEL, tcfg, device, n_img)
     pix, sizes = pixels(0)
     grids = None
     if MODEL.startswith("qwen"):
@@ -499,70 +392,11 @@ def dominant_kernel_on_all_lanes(sms, streams, tcfg, CO, fp8, device, iters=24):
                 us_per_launch_per_stream=round(1e3 * wall_ms / iters, 2), achieved=round(ach, 1), unit="GB/s", frac=round(ach / 8000.0, 4))
 
 
-def pin_to_gpu_numa_node(local):
-    """One rank per GPU, `lanes` host threads per rank (each issues hipGraph launches and waits on events): keep them on the cores of the NUMA
-    node the GPU hangs off, so that eight ranks on a two-socket node do not launch across the socket link (host-side launch
-    contention is the one scaling risk of a replicas-only design).  PCI address from the device properties -> /sys/bus/pci/devices/<addr>/numa_node
-    -> that node's cpulist -> os.sched_setaffinity (threads started later inherit it).  Anything missing (no NUMA information, a container that
-    hides /sys, VISPEC_BENCH_AFFINITY=0): no pinning, and the returned string says why.  -> description for the bench line."""
-    if os.environ.get("VISPEC_BENCH_AFFINITY", "1") == "0":
-        return "off (VISPEC_BENCH_AFFINITY=0)"
-    try:
-        pr = torch.cuda.get_device_properties(local)
-        addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-        with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
-            node = int(f.read().strip())
-        if node < 0:
-            return f"none (GPU {addr}: numa_node = -1, single-node host or no NUMA information)"
-        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
-            cpus = set()
-            for part in f.read().strip().split(","):
-                lo, _, hi = part.partition("-")
-                cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if not cpus:
-            return f"none (NUMA node {node} of GPU {addr} has no CPU this process may run on)"
-        os.sched_setaffinity(0, cpus)
-        return f"NUMA node {node} of GPU {addr}: {len(cpus)} CPUs"
-    except Exception as e:
-        return f"none ({type(e).__name__}: {e})"[:160]
-
-
-def host_usage():
-    """(process CPU seconds user + system, peak resident set size in GB) of this rank."""
-    import resource
-    t = os.times()
-    return t.user + t.system, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
-
-
 def prefill_gemm_mode():
     """Which library kernels ran the prefill GEMMs: "recorded" = the committed TunableOp table matched this PyTorch / ROCm / GPU; anything else
     names why the libraries' defaults ran (+10 % prefill time, measured in round 4)."""
     from vispec_amd.model.target import prefill_gemm_selection
     return prefill_gemm_selection()
-
-
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on 127.0.0.1) —
-    the same environment `python -m torch.distributed.run --nproc-per-node N` would set.  Rank 0's stdout carries the JSON line."""
-    import socket
-    import subprocess
-    have = torch.cuda.device_count()
-    if have < n and not os.environ.get("VISPEC_FORCE_DEVICE"):
-        log(f"error: --gpus {n} requested but {have} GPU(s) are visible; refusing to run a smaller job under that label")
-        sys.exit(2)
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", "1")  # what torch.distributed.run sets for nproc > 1: N ranks x lanes must not each spin up a 256-thread pool
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [pr.wait() for pr in procs]
-    sys.exit(max(abs(rc) for rc in rcs))
 
 
 def main():
@@ -613,7 +447,7 @@ def main():
             MODELS[k]["desc"] = f"1 image ({N_IMG} image tokens) + 512 text + 48 template tokens per request (L={N_PRE + N_IMG + N_POST})"
     REAL_WEIGHTS = resolve_weights(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args.gpus)  # does not return
+        self_launch(args.gpus, __file__)  # does not return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -650,7 +484,7 @@ def main():
     if not args.no_vision_in_loop:
         try:  # the vision front-end inside every timed specgenerate call, like the reference harness's wall clock (gen_spec_answer_coco_caption.py:221-232)
             n_img_model = {"qwen7b": 1024, "qwen7b-hires": 1564, "qwen7b-fp8": 1564, "qwen7b-fp8a8": 1564}.get(MODEL, N_IMG)
-            FRONT_END = InLoopFrontEnd(*build_front_end(tcfg, device, n_img_model))
+            FRONT_END = InLoopFrontEnd(*build_front_end(MODEL, tcfg, device, n_img_model))
             for grp in (sms if CO >= 2 else [[m] for m in sms]):
                 for m in grp:
                     m.base_model.vision = FRONT_END

@@ -297,3 +297,40 @@ def test_c8_gemm_fp8_activations_against_the_oracle(lib, eng8, N, K, n_req, m_ti
         assert_bf16_close(fn(Y[32 * t:32 * t + m_tile]), want, min_exact=0.9, ulps=1 if epi == 0 else 2, outlier_frac=1e-4,
                           scale=floor if epi != 1 else np.maximum(floor, np.maximum(np.abs(rt), np.abs(want))))
         assert (Y[32 * t + m_tile:32 * t + 32].float() == 7.0).all()
+
+
+@pytest.mark.parametrize("tree", [dict(total_token=20, depth=5, top_k=4), dict(total_token=12, depth=2, top_k=3), dict(total_token=30, depth=2, top_k=10)])
+@pytest.mark.parametrize("n_req", [6, 8])
+def test_cohorts_of_six_and_eight_with_other_tree_shapes(n_req, tree):
+    """The draft's two-tile slab GEMMs with row counts other than the default's (top_k = 4 / 3 rows per level, depth + 2 = 7 / 4 catch-up rows)
+    and a tree whose levels do not fit a slab (top_k = 10: the draft's GEMMs — lm_head included — then take the tile-per-request form, i.e.
+    the cohort-8 kernel at m_tile = 10): composition independence, == the single requests, == the oracle."""
+    import dataclasses
+    sm, ot, od = build(50, 60, True, **tree)
+    models = [sm] + [sm.make_cohort_member() for _ in range(n_req - 1)]
+    rng = np.random.default_rng(193 + n_req)
+    reqs = [(torch.from_numpy(rng.integers(3, IMG_TOK, size=n))[None], {}) for n in (17, 11, 23, 14, 9, 20, 12, 16)[:n_req]]
+    budgets = [26, 19, 33, 12, 22, 15, 28, 18][:n_req]
+    got = specgenerate_cohort(models, reqs, max_new_tokens=budgets)
+    rev = specgenerate_cohort(models, reqs[::-1], max_new_tokens=budgets[::-1])[::-1]
+    for t, (a, b) in enumerate(zip(got, rev)):
+        np.testing.assert_array_equal(a[0][0].cpu().numpy(), b[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert a[1:] == b[1:]
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    od.cfg = dataclasses.replace(od.cfg, **tree)
+    o_out, o_new, o_idx, o_acc = vo.specgenerate(ot, od, reqs[0][0][0].numpy(), max_new_tokens=budgets[0], max_pos=T["max_pos"])
+    np.testing.assert_array_equal(got[0][0][0].cpu().numpy(), o_out)
+    assert got[0][3] == o_acc
+
+
+def test_cohort_of_eight_refuses_trees_of_more_than_one_tile():
+    """A cohort member owns ONE 32-row activation tile: trees of 33..64 nodes (autotune_total_token) are refused loudly for every cohort size."""
+    sm, _, _ = build(50, 60, True)
+    members = [sm.make_cohort_member() for _ in range(7)]
+    with pytest.raises(RuntimeError, match="total_token <= 32"):
+        sm.engine.set_total_token(40)
+    with pytest.raises(RuntimeError, match="total_token <= 32"):
+        members[6].engine.set_total_token(33)
