@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-CLASSES = (("wide8", "gemm_cohort"), ("gemm_w32_wide_kernel", "gemm_cohort"), ("gemm_w32_big", "draft_prefill"), ("gemm_w32_kernel", "gemm_single/draft"),
+CLASSES = (("gemm_w32_c8", "gemm_cohort"), ("wide8", "gemm_cohort"), ("gemm_w32_wide_kernel", "gemm_cohort"), ("gemm_w32_big", "draft_prefill"), ("gemm_w32_kernel", "gemm_single/draft"),
            ("tree_attn2_partial", "attn_partial"), ("tree_attn_reduce", "attn_merge"), ("splitk_reduce", "reduce"), ("Cijk", "prefill_gemm"),
            ("prefill_attn", "prefill_attn"), ("quant_rows", "quant"))
 
