@@ -29,7 +29,9 @@
 #define C8_NL 8
 #define C8_MPAD (32 * C8_NL)
 #define C8_BUFBYTES (C8_NL * 4096)
-#define C8_LA 2
+#ifndef C8_LA
+#define C8_LA 2  // groups of lookahead (-DC8_LA=3: 12 KiB of W per wave + 96 KiB of X per workgroup in flight, all 160 KiB of LDS)
+#endif
 #define C8_LDS_BYTES ((C8_LA + 2) * C8_BUFBYTES)  // 128 KiB (ring of LA + 1 buffers + the zero buffer): one workgroup per CU
 
 template <int W8> constexpr int c8_group_k() { return W8 == 2 ? 128 : 64; }
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
   constexpr int GK = KSTEP * LOADS;        // k per group: 128 bytes of every activation row in all three forms
   constexpr int PPW = 4;                   // 1 KiB activation pieces a wave moves per group: the four pieces of tile `wave`
   constexpr int QIN = LA * (TL + PPW);     // memory operations in flight per wave in steady state
-  static_assert(LA == 2, "the group bodies below are written for two groups of lookahead");
+  static_assert(LA == 2 || LA == 3, "the loop below is unrolled for two or three groups of lookahead");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
   // Split-K launches: the workgroups of one split read the same [256, K / S] slice of X.  Workgroups go to the XCDs round-robin by linear id
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
   // stand-in weight source: tile 0 of the workgroup's first row block, every 1 KiB load at the same bytes (offsets cancelled)
   const long wstand_off = ((long)min(bx * 8, tiles - 1) - tile) * (K / KSTEP) * (TPS * 1024) - (long)g_lo * (TL * 1024);  // (relative to wsrc)
   __syncthreads();  // (the zero buffer is written; nothing else touches LDS before the first DMA lands)
-  // ---- prologue: groups 0 and 1 in the steady-state order [D(0), W(0, *), D(1), W(1, *)]
+  // ---- prologue: groups 0 .. LA-1 in the steady-state order [D(0), W(0, *), D(1), W(1, *), ...]
   C8_DMA(0, 0)
   C8_WLOAD_ALL(0, wsrc)
   {
@@ -202,11 +204,17 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
     C8_DMA(min(1, G - 1), 1)
     C8_WLOAD_ALL(1, wp)
   }
+  if constexpr (LA > 2) {
+    const unsigned char* wp = wsrc + (G > 2 ? (long)(2 * TL * 1024) : wstand_off);
+    C8_DMA(min(2, G - 1), 2)
+    C8_WLOAD_ALL((LA > 2 ? 2 : 0), wp)
+  }
   wide_wait_barrier<QIN - PPW>();  // group 0's activations are staged
   int rd = 0, wr = LA, gi = 0;  // ring slot read by the current group / written by the prefetch (LA ahead, mod NB)
   while (gi < G) {
     C8_GROUP(0)
     C8_GROUP(1)
+    if constexpr (LA > 2) C8_GROUP((LA > 2 ? 2 : 0))
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stand-in fetches of the last groups (their LDS-DMAs must not outlive the workgroup)
 #undef C8_GROUP
