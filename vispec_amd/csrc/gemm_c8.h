@@ -7,7 +7,9 @@
 // GEMM costs, in CU-time: per (row block x request tile) a workgroup of RB row blocks x NL tiles ingests (RB + NL) / (RB NL) units —
 // 0.375 at 8 x 4 (and at every shape two accumulator sets allow for eight tiles), 0.25 at 8 x 8.  So the eight-request form gives the
 // quarter fold up: ONE accumulator set per wave (16 x 8 = 128 registers), the split's K range walked in ascending k from the first
-// k-step to the last.
+// k-step to the last.  Measured (profiles/r05_*): 1.35-1.39 x the time of the 8 x 4 kernel for twice the requests; the matrix pipe of
+// the CUs it occupies is ~78 % busy (SQ_VALU_MFMA_BUSY_CYCLES = 32 x the MFMA count) next to ~50 of ~54 GB/s of ingest: M = 256 rows per
+// weight pass is the CU's balance point — more requests per pass would be MFMA-bound.
 //
 // Arithmetic ("the c8 order"): an output element is ONE chain of v_mfma_f32_32x32x16_bf16 (fp8 activations: v_mfma_scale_f32_32x32x64_f8f6f4)
 // accumulations over the split's k-steps in ascending order, starting from +0; split-K partials are added in ascending split order by
