@@ -110,3 +110,16 @@ def test_bench_resolves_real_checkpoint_directories(tmp_path, monkeypatch):
         bench.resolve_weights(NS(base_model_path=str(a), spec_model_path=None, weights_dir=None))
     with pytest.raises(SystemExit):
         bench.resolve_weights(NS(base_model_path=str(a), spec_model_path=str(tmp_path / "missing"), weights_dir=None))
+
+
+def test_bench_host_helpers_degrade_without_a_gpu_or_numa_information(monkeypatch):
+    """bench.py pins a rank's lane threads to the NUMA node of its GPU and reports what the rank costs the host; on a box without a GPU (here),
+    without /sys NUMA files, or with VISPEC_BENCH_AFFINITY=0 the pinning is a no-op that says why — it never raises and never narrows the affinity."""
+    from vispec_amd.evaluation.bench_launch import host_usage, pin_to_gpu_numa_node
+    before = os.sched_getaffinity(0)
+    note = pin_to_gpu_numa_node(0)
+    assert note.startswith("none") and os.sched_getaffinity(0) == before
+    monkeypatch.setenv("VISPEC_BENCH_AFFINITY", "0")
+    assert pin_to_gpu_numa_node(0).startswith("off") and os.sched_getaffinity(0) == before
+    cpu_s, rss_gb = host_usage()
+    assert cpu_s > 0 and 0 < rss_gb < 64
