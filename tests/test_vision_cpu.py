@@ -77,13 +77,23 @@ def test_qwen25vl_front_end_and_config(tmp_path):
     torch.manual_seed(2)
     m = Qwen2_5_VLForConditionalGeneration(cfg).eval()
     m.save_pretrained(tmp_path)
-    fe = HFVisionFrontEnd.from_dir(str(tmp_path), "cpu", torch.float32)
+    fe = HFVisionFrontEnd.from_dir(str(tmp_path), "cpu", torch.float32, batched_windows=False)  # HF's own forward, call for call
     grid = torch.tensor([[1, 4, 6], [1, 2, 2]])
     pv = torch.randn(int(grid.prod(1).sum()), 3 * 2 * 14 * 14)
     with torch.no_grad():
         ref = _pooled(m.model.get_image_features(pv, grid))
     mine = fe.features(pv, image_grid_thw=grid)
     assert torch.equal(mine, ref) and mine.shape == (7, 64)  # (4*6 + 2*2) / merge 4
+    # the default: equal-length windows attended in one batched call (vision.py: _qwen_vision_attention_batched) — the same numbers; a grid with
+    # border windows of several lengths and two images
+    fe_b = HFVisionFrontEnd.from_dir(str(tmp_path), "cpu", torch.float32)
+    for g in (grid, torch.tensor([[1, 10, 14], [1, 6, 4]])):
+        pv = torch.randn(int(g.prod(1).sum()), 3 * 2 * 14 * 14)
+        with torch.no_grad():
+            ref = _pooled(m.model.get_image_features(pv, g))
+        got = fe_b.features(pv, image_grid_thw=g)
+        assert got.shape == ref.shape
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
     tcfg, sd, _ = load_target_dir(str(tmp_path))
     assert tcfg.qkv_bias and tcfg.attn_impl == "sdpa" and tuple(tcfg.mrope_section) == (4, 6, 6)
     assert (tcfg.image_token_index, tcfg.video_token_id, tcfg.num_kv_heads) == (150, 151, 1)

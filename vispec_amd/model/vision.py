@@ -45,15 +45,54 @@ def _strip(key, prefixes):
     return None
 
 
-class HFVisionFrontEnd:
-    """`features(pixel_values, image_sizes=None, image_grid_thw=None)` -> [n_image_tokens, D_text] in prompt order."""
+def _qwen_vision_attention_batched(self, hidden_states, cu_seqlens, position_embeddings=None, **kwargs):
+    """Drop-in for transformers' Qwen2_5_VLVisionAttention.forward on its non-flash path.  HF splits the sequence at `cu_seqlens` and calls the
+    attention once per chunk in a Python loop, after a `.tolist()` of a device tensor — for one 1280x960 image that is ~110 windows x 28 windowed
+    layers = ~3 000 attention calls and 32 host synchronisations per image set (measured: the tower costs the Qwen lines of bench.py 17-36 %
+    when it runs inside the timed request, profiles/r05_vision_in_region_ab.txt).  Same arithmetic here — qkv, rotary, softmax(q k^T / sqrt(d)) v per
+    chunk, projection — with the chunks of equal length attended as ONE batched scaled_dot_product_attention call (windows come in at most a handful
+    of lengths), and the chunk table computed once per `cu_seqlens` tensor (the tower hands the same two tensors to all its layers)."""
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import apply_rotary_pos_emb_vision
+    S = hidden_states.shape[0]
+    q, k, v = self.qkv(hidden_states).reshape(S, 3, self.num_heads, -1).permute(1, 0, 2, 3).unbind(0)  # [S, H, hd] each
+    cos, sin = position_embeddings
+    q, k = apply_rotary_pos_emb_vision(q, k, cos, sin)
+    groups = getattr(cu_seqlens, "_vispec_groups", None)
+    if groups is None:
+        bounds = cu_seqlens.tolist()
+        by_len = {}
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if hi > lo:
+                by_len.setdefault(hi - lo, []).append(lo)
+        dev = hidden_states.device
+        groups = [(torch.tensor(starts, device=dev)[:, None] + torch.arange(n, device=dev)[None, :]) for n, starts in sorted(by_len.items())]
+        cu_seqlens._vispec_groups = groups  # (a plain attribute on the tensor object: it lives as long as this forward's cu_seqlens does)
+    out = torch.empty_like(q)
+    for idx in groups:  # idx [chunks of this length, length]
+        o = torch.nn.functional.scaled_dot_product_attention(q[idx].transpose(1, 2), k[idx].transpose(1, 2), v[idx].transpose(1, 2), scale=self.scaling)
+        out[idx] = o.transpose(1, 2)
+    return self.proj(out.reshape(S, -1))
 
-    def __init__(self, arch: str, config, tower: nn.Module, projector: Optional[nn.Module], image_newline: Optional[torch.Tensor]):
+
+class HFVisionFrontEnd:
+    """`features(pixel_values, image_sizes=None, image_grid_thw=None)` -> [n_image_tokens, D_text] in prompt order.
+    batched_windows (Qwen2.5-VL tower, default on): the window attention of every vision block runs as one batched SDPA call per chunk length
+    instead of HF's per-window Python loop (_qwen_vision_attention_batched) — the tower stays HF's module on PyTorch-ROCm, only its attention call
+    pattern changes; False = HF's own forward, call for call."""
+
+    def __init__(self, arch: str, config, tower: nn.Module, projector: Optional[nn.Module], image_newline: Optional[torch.Tensor],
+                 batched_windows: bool = True):
         self.arch, self.config, self.tower, self.projector, self.image_newline = arch, config, tower, projector, image_newline
+        if arch == "Qwen2_5_VLForConditionalGeneration" and batched_windows:
+            import types
+            vc = getattr(config, "vision_config", None)
+            if getattr(vc, "_attn_implementation", "sdpa") in ("sdpa", "eager", None):  # (flash_attention_2 takes HF's own varlen call)
+                for blk in getattr(tower, "blocks", []):
+                    blk.attn.forward = types.MethodType(_qwen_vision_attention_batched, blk.attn)
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
-    def from_dir(cls, path: str, device="cpu", dtype=torch.bfloat16) -> "HFVisionFrontEnd":
+    def from_dir(cls, path: str, device="cpu", dtype=torch.bfloat16, batched_windows: bool = True) -> "HFVisionFrontEnd":
         from transformers import AutoConfig, AutoModel
         config = AutoConfig.from_pretrained(path, local_files_only=True)
         arch = (config.architectures or ["?"])[0]
@@ -82,7 +121,7 @@ class HFVisionFrontEnd:
             from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel as Visual
             visual = Visual._from_config(config.vision_config)
             _load(visual, buckets["visual"], "visual")
-            fe = cls(arch, config, visual.to(device, dtype).eval(), None, None)
+            fe = cls(arch, config, visual.to(device, dtype).eval(), None, None, batched_windows=batched_windows)
         else:
             raise NotImplementedError(f"no vision front-end for {arch}")
         return fe
