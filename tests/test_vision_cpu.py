@@ -94,6 +94,12 @@ def test_qwen25vl_front_end_and_config(tmp_path):
         got = fe_b.features(pv, image_grid_thw=g)
         assert got.shape == ref.shape
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+        # a second image set on the same grid: the grid's index tables and chunk tables come from the front-end's cache
+        pv2 = torch.randn_like(pv)
+        with torch.no_grad():
+            ref2 = _pooled(m.model.get_image_features(pv2, g))
+        torch.testing.assert_close(fe_b.features(pv2, image_grid_thw=g), ref2, rtol=1e-5, atol=1e-6)
+    assert len(fe_b._grid_tables) == 2 and all(v for v in fe_b._grid_tables.values())
     tcfg, sd, _ = load_target_dir(str(tmp_path))
     assert tcfg.qkv_bias and tcfg.attn_impl == "sdpa" and tuple(tcfg.mrope_section) == (4, 6, 6)
     assert (tcfg.image_token_index, tcfg.video_token_id, tcfg.num_kv_heads) == (150, 151, 1)

@@ -83,6 +83,7 @@ class HFVisionFrontEnd:
     def __init__(self, arch: str, config, tower: nn.Module, projector: Optional[nn.Module], image_newline: Optional[torch.Tensor],
                  batched_windows: bool = True):
         self.arch, self.config, self.tower, self.projector, self.image_newline = arch, config, tower, projector, image_newline
+        self._batched_windows, self._grid_tables = bool(batched_windows), {}
         if arch == "Qwen2_5_VLForConditionalGeneration" and batched_windows:
             import types
             vc = getattr(config, "vision_config", None)
@@ -127,13 +128,38 @@ class HFVisionFrontEnd:
         return fe
 
     # ------------------------------------------------------------------------------------------------
+    def _qwen_grid_tables(self, grid_thw, device) -> dict:
+        """The index tables HF's Qwen2.5-VL tower derives from `grid_thw` at the top of every forward — rotary position ids, the window
+        permutation, the window and image boundaries (Python loops over the images with `.tolist()` round trips) — computed ONCE per distinct
+        grid with HF's own helpers and handed to the forward through the keyword arguments those helpers look up first (`position_ids`,
+        `window_index`, `cu_window_seqlens`, `cu_seqlens`).  Same tables, same forward; a serving process sees a handful of grids.  The cached
+        boundary tensors also keep the chunk tables of _qwen_vision_attention_batched across requests: no host synchronisation per image set."""
+        if not self._batched_windows:
+            return {}
+        key = tuple(tuple(int(v) for v in row) for row in (grid_thw.tolist() if torch.is_tensor(grid_thw) else grid_thw))
+        hit = self._grid_tables.get((key, str(device)))
+        if hit is None:
+            from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
+            t = self.tower
+            g = torch.as_tensor(key, device=device)
+            try:
+                window_index, cu_window = M.get_vision_window_index(g, spatial_merge_size=t.spatial_merge_size, window_size=t.window_size, patch_size=t.patch_size)
+                cu, _ = M.get_vision_attention_seqlens(g, t.config)
+                hit = dict(position_ids=M.get_vision_position_ids(g, t.spatial_merge_size), window_index=window_index, cu_window_seqlens=cu_window, cu_seqlens=cu)
+            except (AttributeError, TypeError):  # another transformers layout: the tower computes its tables itself
+                hit = {}
+            if len(self._grid_tables) > 64:
+                self._grid_tables.clear()
+            self._grid_tables[(key, str(device))] = hit
+        return dict(hit)
+
     @torch.no_grad()
     def features(self, pixel_values, image_sizes=None, image_grid_thw=None, vision_feature_layer=None,
                  vision_feature_select_strategy=None) -> torch.Tensor:
         c = self.config
         if self.arch == "Qwen2_5_VLForConditionalGeneration":
             dev = next(self.tower.parameters())
-            out = self.tower(pixel_values.to(dev.device, dev.dtype), grid_thw=image_grid_thw.to(dev.device))
+            out = self.tower(pixel_values.to(dev.device, dev.dtype), grid_thw=image_grid_thw.to(dev.device), **self._qwen_grid_tables(image_grid_thw, dev.device))
             out = getattr(out, "pooler_output", out)  # transformers 5.x wraps the merged tokens
             return out if torch.is_tensor(out) else torch.cat(list(out), dim=0)
         layer = c.vision_feature_layer if vision_feature_layer is None else vision_feature_layer
