@@ -196,6 +196,21 @@ __device__ __forceinline__ uint4 ld_weight(const uint4* p) {
 #endif
 }
 
+// Read-once fp32 partials (split-K slabs, attention key-split partials) in the kernels that finish them: -DVISPEC_PARTIAL_NT=1 loads them
+// non-temporal (after this read nobody needs the line again) — measured: 3379 / 3380 vs 3401 / 3396 tok/s with plain loads, same box
+// (profiles/r05_ab_partials_nontemporal.txt): off
+#ifndef VISPEC_PARTIAL_NT
+#define VISPEC_PARTIAL_NT 0
+#endif
+__device__ __forceinline__ float4 ld_partial(const float4* p) {
+#if VISPEC_PARTIAL_NT
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+
 // ---- fp8 ACTIVATIONS (round 4, W8A8: BASELINE config 5 "CDNA4 fp8 MFMA"): the target's q|k|v, gate|up and down GEMMs can take their activations in
 // e4m3 as well, one dynamic scale per row (token): x ~ sx[m] * q[m, k].  The GEMM then runs on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the
 // bf16 rate, 64 k per instruction = two 1 KiB weight tiles) with unit block scales, and the epilogue multiplies the fp32 accumulator by
@@ -719,7 +734,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   for (int n = threadIdx.x * 4; n < N; n += nthreads * 4) {
     float4 p[8];
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) p[sl] = *reinterpret_cast<const float4*>(part + ((size_t)min(sl, S - 1) * Mpad + m) * N + n);
+    for (int sl = 0; sl < 8; ++sl) p[sl] = ld_partial(reinterpret_cast<const float4*>(part + ((size_t)min(sl, S - 1) * Mpad + m) * N + n));
     uint2 rv = make_uint2(0, 0), bv = make_uint2(0, 0);
     if (R) rv = *reinterpret_cast<const uint2*>(R + (size_t)mo * ldr + n);
     if (bias) bv = *reinterpret_cast<const uint2*>(bias + n);
@@ -1453,7 +1468,7 @@ __device__ __forceinline__ void tree_attn_reduce_body(const AttnReq& R, float* _
   }
   float4 po[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) po[t] = *reinterpret_cast<const float4*>(part_o + (base + min(t, ns - 1)) * (128 * 32) + e4);
+  for (int t = 0; t < 16; ++t) po[t] = ld_partial(reinterpret_cast<const float4*>(part_o + (base + min(t, ns - 1)) * (128 * 32) + e4));
   float mm = NEG_INF;
 #pragma unroll
   for (int t = 0; t < 8; ++t) mm = fmaxf(mm, mv[t]);  // clamped duplicates do not change a max
