@@ -36,7 +36,6 @@
 #endif
 #define C8_LDS_BYTES ((C8_LA + 2) * C8_BUFBYTES)  // 128 KiB (ring of LA + 1 buffers + the zero buffer): one workgroup per CU
 
-template <int W8> constexpr int c8_group_k() { return W8 == 2 ? 128 : 64; }
 // the fast kernel needs whole groups: K a multiple of the group, at least one group per split
 static inline bool c8_fast_ok(int K, int S, int W8) {
   const int gk = W8 == 2 ? 128 : 64;
