@@ -955,7 +955,13 @@ static int launch_attention_n(hipStream_t s, const AttnCall* calls, int n, int l
   // 512 keys (four 128-key chunks) per workgroup: round 2 ran 256; with the four requests of a wide cohort in one launch the 256-key
   // grid is three rounds of workgroups per CU slot and twice the partial tiles to merge (4 lanes x cohort 4: 1980 -> 2070 tok/s; one
   // request alone: 5.29 -> 5.21 ms per round)
-  int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : 512;
+  // cohorts of five to eight requests (round 5): 768 keys — eight requests are 1 792 workgroups at 512 keys (seven rounds of the CU slots two
+  // workgroups hold each), a third fewer partial tiles to write and merge at 768: 3369 / 3379 -> 3418 tok/s on the same box, while ONE request
+  // alone loses its parallelism (4.90 -> 5.01 ms per round: single requests and cohorts of up to four keep 512, and with it their split
+  // boundaries — the bit-identity of a cohort row with the single-request row).  All cohorts of 5..8 share the 768-key boundaries, so a request's
+  // result still does not depend on the cohort's size or composition (profiles/r05_env_knobs_sweep.txt).
+  static const int kpw_c8 = getenv("VISPEC_ATT_KPW_C8") ? atoi(getenv("VISPEC_ATT_KPW_C8")) : 768;
+  int kpw = (kpw_env >= ATT2_CHUNK && kpw_env % ATT2_CHUNK == 0) ? kpw_env : ((n > 4 && kpw_c8 >= ATT2_CHUNK && kpw_c8 % ATT2_CHUNK == 0) ? kpw_c8 : 512);
   if (max_keys < 1) max_keys = 1;
   if (max_keys > s_max) max_keys = s_max;
   // keys per workgroup from the CACHE CAPACITY, never from the requests' current lengths: the split boundaries (and with them the order in
