@@ -45,7 +45,7 @@ def test_replicate_weights_world2(mode):
     assert sorted(res[0][5] + res[1][5]) == list(range(7)) and not set(res[0][5]) & set(res[1][5])
 
 
-@pytest.mark.parametrize("world,lanes,cohort,n_requests", [(1, 4, 4, 0), (2, 4, 4, 0), (8, 4, 4, 0), (8, 4, 4, 64), (2, 3, 2, 7), (8, 4, 1, 64)])
+@pytest.mark.parametrize("world,lanes,cohort,n_requests", [(1, 4, 4, 0), (2, 4, 4, 0), (8, 4, 4, 0), (8, 4, 4, 64), (2, 3, 2, 7), (8, 4, 1, 64), (1, 4, 8, 0), (8, 4, 8, 0), (8, 3, 8, 64), (2, 4, 8, 37)])
 def test_bench_request_plan_covers_every_request_exactly_once(world, lanes, cohort, n_requests):
     """bench.py's work split over ranks x lanes x cohorts (BASELINE config 4: 64 requests over 8 replicas): in every step each request id
     appears on exactly one (rank, lane); weak scaling gives every lane one full cohort per step, the fixed batch is dealt i mod world."""
