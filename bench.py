@@ -96,9 +96,10 @@ REFILL = True  # --no-refill: cohort by cohort
 WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight for bf16 weights and for W8A8, four for fp8 weights with bf16 activations)
 
 
-def build_models(device, seed, rank, world, lanes, cohort=1):
+def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
     """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2..4 every lane
-    also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then."""
+    also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then.
+    structured=False (tests/test_unstructured_gpu.py only): plain random matrices, flat logits — never the bench workload."""
     from vispec_amd import parallel, synth_gpu
     from vispec_amd.engine import LLAVA_16_7B, DraftConfig, TargetConfig
     from vispec_amd.model import SpecModel
@@ -123,7 +124,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         first.engine.close()
         del first
     else:  # rank 0 creates the weights; the others allocate same-shaped buffers (different seed) and receive rank 0's over RCCL
-        tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=True, num_q=TREE["num_q"],
+        tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=structured, num_q=TREE["num_q"],
                                      rho=RHO[MODEL], succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
     t_rep = 0.0
     if world > 1 and not real:
@@ -142,7 +143,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1):
         if not same:
             del tw, dw
             torch.cuda.empty_cache()
-            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=True, num_q=TREE["num_q"], rho=RHO[MODEL],
+            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=structured, num_q=TREE["num_q"], rho=RHO[MODEL],
                                          succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
         log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
             f"in {t_rep:.2f} s, checksums {'equal' if same else 'differ: weights regenerated locally'}")
@@ -409,6 +410,8 @@ def main():
                     help="drop BASELINE configs[0] (one LLaVA-1.5-7B-shaped request, L=643, end to end on the host cores, ~20 s) from the cpu_baseline object")
     ap.add_argument("--cpu-config0", action="store_true", help=argparse.SUPPRESS)  # (round 2-3 spelling: the leg is on by default now)
     ap.add_argument("--no-ar", action="store_true")
+    ap.add_argument("--ar-batch1-lanes", action="store_true",
+                    help="also time R lanes of batch-1 AR requests (one request per weight pass): information only, never the denominator of speedup_vs_ar")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="llava7b", choices=sorted(MODELS))
     ap.add_argument("--n-img", type=int, default=0, help="image tokens per request of the llava workloads (default 2144; SURVEY §8d also names 2928)")
@@ -417,7 +420,8 @@ def main():
                                                          "0 = 4 (3 for llava13b: 32 request slots of its 6.7 GB KV caches do not fit 288 GB next to the weights)")
     ap.add_argument("--cohort", type=int, default=8, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="requests per lane that run their rounds in lockstep on ONE weight pass (n = every GEMM of a round serves n "
-                         "independent batch-1 requests; tokens of each request are those of a run on its own)")
+                         "independent batch-1 requests; up to 4: the tokens of each request are bit for bit those of a run on its own; 5..8: the "
+                         "cohort-8 summation order — independent of what shares the pass, but not bit-identical to a solo run)")
     ap.add_argument("--wide-row-blocks", type=int, default=-1, choices=(-1, 0, 2, 3, 4, 8, 84),
                     help="weight row blocks per workgroup of a 3-4 request cohort's GEMMs (vispec_set_wide_row_blocks); -1 = 0 with one lane, "
                          "84 (eight for bf16 weights and W8A8, four for W8A16) with several")
@@ -477,7 +481,10 @@ def main():
     R = args.lanes if args.lanes > 0 else (3 if MODEL == "llava13b" and args.cohort > 6 else 4)
     fp8 = "fp8" in MODEL
     CO = args.cohort
+    t_start = time.time()
     sms, tcfg, t_rep = build_models(device, args.seed, rank, world, R, CO)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_start  # weight synthesis (or checkpoint load) + W32 packing + replication + contexts / KV caches of every lane
     pairs = sms if CO >= 2 else None
     global FRONT_END
     vision_note = "not in the timed region (--no-vision-in-loop): the requests start from projected image features resident in HBM"
@@ -515,7 +522,9 @@ def main():
 
     lock = [0] * R  # lockstep rounds a lane executed in continuous-batching mode (slot utilisation = request-rounds / (CO x this))
 
-    def lane_fn(lane, lo_, hi, ar=False):
+    def lane_fn(lane, lo_, hi, ar=False, ar_new=None):
+        ar_new = MAX_NEW if ar_new is None else ar_new  # (the AR legs' graph-capturing pre-run decodes a few tokens only)
+
         def f():
             lo = lo_
             tok = rnd = 0
@@ -547,13 +556,13 @@ def main():
                             accs += acc
                     while CO >= 2 and ar == "cohort" and len(todo) >= 2:  # the AR baseline at the same batching: CO requests per weight pass
                         now, todo = todo[:CO], todo[CO:]
-                        outs = baseline_generate_cohort(pairs[lane][:len(now)], [get_req(i) for i in now], max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1)
+                        outs = baseline_generate_cohort(pairs[lane][:len(now)], [get_req(i) for i in now], max_new_tokens=ar_new, max_steps=ar_new + 1)
                         for o, i in zip(outs, now):
                             tok += o.shape[1] - get_req(i)[0].shape[1]
                     for i in todo:
                         ids, pix = get_req(i)
                         if ar:
-                            o = sms[lane].baseline_generate(ids, max_new_tokens=MAX_NEW, max_steps=MAX_NEW + 1, **pix)
+                            o = sms[lane].baseline_generate(ids, max_new_tokens=ar_new, max_steps=ar_new + 1, **pix)
                             tok += o.shape[1] - ids.shape[1]
                         else:
                             o, new_token, idx, acc = sms[lane].specgenerate(ids, max_new_tokens=MAX_NEW, log=True, return_acceptance_len=True,
@@ -567,7 +576,12 @@ def main():
             return tok, rnd, accs
         return f
 
+    t_w0 = time.time()
     run_lanes([lane_fn(l, 0, W) for l in range(R)])
+    t_warm = time.time() - t_w0  # the W warm-up steps: every hipGraph of the timed region is captured here, the TunableOp table is read
+    startup = dict(build_models_s=round(t_build, 2), weight_replication_s=round(t_rep, 2), warmup_steps_s=round(t_warm, 2),
+                   note="per rank, before the timed region: weight synthesis / load + W32 packing + contexts and KV caches; then the warm-up steps (graph capture)")
+    log(f"[rank {rank}] start-up: build_models {t_build:.1f} s (replication {t_rep:.1f} s), {W} warm-up step(s) {t_warm:.1f} s")
     lock[:] = [0] * R
     barrier()
     cpu0, _ = host_usage()
@@ -576,6 +590,9 @@ def main():
     barrier()
     dt = time.time() - t0
     cpu1, rss_gb = host_usage()
+    if os.environ.get("VISPEC_BENCH_MARK") and rank == 0:  # tools/mem_activity.py: wall-clock bounds of the timed region (epoch seconds)
+        with open(os.environ["VISPEC_BENCH_MARK"], "w") as f:
+            json.dump(dict(t0=t0, t1=t0 + dt), f)
     host_cpu_s, rank_wall_s = cpu1 - cpu0, dt  # what this rank's host side cost during the timed region (lane threads + launches + event waits)
     tokens = sum(r[0] for r in res)
     rounds = sum(r[1] for r in res)
@@ -589,7 +606,7 @@ def main():
                            backend=None if dist is None else dist.get_backend(), timed_request_ids=sorted(i for lane in plan for st_ in lane[W:W + K] for i in st_),
                            warmup_request_ids=sorted(i for lane in plan for st_ in lane[:W] for i in st_), tokens=int(tokens), rounds=int(rounds),
                            wall_s=round(dt, 4), host_cpu_s=round(host_cpu_s, 3), host_cpu_per_wall=round(host_cpu_s / dt, 3), peak_rss_GB=round(rss_gb, 2),
-                           affinity=affinity, lanes=R), f)
+                           affinity=affinity, lanes=R, startup=startup), f)
     stats = torch.tensor([dt, tokens, rounds, sum(accs)], dtype=torch.float64, device=device)
     host_mx = torch.tensor([host_cpu_s / rank_wall_s, rss_gb], dtype=torch.float64, device=device)
     if dist is not None:
@@ -603,6 +620,12 @@ def main():
     else:
         acc_sum = float(sum(accs))
     value = tokens / dt
+    if dist is not None:
+        # The job's measurement is complete: every rank leaves the process group NOW.  Rank 0's annotation legs below take minutes (single-request
+        # roofline legs, the AR baseline at equal batching); ranks 1..N-1 used to sit in a final dist.barrier() under RCCL's watchdog meanwhile.
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
 
     extra = {}
     if rank == 0:
@@ -638,17 +661,38 @@ def main():
             # ---- roofline legs: per-kernel device timestamps around every skinny-GEMM / attention launch (hipExtLaunchKernel events on the
             #      launch stream), (1) of one more single request, (2) with cohorts, of one cohort of the timed region's size: the kernels the
             #      timed region actually runs (each GEMM launch then serves CO requests with ONE pass over the weight)
-            def price(rep):
+            def price(rep, n_req):
+                """-> (prefill MFMA record, priced kernels, dominant key).  Priced = every launch kind with algorithmic bytes: the GEMMs (the weight
+                once per launch, recorded by the library) and the tree attention's partial kernel (K/V rows of its requests once per launch: the
+                context length lives on the device, so the mid-request context prices it).  DOMINANT = the kind with the largest TOTAL device time
+                (launches x average duration) in this instrumented leg — what a rocprofv3 summary of the same cohort ranks first."""
                 pf_ = rep.pop("gemm_prefill_mfma", None)
-                gemm_ = {k: v for k, v in rep.items() if k.startswith("gemm") and v["bytes"] > 0}
-                # dominant kernel = the instantiation that moves the most bytes per round (it is also the one with the largest total
-                # duration in the rocprofv3 summary under profiles/)
-                dom_ = max(gemm_, key=lambda k: gemm_[k]["bytes"])
-                return pf_, gemm_, dom_
+                priced = {k: dict(v) for k, v in rep.items() if k.startswith("gemm") and v["bytes"] > 0}
+                if "attn_partial" in rep:
+                    a = dict(rep["attn_partial"])
+                    a["bytes"] = a["launches"] * n_req * 2.0 * tcfg.num_kv_heads * tcfg.head_dim * 2 * n_mid
+                    priced["attn_partial"] = a
+                dom_ = max(priced, key=lambda k: priced[k]["ms"])
+                return pf_, priced, dom_
 
-            def roofline_of(rep, gemm_, dom_, keys, note):
-                d = gemm_[dom_]
-                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            def flops_of(kind, v, n_req):
+                """MFMA work of a priced kind: GEMM = 2 x (32 rows per request tile x requests) x N x K (N x K = weight elements = bytes / element size);
+                attention = Q K^T + P V over one 32-row query tile per head: 32 G flops per K/V byte (G = query heads per KV head)."""
+                if kind == "attn_partial":
+                    return 32.0 * (tcfg.num_heads // tcfg.num_kv_heads) * v["bytes"]
+                return 2.0 * 32 * n_req * v["bytes"] / (1 if fp8 else 2)
+
+            def kernel_line(kind, v, n_req):
+                t = v["ms"] * 1e-3
+                hbm, mf = v["bytes"] / t / 8e12, flops_of(kind, v, n_req) / t / 2.5e15
+                return dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2), total_ms=round(v["ms"], 3),
+                            GBps=round(v["bytes"] / t / 1e9, 1), frac=round(hbm, 4), mfma_frac=round(mf, 4),
+                            cus_occupied=round(min(1.0, v.get("workgroups", 0.0) / v["launches"] / 256.0), 3) if v.get("workgroups") else None)
+
+            def roofline_of(rep, priced, dom_, keys, note, n_req):
+                d = priced[dom_]
+                line = kernel_line(dom_, d, n_req)
+                gemm_ = {k: v for k, v in priced.items() if k.startswith("gemm")}
                 all_b = sum(v["bytes"] for v in gemm_.values())
                 all_ms = sum(v["ms"] for v in gemm_.values())
                 # HBM traffic of that kernel from the PMC pass kept under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run;
@@ -667,16 +711,24 @@ def main():
                                               f"the tree: NOT measured by this run; x2 = the guide's gfx950 correction)")
                 except Exception:
                     pass
-                return dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic,
-                            traffic_source=traffic_source,
-                            kernel=f"{dom_} ({keys.get(dom_, '?')})", what=note, launches=int(d["launches"]),
-                            avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                # the roof that binds: the larger of the two fractions.  A cohort GEMM occupies `cus_occupied` of the chip by design (CU-time is
+                # what it costs): per occupied CU its matrix pipe is mfma_frac / cus_occupied busy.
+                bound = "mfma" if line["mfma_frac"] > line["frac"] else "hbm"
+                ach, peak, unit = ((flops_of(dom_, d, n_req) / (d["ms"] * 1e-3) / 1e12, 2500.0, "TFLOP/s") if bound == "mfma"
+                                   else (d["bytes"] / (d["ms"] * 1e-3) / 1e9, 8000.0, "GB/s"))
+                by_bytes = max(gemm_, key=lambda k: gemm_[k]["bytes"])
+                return dict(bound=bound, achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                            hbm_frac=line["frac"], hbm_GBps=line["GBps"], mfma_frac=line["mfma_frac"], cus_occupied=line["cus_occupied"],
+                            mfma_frac_of_occupied_cus=(round(line["mfma_frac"] / line["cus_occupied"], 4) if line["cus_occupied"] else None),
+                            traffic=traffic, traffic_source=traffic_source,
+                            kernel=f"{dom_} ({keys.get(dom_, '?')})",
+                            dominant_by="largest total device time (launches x average duration) among the priced kernels of this instrumented leg",
+                            what=note, launches=int(d["launches"]), avg_launch_us=line["avg_launch_us"],
                             algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                             timing="device begin/end timestamps of each dispatch (hipExtLaunchKernel events) on the launch stream",
                             all_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
-                            by_kernel={k: dict(launches=int(v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
-                                               GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                               frac=round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4)) for k, v in rep.items() if v["bytes"] > 0})
+                            largest_bytes_gemm=dict(kernel=f"{by_bytes} ({keys.get(by_bytes, '?')})", **kernel_line(by_bytes, gemm_[by_bytes], n_req)),
+                            by_kernel={k: kernel_line(k, v, n_req) for k, v in priced.items()})
 
             torch.cuda.synchronize()
             eng.prof_enable(True)
@@ -685,8 +737,8 @@ def main():
             rep = eng.prof_report()
             eng.prof_enable(False)
             # the draft prefill's big-M GEMM is MFMA-bound: the library records its FLOPs, reported on their own below
-            pf, gemm, dom = price(rep)
-            single_roof = roofline_of(rep, gemm, dom, PROF_KERNEL_KEYS, "one request per launch (the instrumented single-request leg)")
+            pf, gemm, dom = price(rep, 1)
+            single_roof = roofline_of(rep, gemm, dom, PROF_KERNEL_KEYS, "one request per launch (the instrumented single-request leg)", 1)
             if pf:
                 single_roof["prefill_gemm_mfma"] = dict(launches=int(pf["launches"]), avg_launch_us=round(1e3 * pf["ms"] / pf["launches"], 2),
                                                         TFLOPs=round(pf["bytes"] / (pf["ms"] * 1e-3) / 1e12, 1), peak=2500.0,
@@ -702,7 +754,7 @@ def main():
                 rep_c = eng.prof_report()
                 eng.prof_enable(False)
                 rep_c.pop("gemm_prefill_mfma", None)
-                _, gemm_c, dom_c = price(rep_c)
+                _, gemm_c, dom_c = price(rep_c, len(now))
                 rb_timed = WIDE_RB if WIDE_RB >= 0 else (0 if R == 1 else 84)
                 wide8 = 3 <= CO <= 4 and (rb_timed == 8 or (rb_timed == 84 and (not fp8 or "a8" in MODEL)))  # (vispec_set_wide_row_blocks(84): W8A16 stays on four)
                 keys_c = PROF_KERNEL_KEYS_C8 if CO >= 5 else ((PROF_KERNEL_KEYS_WIDE8 if wide8 else PROF_KERNEL_KEYS_WIDE) if CO >= 3 else PROF_KERNEL_KEYS_PAIRED)
@@ -711,12 +763,12 @@ def main():
                                                 f"algorithmic bytes = the weight once, whatever the number of requests it serves"
                                                 + ("; the launch shape is the multi-lane one (eight weight row blocks per workgroup: half the workgroups, half "
                                                    "the activation traffic) — alone it fills about a third of the CUs, each at the CU's ingest cap; `deployed` "
-                                                   "times the same kernel the way the timed region runs it" if wide8 else ""))
+                                                   "times the same kernel the way the timed region runs it" if wide8 else ""), len(now))
                 extra["roofline"]["cohort_round_ms_instrumented"] = round(1e3 * st_c["decode_s"] / st_c["rounds"], 3)
                 # one launch serves CO requests with ONE pass over the weight: `achieved` counts those bytes once (the roofline the kernel is held to);
                 # what the CO requests would have streamed one by one is CO times that — the figure to compare across cohort sizes
                 extra["roofline"]["requests_per_launch"] = CO
-                extra["roofline"]["weight_bytes_delivered_to_requests_GBps"] = round(CO * extra["roofline"]["achieved"], 1)
+                extra["roofline"]["weight_bytes_delivered_to_requests_GBps"] = round(CO * extra["roofline"]["largest_bytes_gemm"]["GBps"], 1)  # (of the gate|up launch)
                 extra["roofline"]["wide_row_blocks"] = rb_timed
                 if CO >= 3 and R >= 2:
                     try:
@@ -764,7 +816,8 @@ def main():
                     achieved_region=extra["aggregate"]["streamed_GBps_per_gpu"], frac_region=extra["aggregate"]["frac_of_8TBps"],
                     request_rounds_per_s_per_gpu=extra["aggregate"]["request_rounds_per_s_per_gpu"],
                     region_note="achieved_region / frac_region = algorithmic bytes of the whole timed region (weights / cohort + own KV per request-round) "
-                                "per second per GPU over 8 TB/s; `achieved` / `frac` above = the dominant kernel alone on the GPU")
+                                "per second per GPU over 8 TB/s; `achieved` / `frac` above = the dominant kernel (largest total device time) of one cohort ALONE on "
+                                "the GPU, on the roof that binds it (`bound`); `hbm_frac` / `mfma_frac` = both of its fractions")
                 bk = extra["roofline"].get("by_kernel", {})
                 tot = {k: v["launches"] * v["avg_launch_us"] for k, v in bk.items() if k.startswith("gemm")}
                 if tot:
@@ -802,24 +855,26 @@ def main():
                     extra["spec_equals_ar_prefix"] = int((ar[0, :nmin] == out[0, :nmin]).long().cumprod(0).sum().item()) - ids.shape[1]
                 # the speed-up of the LINE divides like by like (speed.py:56-97): the same lanes x cohorts, the requests of one timed step,
                 # decoded autoregressively with CO requests per weight pass (vispec_cohortn_ar_step)
-                def ar_leg(mode):
+                def ar_leg(mode, ar_new=None):
                     torch.cuda.synchronize()
                     t1_ = time.time()
-                    res_ = run_lanes([lane_fn(l, W, W + 1, ar=mode) for l in range(R)])
+                    res_ = run_lanes([lane_fn(l, W, W + 1, ar=mode, ar_new=ar_new) for l in range(R)])
                     torch.cuda.synchronize()
                     dt_ = time.time() - t1_
                     n_ = sum(r[0] for r in res_)
                     return n_ / dt_, n_, dt_
                 if CO >= 2:
-                    ar_leg("cohort")  # (captures the AR cohort graphs outside the timed leg)
+                    ar_leg("cohort", ar_new=24)  # (captures the AR cohort graphs outside the timed leg: a few steps are enough)
                     ar_rate, ar_n, ar_dt = ar_leg("cohort")
                     extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, cohort=CO, new_tokens=int(ar_n), wall_s=round(ar_dt, 3),
                                                 what=f"greedy AR of the same requests at the SAME batching as the timed region: {R} lanes x {CO} requests per weight pass")
                     extra["speedup_vs_ar"] = round((tokens / world / dt) / ar_rate, 3)
-                    b1_rate, b1_n, b1_dt = ar_leg(True)
-                    extra["ar_baseline_batch1_lanes"] = dict(tokens_per_s=round(b1_rate, 2), lanes=R, cohort=1, new_tokens=int(b1_n), wall_s=round(b1_dt, 3),
-                                                             what=f"{R} lanes of batch-1 AR requests (one request per weight pass): NOT the denominator of speedup_vs_ar — "
-                                                                  f"against it the line is {round((tokens / world / dt) / b1_rate, 3)}x, most of which is batching, not speculation")
+                    if args.ar_batch1_lanes:  # (off by default since round 6: 26 s of a leg that is not the denominator of any figure of the line)
+                        b1_rate, b1_n, b1_dt = ar_leg(True)
+                        extra["ar_baseline_batch1_lanes"] = dict(
+                            tokens_per_s=round(b1_rate, 2), lanes=R, cohort=1, new_tokens=int(b1_n), wall_s=round(b1_dt, 3),
+                            what=f"{R} lanes of batch-1 AR requests (one request per weight pass): NOT the denominator of speedup_vs_ar — against it the "
+                                 f"line is {round((tokens / world / dt) / b1_rate, 3)}x, most of which is batching, not speculation")
                 else:
                     ar_rate, ar_n, ar_dt = ar_leg(True)
                     extra["ar_baseline"] = dict(tokens_per_s=round(ar_rate, 2), lanes=R, cohort=1, new_tokens=int(ar_n), wall_s=round(ar_dt, 3))
@@ -869,11 +924,9 @@ def main():
                      "peak_rss_GB": round(float(host_mx[1]), 2), "lane_threads": R, "host_cores": os.cpu_count(), "affinity": affinity},
             "mean_accept_length_tau": round(acc_sum / max(1.0, rounds), 3), "tokens_per_round": round(tokens / max(1.0, rounds), 3),
         }
+        line["startup"] = startup
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 # library profiling kinds -> the kernel instantiation they time (names as they appear in the rocprofv3 summaries under profiles/)

@@ -232,11 +232,14 @@ int vispec_cohort_draft_round(vispec_ctx* leader, vispec_ctx* member, void* stre
 /* The same for n = 2..8 requests: ctxs[0] = the leader, the others its members owning activation tiles 1 .. n-1 (any order).  Five to
    eight requests (round 5): the target's GEMMs run on csrc/gemm_c8.h's kernel (8 weight row blocks x 8 request tiles per workgroup, ONE
    accumulator chain per output element: a request's tokens do not depend on what shares its weight pass, its logits differ from the
-   single-request kernel's in fp32 summation order only — tests/test_c8_gpu.py, tests/test_full_size_gpu.py), the draft's in the two-tile
-   slab form (single-request order), attention / per-request kernels as one launch for all eight.  With
+   single-request kernel's in fp32 summation order only — tests/test_c8_gpu.py, tests/test_full_size_gpu.py), the draft's GEMMs in the two-tile
+   slab form (the single-request summation order, bit for bit), attention / per-request kernels as one launch for all eight; BOTH attentions
+   of such a cohort — the target's tree attention and the draft's — split the keys 768 per workgroup instead of 512, so the draft path as a
+   whole is composition-independent but, like the target path, not bit-identical to a solo request's.  With
    three or four requests the GEMMs run on csrc/gemm_wide.h's kernel (16 waves = 4 weight row blocks x 4 K-quarters sharing each staged
    activation group; per-row arithmetic identical to the single-request kernel), attention takes all requests in one partial + one
-   reduce launch.  Same guarantees: every request's tokens are those of the same request alone, bit for bit. */
+   reduce launch.  Guarantee for n <= 4: every request's tokens are those of the same request alone, bit for bit; for n = 5..8: every
+   request's tokens are those it produces in ANY cohort of 5..8 (tile, neighbours, live-row count do not matter). */
 int vispec_cohortn_verify_accept(vispec_ctx* const* ctxs, int n, void* stream, int forced_accept);
 int vispec_cohortn_draft_round(vispec_ctx* const* ctxs, int n, void* stream);
 
@@ -311,7 +314,7 @@ int vispec_graph_stats(vispec_ctx*, long long* out3);  /* {replays, captures, di
 int vispec_set_wide_row_blocks(vispec_ctx* leader, int row_blocks);
 /* In-library profiling used by bench.py's roofline object: when on, every skinny-GEMM / attention launch is bracketed by
    HIP events on its own stream.  kinds 0..4 = skinny GEMM {none, residual, swiglu, split-K partial, split-K reduce(+norm)}, 9 = attention
-   partial, 10 = attention reduce.  report: out[kind*3+{0,1,2}] = {launches, total ms, total algorithmic bytes}. Blocking. */
+   partial, 10 = attention reduce.  report: out[kind*4+{0,1,2,3}] = {launches, total ms, total algorithmic bytes, total workgroups}. Blocking. */
 int vispec_prof_enable(vispec_ctx*, int on);
 int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, int n_kinds);
 /* device pointers of internal buffers (hidden_state_new [T,D], verify logits [T,V] bf16, draft last hidden ...) */

@@ -35,6 +35,7 @@
 #define C8_LA 2  // groups of lookahead (-DC8_LA=3: 12 KiB of W per wave + 96 KiB of X per workgroup in flight, all 160 KiB of LDS)
 #endif
 #define C8_LDS_BYTES ((C8_LA + 2) * C8_BUFBYTES)  // 128 KiB (ring of LA + 1 buffers + the zero buffer): one workgroup per CU
+static_assert(C8_LDS_BYTES <= 160 * 1024, "the cohort-8 ring does not fit a CU's 160 KiB of LDS");
 
 // the fast kernel needs whole groups: K a multiple of the group, at least one group per split
 static inline bool c8_fast_ok(int K, int S, int W8) {
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
                                                           const float* __restrict__ wscale, RopeEpi re, int tiles,
                                                           const float* __restrict__ xscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  WGCLK_BEGIN();
   constexpr bool A8 = W8 == 2;
   constexpr int NL = C8_NL, LA = C8_LA, NB = LA + 1;
   constexpr int KSTEP = A8 ? 64 : (W8 ? 32 : 16), LOADS = W8 ? 2 : 4, TPS = A8 ? 2 : 1, TL = LOADS * TPS;  // k per step, steps per group, tiles per step / group
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
 #undef C8_DMA
   if (!tile_ok) return;
   wide_epilogue<EPI, W8, NL, C8_MPAD>(acc, tile, split, j, hi, m_tile, N, bias, Yv, ldy, R, ldr, wscale, re, xscale, n_live);
+  WGCLK_END(10 + EPI, Yv);
 }
 
 // The same arithmetic for shapes the ring cannot walk (K not a multiple of a group, or fewer groups than splits: the tiny models of the test

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wgclock.h"
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -63,6 +64,7 @@ __device__ __forceinline__ void pack_apply(F f, const ArgPack<T, Ts...>& p, Us..
 template <class P> struct Packs4 { P p[MAX_COHORT]; };  // (the name is round 2's: up to MAX_COHORT packs)
 template <class Fn, int TPB, class P>
 __global__ __launch_bounds__(TPB) void batch4_kernel(Packs4<P> a) {
+  WGCLK_SCOPE(70, nullptr);
   const int z = blockIdx.z;  // (selected with compares: a dynamically indexed kernel argument would be copied to scratch; ONE call
   P p = a.p[0];              //  site: a body's static __shared__ arrays must not be instantiated once per request)
   if (z == 1) p = a.p[1];
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 2 ? (NT == 1 ? (W8 == 1 ? VISPEC_W8
   auto grow = [&](int m) { return SLAB ? ((m >> 3) << 5) + (m & 7) : m; };  // row of X / Y / R that tile row m stands for
   static_assert(UNROLL == 4 || UNROLL == 8, "staging map is written for 4 or 8 k-steps per group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  WGCLK_SCOPE(40 + EPI + 8 * (SLAB ? 1 : 0), Yv);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index provably uniform
   const int j = lane & 31, hi = lane >> 5;
   const int tile = blockIdx.x, split = blockIdx.y;
@@ -720,6 +723,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   // clamped (always valid) slab indices, residual, bias, norm weight — is issued before the first use, and a row that fits one
   // pass of the block (N <= 4 x threads: every model here) keeps its values in registers across the block-wide sum of squares.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+  WGCLK_SCOPE(60, Y);
   float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable): only for rows longer than one pass
   __shared__ float partsum[16];
   const int m = blockIdx.x;
@@ -1009,6 +1013,7 @@ template <bool EAGER>
 __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs args, int ldq, int s_max, int H, int H_kv, int M, int tail,
                                                                     int keys_per_wg, int nsplit, int NQT, int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WGCLK_BEGIN();
   unsigned char* sK = smem;
   unsigned char* sV = smem + ATT2_CHUNK * 256;
   const int split = blockIdx.x, kvh = blockIdx.y;
@@ -1221,6 +1226,7 @@ __global__ __launch_bounds__(256, 2) void tree_attn2_partial_kernel(AttnArgs arg
   // last arriver: agent acquire -> barrier -> plain loads.  (First form: plain stores + a lane-0 agent RELEASE fence per workgroup — the L2
   // write-back of 16 KB of fresh partial per workgroup, 1 792 times a launch: 3252 -> 2556 tok/s, profiles/r05_ab_attention_fused_merge.txt.)
   // The ticket counter returns to zero with the last arriver (graph replays start from zero).
+  WGCLK_END(EAGER ? 20 : 21, args.r[0].part_o);
   if (!fused) return;
   const int ns_act = max(1, min(nsplit, (n_total + keys_per_wg - 1) / keys_per_wg));  // workgroups that did not take the early exit above
   __shared__ int s_last;
@@ -1283,6 +1289,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Vc, int s_max, int H, int H_kv, int L,
                                                               bf16_t* __restrict__ out, int ldo, int paired) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WGCLK_BEGIN();
   unsigned char* sK = smem;
   unsigned char* sV = smem + ATT2_CHUNK * 256;
   const int head = blockIdx.y, kvh = head / (H / H_kv);
@@ -1435,6 +1442,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const bf16_t* __re
   }
   __syncthreads();  // the next pass re-stages the LDS image
   }
+  WGCLK_END(30, out);
 }
 
 // merge partials over splits — the body: (head, m-tile) of request R, d-rows [32 dpart, +32); 256 threads; `sh` = 10.5 KB of LDS scratch
@@ -1521,7 +1529,9 @@ __global__ __launch_bounds__(256) void tree_attn_reduce_kernel(AttnArgs args, in
   const AttnReq R = attn_req(args, blockIdx.z);
   __shared__ float sh[ATT_RED_LDS_FLOATS];
   const int MT = (M + 31) >> 5;
+  WGCLK_BEGIN();
   tree_attn_reduce_body(R, sh, blockIdx.x / MT, blockIdx.x % MT, blockIdx.y, H, H_kv, M, tail, keys_per_wg, nsplit, ldo);
+  WGCLK_END(22, args.r[0].part_o);
 }
 
 // x <- bf16(x + r) (the residual add of the decoder layer, modeling_llama_kv.py:742-756) and y = RMSNorm(x) * w in ONE pass over the row:

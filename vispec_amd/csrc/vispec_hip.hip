@@ -31,6 +31,16 @@ static int fail(const std::string& s) {
     if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));                     \
   } while (0)
 #define KCHK() HIPCHK(hipGetLastError())
+// every extern "C" entry point that takes a ctx starts with one of these: a leader destroyed while members were alive is a ZOMBIE (its
+// workspaces live on for the members that alias them, its handle is dead) — include/vispec_hip.h: "every entry point refuses it"
+#define CTX_LIVE(ctx)                                                                                         \
+  do {                                                                                                        \
+    if (!(ctx) || (ctx)->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)"); \
+  } while (0)
+#define CTX_LIVE_OPT(ctx) /* entry points that accept ctx == nullptr (bare GEMM launches without workspaces) */ \
+  do {                                                                                                        \
+    if ((ctx) && (ctx)->zombie) return fail("the leader ctx was already destroyed: its handle is invalid");      \
+  } while (0)
 
 struct vispec_ctx {
   vispec_config c;
@@ -277,7 +287,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<0>()) != hipSuccess) (void)hipGetLastError();
     for (const void* f : wide8_fp8)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide8_lds_bytes<1>()) != hipSuccess) (void)hipGetLastError();
-    // the cohort-8 form (gemm_w32_c8_kernel): 96 KiB of dynamic LDS
+    // the cohort-8 form (gemm_w32_c8_kernel): C8_LDS_BYTES = (C8_LA + 2) x 32 KiB = 128 KiB of dynamic LDS (160 KiB with -DC8_LA=3: the whole CU)
 #define C8_ALL_EPI(W8_)                                                                                                     \
   (const void*)gemm_w32_c8_kernel<EPI_NONE, W8_>, (const void*)gemm_w32_c8_kernel<EPI_RESIDUAL, W8_>,                          \
       (const void*)gemm_w32_c8_kernel<EPI_SWIGLU, W8_>, (const void*)gemm_w32_c8_kernel<EPI_PARTIAL, W8_>,                     \
@@ -328,21 +338,25 @@ extern "C" void vispec_ctx_destroy(vispec_ctx* ctx) {
 }
 
 extern "C" int vispec_set_target_layer(vispec_ctx* ctx, int layer, const vispec_layer_weights* w) {
+  CTX_LIVE(ctx);
   if (!ctx || !w || layer < 0 || layer >= ctx->c.num_layers) return fail("bad layer");
   ctx->layers[layer] = *w;
   return 0;
 }
 extern "C" int vispec_set_target_misc(vispec_ctx* ctx, const vispec_target_misc* m) {
+  CTX_LIVE(ctx);
   if (!ctx || !m) return fail("null");
   ctx->tm = *m;
   return 0;
 }
 extern "C" int vispec_set_draft_weights(vispec_ctx* ctx, const vispec_draft_weights* w) {
+  CTX_LIVE(ctx);
   if (!ctx || !w) return fail("null");
   ctx->dw = *w;
   return 0;
 }
 extern "C" int vispec_set_kv(vispec_ctx* ctx, void* target_kv, void* draft_kv) {
+  CTX_LIVE(ctx);
   if (!ctx) return fail("null");
   ctx->target_kv = (bf16_t*)target_kv;
   ctx->draft_kv = (bf16_t*)draft_kv;
@@ -361,6 +375,7 @@ struct Prof {
   std::vector<hipEvent_t> ev;  // 2 per record
   std::vector<int> kind;
   std::vector<double> bytes;
+  std::vector<double> wgs;  // workgroups of the bracketed launch (PLAUNCH): CUs asked for
   size_t used = 0;
   hipEvent_t cur_a = nullptr, cur_b = nullptr;  // events of the launch being bracketed
 } g_prof;
@@ -371,6 +386,8 @@ static void prof_begin(hipStream_t, int kind, double bytes) {
   }
   g_prof.kind.resize(g_prof.used + 1);
   g_prof.bytes.resize(g_prof.used + 1);
+  g_prof.wgs.resize(g_prof.used + 1);
+  g_prof.wgs[g_prof.used] = 0.0;
   g_prof.kind[g_prof.used] = kind;
   g_prof.bytes[g_prof.used] = bytes;
   g_prof.cur_a = g_prof.ev[2 * g_prof.used];
@@ -384,8 +401,11 @@ static void prof_end(hipStream_t) {
 // launch inside a prof_begin / prof_end bracket
 #define PLAUNCH(kernel, grid, block, lds, s, ...)                                                                          \
   do {                                                                                                                      \
-    if (g_prof.cur_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_prof.cur_a, g_prof.cur_b, 0, __VA_ARGS__);       \
-    else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                                      \
+    if (g_prof.cur_a) {                                                                                                     \
+      const dim3 g_ = (grid);                                                                                               \
+      g_prof.wgs[g_prof.used] = (double)g_.x * g_.y * g_.z;                                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_prof.cur_a, g_prof.cur_b, 0, __VA_ARGS__);                       \
+    } else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                                    \
   } while (0)
 // One launch of a small per-request kernel for ALL requests of a cohort (csrc/kernels.h: batch4_kernel runs the kernel's body with the
 // argument pack of request blockIdx.z).
@@ -402,23 +422,42 @@ extern "C" int vispec_prof_enable(vispec_ctx*, int on) {
   g_prof.cur_a = g_prof.cur_b = nullptr;
   return 0;
 }
-// out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic bytes}; blocking.
+// out[kind*4 + {0,1,2,3}] = {launches, total ms, total algorithmic bytes, total workgroups}; blocking.
 extern "C" int vispec_prof_report_host(vispec_ctx*, void* stream, double* out, int n_kinds) {
   if (!out || n_kinds < 1) return fail("bad args");
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  for (int i = 0; i < n_kinds * 3; ++i) out[i] = 0.0;
+  for (int i = 0; i < n_kinds * 4; ++i) out[i] = 0.0;
   for (size_t r = 0; r < g_prof.used; ++r) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * r], g_prof.ev[2 * r + 1]));
     const int k = g_prof.kind[r];
     if (k < 0 || k >= n_kinds) continue;
-    out[k * 3 + 0] += 1.0;
-    out[k * 3 + 1] += ms;
-    out[k * 3 + 2] += g_prof.bytes[r];
+    out[k * 4 + 0] += 1.0;
+    out[k * 4 + 1] += ms;
+    out[k * 4 + 2] += g_prof.bytes[r];
+    out[k * 4 + 3] += g_prof.wgs[r];
   }
   g_prof.used = 0;
   return 0;
 }
+
+#ifdef VISPEC_WG_CLOCK
+// Diagnostic build only (csrc/wgclock.h; tools/wg_clock.py): the record buffer of the per-workgroup clocks.  Not declared in
+// include/vispec_hip.h and absent from the product build.
+extern "C" int vispec_debug_wgclock_set(void* buf, unsigned cap) {
+  WgClkRec* b = (WgClkRec*)buf;
+  const unsigned zero = 0;
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgclk_buf), &b, sizeof(b)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgclk_cap), &cap, sizeof(cap)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgclk_n), &zero, sizeof(zero)));
+  return 0;
+}
+extern "C" long long vispec_debug_wgclock_count(void) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgclk_n), sizeof(n)) != hipSuccess) return -1;
+  return (long long)n;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------ launch helpers
 // packed size in bf16 elements of an [N, K] weight in the W32 layout (rows padded to a multiple of 32)
@@ -1136,16 +1175,19 @@ extern "C" int vispec_pack_weight_fp8(vispec_ctx*, void* stream, const void* Wq_
 // vispec_gemm_skinny on an fp8 (e4m3) W32 image: Y = bf16(scale[n] * (X · Wq^T) + bias) (+ epilogue); scale fp32 [N] (2N for SwiGLU)
 extern "C" int vispec_gemm_skinny_fp8(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P8, const void* wscale,
                                       const void* bias, void* Y, int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
+  CTX_LIVE_OPT(ctx);
   if (epilogue < 0 || epilogue > 2 || !wscale) return fail("gemm_skinny_fp8: bad arguments");
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P8, bias, Y, ldy, R, ldr, M, N, K, epilogue, wscale);
 }
 extern "C" int vispec_gemm_skinny(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
                                   int ldy, const void* R, int ldr, int M, int N, int K, int epilogue) {
+  CTX_LIVE_OPT(ctx);
   if (epilogue < 0 || epilogue > 2) return fail("gemm_skinny: bad epilogue");
   return launch_gemm(ctx, (hipStream_t)stream, X, ldx, P, bias, Y, ldy, R, ldr, M, N, K, epilogue);
 }
 extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* wscale, const void* bias, void* Y,
                                   int ldy, const void* R, int ldr, int n_req, int m_tile, int N, int K, int epilogue) {
+  CTX_LIVE_OPT(ctx);
   if (epilogue < 0 || epilogue > 2) return fail("gemm_cohort: bad epilogue");
   if (n_req < 2 || n_req > MAX_COHORT || m_tile == 0 || m_tile > 32 || m_tile < -8) return fail("gemm_cohort: 2..8 requests of 1..32 rows (slab mode: -8..-1)");
   if (m_tile < 0)  // slab mode: the requests' rows share one activation tile
@@ -1158,6 +1200,7 @@ extern "C" int vispec_gemm_cohort(vispec_ctx* ctx, void* stream, const void* X, 
 // fused RMSNorm of the split-K reduce (the o_proj / down_proj form).
 extern "C" int vispec_gemm_fp8a8(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P8, const void* wscale, const void* bias, void* Y, int ldy,
                                  const void* R, int ldr, int n_req, int m_tile, int M, int N, int K, int epilogue, const void* norm_w, void* normed, float eps) {
+  CTX_LIVE_OPT(ctx);
   if (!ctx || !wscale || epilogue < 0 || epilogue > 2 || K % 64 || ldx != K) return fail("gemm_fp8a8: needs a ctx, weight scales, K %% 64 == 0 and a dense X (ldx == K)");
   if (n_req < 1 || n_req > MAX_COHORT || (n_req > 1 && (m_tile < 1 || m_tile > 32)) || (n_req == 1 && (M < 1 || M > 64))) return fail("gemm_fp8a8: bad row layout");
   const size_t kmax = (size_t)std::max(std::max((int)ctx->c.hidden_size, (int)(ctx->c.num_heads * ctx->c.head_dim)), (int)ctx->c.intermediate_size);
@@ -1185,6 +1228,7 @@ extern "C" int vispec_quant_rows_e4m3(vispec_ctx*, void* stream, const void* X, 
 }
 // test hook: the ctx's W8A8 scratch (e4m3 codes [rows][K] and per-row scales) as the last quantisation left it — copied on `stream`
 extern "C" int vispec_a8_scratch_read(vispec_ctx* ctx, void* stream, void* codes_out, void* scales_out, int rows, int K) {
+  CTX_LIVE(ctx);
   if (!ctx || !ctx->xq || rows < 1 || rows > ROWS || K < 1) return fail("a8_scratch_read: bad arguments");
   if (hipMemcpyAsync(codes_out, ctx->xq, (size_t)rows * K, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
       hipMemcpyAsync(scales_out, ctx->sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
@@ -1195,6 +1239,7 @@ extern "C" int vispec_a8_scratch_read(vispec_ctx* ctx, void* stream, void* codes
 extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void* X, int ldx, const void* P, const void* bias, void* Y,
                                        int ldy, const void* R, int ldr, const void* norm_w, void* normed, int ldn, float eps, int M,
                                        int N, int K) {
+  CTX_LIVE_OPT(ctx);
   GemmOut o;
   o.Y = Y; o.ldy = ldy; o.R = R; o.ldr = ldr; o.norm_w = norm_w; o.normed = normed; o.ldn = ldn; o.eps = eps;
   return launch_gemm_ex(ctx, (hipStream_t)stream, X, ldx, P, bias, M, N, K, R ? EPI_RESIDUAL : EPI_NONE, o);
@@ -1203,6 +1248,7 @@ extern "C" int vispec_gemm_skinny_norm(vispec_ctx* ctx, void* stream, const void
 //   variant = S*100 + NW_code*10 + UNROLL_code ; NW_code 0/1 = 4/8 waves ; UNROLL_code 0/1/2 = 4/8/16 ; S = split-K (>=1 -> partial path)
 extern "C" int vispec_gemm_skinny_tune(vispec_ctx* ctx, int variant, void* stream, const void* X, int ldx, const void* P, void* Y, int ldy,
                                        int M, int N, int K) {
+  CTX_LIVE_OPT(ctx);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)P;
   const int tiles = (N + 31) / 32;
@@ -1389,6 +1435,7 @@ extern "C" int vispec_gemm_qkv_rope(vispec_ctx* ctx, void* stream, const void* X
                                     const void* bias, void* qkv, int M, int H, int H_kv, int hd, int K, const void* cosT,
                                     const void* sinT, const int* pos_base_dev, const int* pos_off_dev, void* k_cache, void* v_cache,
                                     int s_max, const int* kv_base_dev) {
+  CTX_LIVE_OPT(ctx);
   if (hd != 128) return fail("gemm_qkv_rope: head_dim must be 128");
   PosSpec ps;
   ps.base = pos_base_dev;
@@ -1399,7 +1446,8 @@ extern "C" int vispec_gemm_qkv_rope(vispec_ctx* ctx, void* stream, const void* X
 extern "C" int vispec_tree_attention(vispec_ctx* ctx, void* stream, const void* q, int ldq, const void* k_cache,
                                      const void* v_cache, int s_max, int H, int H_kv, int hd, int M, const int* prefix_dev,
                                      int tail, const uint64_t* mask_dev, void* out, int ldo, int eager_scores) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE_OPT(ctx);
+  CTX_LIVE(ctx);
   if (hd != 128) return fail("tree_attention: head_dim must be 128");
   return launch_attention(ctx, (hipStream_t)stream, q, ldq, k_cache, v_cache, s_max, H, H_kv, M, prefix_dev, tail,
                           (const unsigned long long*)mask_dev, out, ldo, eager_scores, s_max);
@@ -1412,6 +1460,7 @@ extern "C" int vispec_argmax_rows(vispec_ctx*, void* stream, const void* logits,
 }
 extern "C" int vispec_logsoftmax_topk(vispec_ctx* ctx, void* stream, const void* logits, int ld, int M, int V, int k, int* out_idx,
                                       float* out_logp) {
+  CTX_LIVE_OPT(ctx);
   return launch_lstopk(ctx, (hipStream_t)stream, logits, ld, M, V, k, out_idx, out_logp);
 }
 
@@ -1494,12 +1543,13 @@ static vispec_ctx::GraphKey graph_key(vispec_ctx* ctx, int forced_accept, bool s
 }
 // out[0..2] = {graph replays, graph captures, direct (un-graphed) runs} of the round functions since ctx creation
 extern "C" int vispec_graph_stats(vispec_ctx* ctx, long long* out3) {
+  CTX_LIVE(ctx);
   if (!ctx || !out3) return fail("null");
   out3[0] = ctx->graph_replays; out3[1] = ctx->graph_captures; out3[2] = ctx->direct_runs;
   return 0;
 }
 extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   if (row_blocks != 0 && row_blocks != 8 && row_blocks != 84 && (row_blocks < 2 || row_blocks > 4))
     return fail("wide_row_blocks: 8, 4, 3, 2, 84 (= 8 for bf16 weights, 4 for fp8: several lanes) or 0 (= the smallest of 2..4 that still runs in one round of CUs: one lane)");
   ctx->wide_rb = row_blocks;  // (part of the graph key: cohort rounds captured with another value are not replayed)
@@ -1510,14 +1560,14 @@ extern "C" int vispec_set_wide_row_blocks(vispec_ctx* ctx, int row_blocks) {
 // and the draft keep bf16 activations (the PyTorch prefill of an "fp8a8" model quantises the same three GEMM inputs itself and runs the library's
 // fp8 x fp8 GEMM: model/target.py).  Set it on every ctx of a cohort.  (Cached graphs are dropped.)
 extern "C" int vispec_set_fp8_activations(vispec_ctx* ctx, int on) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   if (on && (ctx->c.hidden_size % 64 || ctx->c.intermediate_size % 64)) return fail("fp8 activations need hidden and intermediate sizes that are multiples of 64");
   ctx->a8 = on != 0;
   for (auto* g : {&ctx->g_verify, &ctx->g_draft, &ctx->g_ar, &ctx->g_cverify, &ctx->g_cdraft, &ctx->g_car}) g->clear();
   return 0;
 }
 extern "C" int vispec_set_graphs(vispec_ctx* ctx, int on) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   ctx->use_graphs = on != 0;
   return 0;
 }
@@ -1548,7 +1598,7 @@ __global__ void set_first_token_kernel(DevState* st, const int* tok, int draft_l
 }
 
 extern "C" int vispec_begin_request(vispec_ctx* ctx, void* stream, const int* prompt_ids_host, int L, int max_new_tokens) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   if (L < 1 || L + c.total_token + 8 > c.max_pos) return fail("prompt does not fit the KV cache");
@@ -1743,7 +1793,7 @@ static int draft_round_body(const Cohort& co, hipStream_t s) {
   return draft_grow_tree(co, s);
 }
 extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipStream_t s = (hipStream_t)stream;
   const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_draft, graph_key(ctx, 0, false), [&]() { return draft_round_body(co, s); });
@@ -1751,7 +1801,7 @@ extern "C" int vispec_draft_round(vispec_ctx* ctx, void* stream) {
 
 extern "C" int vispec_draft_prefill(vispec_ctx* ctx, void* stream, const void* hidden, const void* embeds,
                                     const uint8_t* image_mask_host, int L, const int* first_token_dev) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipStream_t s = (hipStream_t)stream;
   const vispec_config& c = ctx->c;
   const int D = c.hidden_size, q = c.num_q, Hd = c.draft_heads;
@@ -2081,7 +2131,7 @@ static int target_accept(const Cohort& co, hipStream_t s, int T, int forced_acce
 }
 
 extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipStream_t s = (hipStream_t)stream;
   const Cohort co = solo_cohort(ctx);
   return run_graphed(ctx, s, ctx->g_verify, graph_key(ctx, forced_accept, true), [&]() {
@@ -2090,11 +2140,11 @@ extern "C" int vispec_verify_accept(vispec_ctx* ctx, void* stream, int forced_ac
   });
 }
 extern "C" int vispec_target_forward(vispec_ctx* ctx, void* stream) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   return target_forward(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token);
 }
 extern "C" int vispec_accept(vispec_ctx* ctx, void* stream, int forced_accept) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   return target_accept(solo_cohort(ctx), (hipStream_t)stream, ctx->c.total_token, forced_accept);
 }
 
@@ -2184,7 +2234,7 @@ extern "C" int vispec_set_retrieve_host(vispec_ctx* ctx, void* stream, const int
 // multinomial) from a host table instead of the counter-based generator — the way the reference's RECORDED draws (tests/golden g7) are fed
 // to verify_accept_sample_kernel.  u = [n_leaf, max_depth] row-major; u == NULL switches the override off.  Blocking.
 extern "C" int vispec_set_uniform_override_host(vispec_ctx* ctx, void* stream, const float* u, int n_leaf, int max_depth, float u_final) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   if (!u) { ctx->u_over_on = false; return 0; }
   if (n_leaf < 1 || n_leaf > TREE_MAX_T || max_depth < 1 || max_depth > TREE_RET_W) return fail("uniform_override: bad shape");
   std::vector<float> tab(TREE_MAX_T * TREE_RET_W + 1, 2.0f);  // (2 = never accepted)
@@ -2202,7 +2252,7 @@ __global__ void set_stop2_kernel(DevState* st, int tok) {
 }
 // is_llama3: "<|eot_id|>" among the generated ids also ends the request (spec_model_ours.py:268-269, 540-542); after begin_request
 extern "C" int vispec_set_stop_token(vispec_ctx* ctx, void* stream, int token_id) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipLaunchKernelGGL(set_stop2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, token_id);
   KCHK();
   return 0;
@@ -2212,7 +2262,7 @@ __global__ void set_rope_delta_kernel(DevState* st, int delta) {
 }
 // spec_model_ours.py:179-201 changes the tree size after construction (`model.spec_layer.total_tokens = total_token - 1`)
 extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   const vispec_config& c = ctx->c;
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
@@ -2224,7 +2274,7 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   return 0;
 }
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipLaunchKernelGGL(set_rope_delta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->st, delta);
   KCHK();
   return 0;
@@ -2232,7 +2282,7 @@ extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {
 
 // temperature <= 1e-5: greedy (utils.py:438-451); > 1e-5: sampling (utils.py:453-493) with the counter-based uniforms of `seed`.
 extern "C" int vispec_set_sampling(vispec_ctx* ctx, float temperature, unsigned long long seed) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   ctx->temperature = temperature;
   ctx->seed = seed;
   ctx->sample_top_k = 0;
@@ -2262,7 +2312,7 @@ extern "C" int vispec_set_next_token(vispec_ctx* ctx, void* stream, const int* t
 }
 
 extern "C" int vispec_ar_step(vispec_ctx* ctx, void* stream) {
-  if (!ctx || ctx->zombie) return fail("null ctx (or a leader already destroyed: its handle is invalid)");
+  CTX_LIVE(ctx);
   hipStream_t s = (hipStream_t)stream;
   return run_graphed(ctx, s, ctx->g_ar, graph_key(ctx, -1, false), [&]() {
     hipLaunchKernelGGL(tree_single_kernel, dim3(1), dim3(64), 0, s, ctx->tb, ctx->st);
@@ -2295,6 +2345,7 @@ extern "C" int vispec_cohortn_ar_step(vispec_ctx* const* ctxs, int n, void* stre
 
 // ------------------------------------------------------------------------------------------------ read-back
 extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
+  CTX_LIVE(ctx);
   if (!ctx || !out) return fail("null");
   DevState h;
   HIPCHK(hipMemcpyAsync(&h, ctx->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -2306,6 +2357,7 @@ extern "C" int vispec_get_state_host(vispec_ctx* ctx, void* stream, int* out) {
 // The same for every request of a cohort with ONE stream synchronisation (the per-request form costs a blocking round trip each: four per
 // lockstep round): the states travel through each ctx's pinned staging buffer.  out = n x 8 ints, laid out as above.
 extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void* stream, int* out) {
+  if (ctxs && n >= 1 && n <= MAX_COHORT) for (int t_ = 0; t_ < n; ++t_) CTX_LIVE(ctxs[t_]);
   if (!ctxs || !out || n < 1 || n > MAX_COHORT) return fail("cohort_get_state: 1..8 contexts");
   for (int t = 0; t < n; ++t) {
     if (!ctxs[t] || !ctxs[t]->h_pin) return fail("null ctx");
@@ -2324,6 +2376,7 @@ extern "C" int vispec_cohort_get_state_host(vispec_ctx* const* ctxs, int n, void
 // every request's DevState into pinned snapshot slot `slot` (0 / 1) in stream order and records the slot's event — the next round can be
 // launched right behind it; `wait` blocks on that event only (not on the stream, which is already running the next round) and unpacks.
 extern "C" int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void* stream, int slot) {
+  if (ctxs && n >= 1 && n <= MAX_COHORT) for (int t_ = 0; t_ < n; ++t_) CTX_LIVE(ctxs[t_]);
   if (!ctxs || n < 1 || n > MAX_COHORT || slot < 0 || slot > 1) return fail("cohort_state_enqueue: 1..8 contexts, slot 0 or 1");
   for (int t = 0; t < n; ++t) {
     if (!ctxs[t]) return fail("null ctx");
@@ -2336,6 +2389,7 @@ extern "C" int vispec_cohort_state_enqueue(vispec_ctx* const* ctxs, int n, void*
   return 0;
 }
 extern "C" int vispec_cohort_state_wait(vispec_ctx* const* ctxs, int n, int slot, int* out) {
+  if (ctxs && n >= 1 && n <= MAX_COHORT) for (int t_ = 0; t_ < n; ++t_) CTX_LIVE(ctxs[t_]);
   if (!ctxs || !out || n < 1 || n > MAX_COHORT || slot < 0 || slot > 1 || !ctxs[0] || !ctxs[0]->st_ev[slot]) return fail("cohort_state_wait: nothing enqueued in this slot");
   HIPCHK(hipEventSynchronize(ctxs[0]->st_ev[slot]));
   for (int t = 0; t < n; ++t) {
@@ -2348,6 +2402,7 @@ extern "C" int vispec_cohort_state_wait(vispec_ctx* const* ctxs, int n, int slot
   return 0;
 }
 extern "C" int vispec_get_last_accept_host(vispec_ctx* ctx, void* stream, int* out2) {
+  CTX_LIVE(ctx);
   if (!ctx || !out2) return fail("null");
   DevState h;
   HIPCHK(hipMemcpyAsync(&h, ctx->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -2357,12 +2412,14 @@ extern "C" int vispec_get_last_accept_host(vispec_ctx* ctx, void* stream, int* o
   return 0;
 }
 extern "C" int vispec_get_tokens_host(vispec_ctx* ctx, void* stream, int* out, int n) {
+  CTX_LIVE(ctx);
   if (!ctx || !out || n < 0 || n > ctx->tokens_cap) return fail("bad args");
   HIPCHK(hipMemcpyAsync(out, ctx->tokens, sizeof(int) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 extern "C" int vispec_get_accept_log_host(vispec_ctx* ctx, void* stream, int* out, int n) {
+  CTX_LIVE(ctx);
   if (!ctx || !out || n < 0 || n > ctx->log_cap) return fail("bad args");
   HIPCHK(hipMemcpyAsync(out, ctx->accept_log, sizeof(int) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -2370,6 +2427,7 @@ extern "C" int vispec_get_accept_log_host(vispec_ctx* ctx, void* stream, int* ou
 }
 extern "C" int vispec_get_tree_host(vispec_ctx* ctx, void* stream, int* tokens_T, int* pos_T, uint64_t* mask_T, int* retrieve,
                                     int* n_leaf, int* max_depth) {
+  CTX_LIVE(ctx);
   if (!ctx) return fail("null");
   hipStream_t s = (hipStream_t)stream;
   DevState h;
@@ -2385,7 +2443,7 @@ extern "C" int vispec_get_tree_host(vispec_ctx* ctx, void* stream, int* tokens_T
 }
 
 extern "C" void* vispec_buffer(vispec_ctx* ctx, const char* name) {
-  if (!ctx || !name) return nullptr;
+  if (!ctx || ctx->zombie || !name) return nullptr;
   struct E { const char* n; void* p; };
   const E tab[] = {{"state", ctx->st}, {"tokens", ctx->tokens}, {"hidden_new", ctx->hidden_new}, {"logits", ctx->logits},
                    {"am", ctx->am}, {"sel", ctx->sel}, {"draft_ids", ctx->draft_ids}, {"accept_hidden", ctx->accept_hidden},

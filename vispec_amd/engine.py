@@ -468,12 +468,12 @@ class Engine:
 
     def prof_report(self) -> Dict[str, Dict[str, float]]:
         n = 16
-        out = (C.c_double * (3 * n))()
+        out = (C.c_double * (4 * n))()
         L.check(self.lib.vispec_prof_report_host(self.h, self._stream(), out, n))
         rep = {}
         for i, name in enumerate(self.PROF_KINDS):
-            if out[3 * i] > 0:
-                rep[name] = dict(launches=out[3 * i], ms=out[3 * i + 1], bytes=out[3 * i + 2])
+            if out[4 * i] > 0:
+                rep[name] = dict(launches=out[4 * i], ms=out[4 * i + 1], bytes=out[4 * i + 2], workgroups=out[4 * i + 3])
         return rep
 
     # -- blocking read-backs ---------------------------------------------------------------------------

@@ -439,9 +439,14 @@ class SpecModel:
 def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=2048, stats=None):
     """The AR baseline (gen_baseline_answer_coco_caption.py:34-133) for two to eight requests in LOCKSTEP on one weight pass: what
     specgenerate_cohort is to specgenerate.  models / requests as there; max_new_tokens may be a list.  Returns one [1, L + new] id tensor
-    per request — the tokens `m.baseline_generate(ids, ...)` returns for that request alone (every row keeps the single-request
-    arithmetic; a request that reaches EOS or its budget freezes on the device while the others go on).  The speed-up bench.py prints
-    divides a cohort's speculative tokens/s by THIS rate: like by like (speed.py:56-97)."""
+    per request — for cohorts of up to four the tokens `m.baseline_generate(ids, ...)` returns for that request alone (a request that
+    reaches EOS or its budget freezes on the device while the others go on).  The speed-up bench.py prints divides a cohort's
+    speculative tokens/s by THIS rate: like by like (speed.py:56-97).
+    Arithmetic class (round 5): cohorts of up to FOUR requests keep every row bit-identical to a run of that request alone; cohorts of
+    FIVE to EIGHT run the cohort-8 GEMM (csrc/gemm_c8.h: one fp32 accumulator chain per element) and 768-key attention splits — a request's
+    tokens then do not depend on WHAT shares its weight pass (any cohort of 5..8, any tile), but they are the tokens of the c8 summation
+    order, which may leave the solo run's at a near tie of the logits.  The class follows len(models) of the call: a deployment that wants
+    one class for every request always calls with its full slot count."""
     n = len(models)
     if not 2 <= n <= 8 or len(requests) != n:
         raise ValueError("a cohort is 2..8 models (leader, members...) and one request per model")
@@ -475,10 +480,15 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
 
     models   = [leader, member, ...]  (members built with cohort_leader=leader: one vispec_ctx, KV cache, tree and round state each)
     requests = [(input_ids [1,L], specgenerate kwargs), ...] one per model; max_new_tokens may be a list (one budget per request)
-    Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — exactly what
+    Returns one (input_ids [1, L+new], new_token, idx, acceptance_len) tuple per request — for cohorts of up to four exactly what
     `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` returns for that request alone, token for token: the prefills run
     per request, every decode round launches each GEMM once on all requests' rows (Engine.cohort_round), and a request that finishes
-    first is frozen on the device while the others complete.  `stats` (a dict, optional) receives the wall time of the round loop
+    first is frozen on the device while the others complete.
+    Arithmetic class (round 5): cohorts of up to FOUR requests keep every row bit-identical to a run of that request alone; cohorts of
+    FIVE to EIGHT run the cohort-8 GEMM (csrc/gemm_c8.h: one fp32 accumulator chain per element) and 768-key attention splits — a request's
+    tokens then do not depend on WHAT shares its weight pass (any cohort of 5..8, any tile), but they are the tokens of the c8 summation
+    order, which may leave the solo run's at a near tie of the logits.  The class follows len(models) of the call: a deployment that wants
+    one class for every request always calls with its full slot count.  `stats` (a dict, optional) receives the wall time of the round loop
     (`decode_s`, bracketed by synchronisations like specgenerate's return_decode_time) and the number of lockstep rounds (`rounds`)."""
     n = len(models)
     if not 2 <= n <= 8 or len(requests) != n:
@@ -537,8 +547,11 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
     token budget, a full KV cache) its slot takes the next request of the queue — prefill, first token and draft prefill of that request
     on the same stream, then it simply joins the following rounds (the other slots' state is device-resident and waits).  A cohort run
     request by request (specgenerate_cohort) executes max(rounds of its requests) lockstep rounds; the stream executes ≈ mean(rounds).
-    Every request keeps the reference's batch-1 semantics: it returns exactly the (input_ids, new_token, idx, acceptance_len) tuple of
-    `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` run alone (spec_model_ours.py:247-582), in request order.
+    Every request keeps the reference's batch-1 semantics: with up to four slots it returns exactly the (input_ids, new_token, idx,
+    acceptance_len) tuple of `m.specgenerate(ids, log=True, return_acceptance_len=True, ...)` run alone (spec_model_ours.py:247-582), in
+    request order; with five to eight slots the tuple of the c8 arithmetic class (see specgenerate_cohort) — independent of what shares the
+    slots.  When len(requests) <= len(models) the call falls back to plain cohorts of len(group) requests, so the class then follows the
+    number of requests that arrive together (4 or fewer: solo arithmetic; 5 or more: c8).
     `stats` (dict, optional): `rounds` = lockstep rounds executed, `request_rounds` = rounds summed over the requests."""
     n, R = len(models), len(requests)
     seeds = list(seeds) if seeds is not None else [0] * R

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import json
 import os
+import threading
 from types import SimpleNamespace
 from typing import Optional
 
@@ -45,6 +46,28 @@ def _strip(key, prefixes):
     return None
 
 
+_tables_lock = threading.Lock()  # the per-grid tables below are shared by every lane thread / HIP stream of a process
+
+
+def _window_groups(cu_seqlens, dev):
+    """Chunk table of _qwen_vision_attention_batched for one `cu_seqlens` tensor: per chunk length, the [chunks, length] gather indices.
+    Built under the lock and PUBLISHED (as an attribute of the tensor object, which a cached grid entry keeps alive across requests) only after
+    the building stream has finished — another lane's stream may gather through it right away, and no stream dependency links the lanes."""
+    with _tables_lock:
+        groups = getattr(cu_seqlens, "_vispec_groups", None)
+        if groups is None:
+            bounds = cu_seqlens.tolist()
+            by_len = {}
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                if hi > lo:
+                    by_len.setdefault(hi - lo, []).append(lo)
+            groups = [(torch.tensor(starts, device=dev)[:, None] + torch.arange(n, device=dev)[None, :]) for n, starts in sorted(by_len.items())]
+            if groups and groups[0].is_cuda:
+                torch.cuda.current_stream(dev).synchronize()
+            cu_seqlens._vispec_groups = groups
+    return groups
+
+
 def _qwen_vision_attention_batched(self, hidden_states, cu_seqlens, position_embeddings=None, **kwargs):
     """Drop-in for transformers' Qwen2_5_VLVisionAttention.forward on its non-flash path.  HF splits the sequence at `cu_seqlens` and calls the
     attention once per chunk in a Python loop, after a `.tolist()` of a device tensor — for one 1280x960 image that is ~110 windows x 28 windowed
@@ -59,14 +82,7 @@ def _qwen_vision_attention_batched(self, hidden_states, cu_seqlens, position_emb
     q, k = apply_rotary_pos_emb_vision(q, k, cos, sin)
     groups = getattr(cu_seqlens, "_vispec_groups", None)
     if groups is None:
-        bounds = cu_seqlens.tolist()
-        by_len = {}
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            if hi > lo:
-                by_len.setdefault(hi - lo, []).append(lo)
-        dev = hidden_states.device
-        groups = [(torch.tensor(starts, device=dev)[:, None] + torch.arange(n, device=dev)[None, :]) for n, starts in sorted(by_len.items())]
-        cu_seqlens._vispec_groups = groups  # (a plain attribute on the tensor object: it lives as long as this forward's cu_seqlens does)
+        groups = _window_groups(cu_seqlens, hidden_states.device)
     out = torch.empty_like(q)
     for idx in groups:  # idx [chunks of this length, length]
         o = torch.nn.functional.scaled_dot_product_attention(q[idx].transpose(1, 2), k[idx].transpose(1, 2), v[idx].transpose(1, 2), scale=self.scaling)
@@ -83,13 +99,17 @@ class HFVisionFrontEnd:
     def __init__(self, arch: str, config, tower: nn.Module, projector: Optional[nn.Module], image_newline: Optional[torch.Tensor],
                  batched_windows: bool = True):
         self.arch, self.config, self.tower, self.projector, self.image_newline = arch, config, tower, projector, image_newline
-        self._batched_windows, self._grid_tables = bool(batched_windows), {}
+        self._batched_windows, self._grid_tables = False, {}
         if arch == "Qwen2_5_VLForConditionalGeneration" and batched_windows:
             import types
             vc = getattr(config, "vision_config", None)
             if getattr(vc, "_attn_implementation", "sdpa") in ("sdpa", "eager", None):  # (flash_attention_2 takes HF's own varlen call)
                 for blk in getattr(tower, "blocks", []):
                     blk.attn.forward = types.MethodType(_qwen_vision_attention_batched, blk.attn)
+                # the cached tables are handed to the forward as keyword arguments ONLY next to the patched attention: HF passes unknown
+                # kwargs through every block into its attention interface, where the flash wrapper reads a stray `position_ids` as a
+                # packed-sequence hint
+                self._batched_windows = True
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
@@ -139,18 +159,31 @@ class HFVisionFrontEnd:
         key = tuple(tuple(int(v) for v in row) for row in (grid_thw.tolist() if torch.is_tensor(grid_thw) else grid_thw))
         hit = self._grid_tables.get((key, str(device)))
         if hit is None:
-            from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
-            t = self.tower
-            g = torch.as_tensor(key, device=device)
-            try:
-                window_index, cu_window = M.get_vision_window_index(g, spatial_merge_size=t.spatial_merge_size, window_size=t.window_size, patch_size=t.patch_size)
-                cu, _ = M.get_vision_attention_seqlens(g, t.config)
-                hit = dict(position_ids=M.get_vision_position_ids(g, t.spatial_merge_size), window_index=window_index, cu_window_seqlens=cu_window, cu_seqlens=cu)
-            except (AttributeError, TypeError):  # another transformers layout: the tower computes its tables itself
-                hit = {}
-            if len(self._grid_tables) > 64:
-                self._grid_tables.clear()
-            self._grid_tables[(key, str(device))] = hit
+            # Built under the lock and published only when the building stream has finished: every lane thread (own HIP stream, no dependency
+            # on the builder's) reads the entry the moment it is in the dict.  The chunk tables of the two boundary tensors are built here as
+            # well, so that no consumer ever runs `.tolist()` on a tensor another stream is still writing.
+            with _tables_lock:
+                hit = self._grid_tables.get((key, str(device)))
+                if hit is None:
+                    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
+                    t = self.tower
+                    g = torch.as_tensor(key, device=device)
+                    try:
+                        window_index, cu_window = M.get_vision_window_index(g, spatial_merge_size=t.spatial_merge_size, window_size=t.window_size,
+                                                                            patch_size=t.patch_size)
+                        cu, _ = M.get_vision_attention_seqlens(g, t.config)
+                        hit = dict(position_ids=M.get_vision_position_ids(g, t.spatial_merge_size), window_index=window_index, cu_window_seqlens=cu_window,
+                                   cu_seqlens=cu)
+                    except (AttributeError, TypeError):  # another transformers layout: the tower computes its tables itself
+                        hit = {}
+                    if torch.device(device).type == "cuda":
+                        torch.cuda.current_stream(device).synchronize()
+                    if len(self._grid_tables) > 64:
+                        self._grid_tables.clear()
+                    self._grid_tables[(key, str(device))] = hit
+            for name in ("cu_window_seqlens", "cu_seqlens"):  # (takes the lock itself; after the entry's tensors are complete)
+                if torch.is_tensor(hit.get(name)):
+                    _window_groups(hit[name], device)
         return dict(hit)
 
     @torch.no_grad()
