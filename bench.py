@@ -43,11 +43,15 @@ MAX_NEW = 512
 # Acceptance is measured on a synthetic successor pair whose draft disagrees with the target on a fraction rho of the vocabulary.
 # rho is chosen per model so that the measured mean accept length lands near the reference's published one (README.md:186-195 of
 # the reference, T=0 averages): tau = p + p^2 + p^3 + p^4 with p ~ 1 - 0.91 rho at depth 3.
-TAU_PUBLISHED = {"llava7b": 2.98, "llava13b": 2.89, "qwen7b": 2.24, "qwen7b-hires": 2.24, "qwen7b-fp8": 2.24, "qwen7b-fp8a8": 2.24}
-RHO = {"llava7b": 0.115, "llava13b": 0.125, "qwen7b": 0.24, "qwen7b-hires": 0.24, "qwen7b-fp8": 0.24, "qwen7b-fp8a8": 0.24}
+TAU_PUBLISHED = {"tiny": 2.98, "llava7b": 2.98, "llava13b": 2.89, "qwen7b": 2.24, "qwen7b-hires": 2.24, "qwen7b-fp8": 2.24, "qwen7b-fp8a8": 2.24}
+RHO = {"tiny": 0.115, "llava7b": 0.115, "llava13b": 0.125, "qwen7b": 0.24, "qwen7b-hires": 0.24, "qwen7b-fp8": 0.24, "qwen7b-fp8a8": 0.24}
 TREE = dict(total_token=30, depth=3, top_k=8, num_q=2)
 # --model selects the BASELINE.json config; the default (configs[1]) is the headline line, the others are extra coverage runs
 MODELS = {
+    # TEST-ONLY (tests/test_world8_gpu.py: eight ranks of the N > 1 control flow on ONE GPU): a LLaVA-shaped target an eighth of the width, four
+    # layers — the same request shape, launch sequence and kernels (head_dim 128), 0.3 GB of weights per rank.  Never a bench line.
+    "tiny": dict(name="LLaVA-shaped TEST model (hidden 1024, 4 layers; control-flow tests only)",
+                 desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
     "llava7b": dict(name="LLaVA-v1.6-vicuna-7B", desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
     "llava13b": dict(name="LLaVA-v1.6-vicuna-13B", desc="1 image (2144 image tokens) + 512 text + 48 template tokens per request (L=2704)"),
     "qwen7b": dict(name="Qwen2.5-VL-7B-Instruct", desc="4 images of 32x32 patches (256 merged tokens each) in a multi-turn prompt + 512 text tokens (L=1584)"),
@@ -96,17 +100,13 @@ REFILL = True  # --no-refill: cohort by cohort
 WIDE_RB = -1  # --wide-row-blocks: -1 = automatic (one lane: 0 = two row blocks where four cannot fill the GPU; several lanes: 84 = eight for bf16 weights and for W8A8, four for fp8 weights with bf16 activations)
 
 
-def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
-    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2..4 every lane
-    also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then.
-    structured=False (tests/test_unstructured_gpu.py only): plain random matrices, flat logits — never the bench workload."""
-    from vispec_amd import parallel, synth_gpu
-    from vispec_amd.engine import LLAVA_16_7B, DraftConfig, TargetConfig
-    from vispec_amd.model import SpecModel
-    from vispec_amd.model.cnets_ours import Model
-    from vispec_amd.model.target import TargetLM
-    from vispec_amd.engine import LLAVA_16_13B, QWEN25_VL_7B
-    if MODEL == "llava13b":
+def model_configs():
+    """-> (TargetConfig, DraftConfig) of bench.MODEL at the published sizes."""
+    from vispec_amd.engine import LLAVA_16_7B, LLAVA_16_13B, QWEN25_VL_7B, DraftConfig, TargetConfig
+    if MODEL == "tiny":
+        tcfg = TargetConfig(hidden_size=1024, num_heads=8, num_kv_heads=8, intermediate_size=2816, vocab_size=32064, num_layers=4, max_position_embeddings=4096)
+        dcfg = DraftConfig(hidden_size=1024, num_heads=8, intermediate_size=2816, vocab_size=32064, max_position_embeddings=4096)
+    elif MODEL == "llava13b":
         tcfg = TargetConfig(**LLAVA_16_13B)
         dcfg = DraftConfig(hidden_size=5120, num_heads=40, intermediate_size=13824, vocab_size=32064, max_position_embeddings=4096)
     elif MODEL.startswith("qwen7b"):
@@ -116,6 +116,27 @@ def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
     else:
         tcfg = TargetConfig(**LLAVA_16_7B)
         dcfg = DraftConfig(hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32064, max_position_embeddings=4096)
+    return tcfg, dcfg
+
+
+def synth_pair(device, seed, structured=True):
+    """The synthetic weight pair of bench.MODEL on the device -> (tcfg, dcfg, TargetWeights, DraftWeightsDev) (also tests/ckpt_writer.py)."""
+    from vispec_amd import synth_gpu
+    tcfg, dcfg = model_configs()
+    tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=structured, num_q=TREE["num_q"], rho=RHO[MODEL],
+                                 succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
+    return tcfg, dcfg, tw, dw
+
+
+def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
+    """`lanes` SpecModels (one vispec_ctx + KV cache + stream each) sharing ONE copy of the weights on this GPU; with cohort = 2..4 every lane
+    also gets cohort members (further request contexts on the same weight pass): returns [leader, member, ...] lists then.
+    structured=False (tests/test_unstructured_gpu.py only): plain random matrices, flat logits — never the bench workload."""
+    from vispec_amd import parallel
+    from vispec_amd.model import SpecModel
+    from vispec_amd.model.cnets_ours import Model
+    from vispec_amd.model.target import TargetLM
+    tcfg, dcfg = model_configs()
     real = REAL_WEIGHTS is not None
     if real:  # every rank reads the checkpoint itself (no collective needed); the lanes share that one copy
         first = SpecModel.from_pretrained(base_model_path=REAL_WEIGHTS[0], spec_model_path=REAL_WEIGHTS[1], device=str(device), **TREE)
@@ -124,8 +145,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
         first.engine.close()
         del first
     else:  # rank 0 creates the weights; the others allocate same-shaped buffers (different seed) and receive rank 0's over RCCL
-        tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed if rank == 0 else seed + 1000 + rank, structured=structured, num_q=TREE["num_q"],
-                                     rho=RHO[MODEL], succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
+        _, _, tw, dw = synth_pair(device, seed if rank == 0 else seed + 1000 + rank, structured)
     t_rep = 0.0
     if world > 1 and not real:
         import torch.distributed as dist
@@ -143,8 +163,7 @@ def build_models(device, seed, rank, world, lanes, cohort=1, structured=True):
         if not same:
             del tw, dw
             torch.cuda.empty_cache()
-            tw, dw = synth_gpu.make_pair(tcfg, dcfg, device, seed=seed, structured=structured, num_q=TREE["num_q"], rho=RHO[MODEL],
-                                         succ_hi=min(tcfg.vocab_size, 151640 if MODEL.startswith("qwen") else 32000))
+            _, _, tw, dw = synth_pair(device, seed, structured)
         log(f"[rank {rank}] replicated {nbytes / 1e9:.2f} GB of weights over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
             f"in {t_rep:.2f} s, checksums {'equal' if same else 'differ: weights regenerated locally'}")
     sms = []
@@ -428,6 +447,8 @@ def main():
     ap.add_argument("--no-vision-in-loop", action="store_true",
                     help="start every request from its projected image features (rounds 1-4) instead of running the HF vision front-end inside the timed "
                          "specgenerate call")
+    ap.add_argument("--xcd-partition", action="store_true",
+                    help="experiment: lane l's stream is created with a CU mask of its share of the eight XCDs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -503,7 +524,11 @@ def main():
     sm = sms[0]
     eng = sm.engine
     K, W = args.steps, args.warmup
-    streams = [torch.cuda.Stream(device) for _ in range(R)]
+    if args.xcd_partition and R >= 2:  # every lane on its own share of the XCDs: its activation blocks stay in ITS L2s (tools/cu_mask_probe.py)
+        from vispec_amd.evaluation.bench_launch import masked_stream
+        streams = [masked_stream(device, lane, R) for lane in range(R)]
+    else:
+        streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
     from vispec_amd.model.spec_model_ours import baseline_generate_cohort, specgenerate_cohort, specgenerate_stream
     plan, scaling = request_plan(args.requests, rank, world, R, CO, W + K)

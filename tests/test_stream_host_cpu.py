@@ -57,6 +57,7 @@ class FakeStream:
 class FakeEngine:
     def __init__(self, stream, t, leader=None):
         self.s, self.t, self.leader, self.device = stream, t, leader, torch.device("cpu")
+        self.total_token = 30
 
     def cohort_round(self, members, forced_accept=-1):
         self.s.ops.append(("round",))

@@ -32,10 +32,10 @@ from vispec_amd.evaluation.bench_launch import run_lanes  # noqa: E402
 from vispec_amd.evaluation.bench_vision import InLoopFrontEnd, build_front_end  # noqa: E402
 from vispec_amd.model.spec_model_ours import specgenerate_stream  # noqa: E402
 
-KID = {**{40 + e: f"skinny<{e}>" for e in range(5)}, **{48 + e: f"slab<{e}>" for e in range(5)}, 60: "splitk reduce(+norm)", 70: "batched small kernels",
+KID = {**{40 + e: f"skinny<{e}>" for e in range(5)}, **{48 + e: f"slab<{e}>" for e in range(5)},
        10: "c8<0> none", 11: "c8<1> residual", 12: "c8<2> gate|up", 13: "c8<3> split-K partial", 14: "c8<4> q|k|v", 20: "attn partial (eager)",
        21: "attn partial", 22: "attn reduce", 30: "prefill attention"}
-CU_SHARE = {**{40 + e: 0.25 for e in range(5)}, **{48 + e: 0.25 for e in range(5)}, 60: 0.25, 70: 0.25,  # (assumed: 256-thread workgroups, <= 4 per CU)
+CU_SHARE = {**{40 + e: 0.25 for e in range(5)}, **{48 + e: 0.25 for e in range(5)},  # (assumed: 256-thread workgroups, <= 4 per CU)
             10: 1.0, 11: 1.0, 12: 1.0, 13: 1.0, 14: 1.0, 20: 0.5, 21: 0.5, 22: 0.125, 30: 0.5}
 REC = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("kid", "<u4"), ("tag", "<u4"), ("blk", "<u4"), ("nblk", "<u4"), ("hw", "<u4"), ("xcc", "<u4"),
                 ("p0", "<u4"), ("p1", "<u4")])

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vispec_hip.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.h"), os.path.join(HERE, "csrc", "tree_kernels.h"), os.path.join(HERE, "csrc", "gemm_wide.h"), os.path.join(HERE, "csrc", "gemm_c8.h"),
-        os.path.join(HERE, "csrc", "gemm_prefill.h"),
+        os.path.join(HERE, "csrc", "gemm_prefill.h"), os.path.join(HERE, "csrc", "wgclock.h"),
         os.path.join(os.path.dirname(HERE), "include", "vispec_hip.h")]
 OUT = os.path.join(HERE, "libvispec_hip.so")
 

@@ -73,6 +73,8 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[NL], int tile, int s
     if (j >= m_tile || mt >= n_live) continue;  // (n_live < NL: the cohort-8 kernel always computes eight tiles)
     const int m = 32 * mt + j;
     if (EPI == EPI_ROPE) {
+      if (re.rows[mt] && j >= re.rows[mt]) continue;  // (second tile of a 33..64-node tree: rows past the tree; 255 -> 0 live rows below)
+      if (re.rows[mt] == 255) continue;
       const PosSpec& ps_ = re.ps[mt];
       const int kvrow = (ps_.kv_base ? *ps_.kv_base : 0) + ps_.kv_add + j;
 #pragma unroll

@@ -64,7 +64,6 @@ __device__ __forceinline__ void pack_apply(F f, const ArgPack<T, Ts...>& p, Us..
 template <class P> struct Packs4 { P p[MAX_COHORT]; };  // (the name is round 2's: up to MAX_COHORT packs)
 template <class Fn, int TPB, class P>
 __global__ __launch_bounds__(TPB) void batch4_kernel(Packs4<P> a) {
-  WGCLK_SCOPE(70, nullptr);
   const int z = blockIdx.z;  // (selected with compares: a dynamically indexed kernel argument would be copied to scratch; ONE call
   P p = a.p[0];              //  site: a body's static __shared__ arrays must not be instantiated once per request)
   if (z == 1) p = a.p[1];
@@ -152,6 +151,9 @@ struct RopeEpi {
   bf16_t* kc[MAX_COHORT] = {};
   bf16_t* vc[MAX_COHORT] = {};
   int s_max = 0, H = 0, H_kv = 0;
+  // live rows of activation tile mt when they differ from the launch's m_tile (0 = m_tile): a request whose tree has 33..64 nodes owns TWO
+  // tiles of a cohort launch (round 6) — 32 live rows in the first, T - 32 in the second; rows past them must not reach the KV cache
+  unsigned char rows[MAX_COHORT] = {};
 };
 
 __global__ __launch_bounds__(64) void pack_w32_kernel(const bf16_t* __restrict__ W, int N, int K, bf16_t* __restrict__ P) {
@@ -723,7 +725,6 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   // clamped (always valid) slab indices, residual, bias, norm weight — is issued before the first use, and a row that fits one
   // pass of the block (N <= 4 x threads: every model here) keeps its values in registers across the block-wide sum of squares.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-  WGCLK_SCOPE(60, Y);
   float* hrow = reinterpret_cast<float*>(smem_r);  // [N] values of h (bf16-representable): only for rows longer than one pass
   __shared__ float partsum[16];
   const int m = blockIdx.x;

@@ -150,18 +150,33 @@ extern "C" const char* vispec_last_error(void) { return g_err.c_str(); }
 extern "C" int vispec_version(void) { return 1; }
 
 #define ROWS (32 * MAX_COHORT)  /* rows of the activation workspaces: eight 32-row tiles (a cohort of up to eight requests shares one weight pass) */
+// A member's TARGET-side activation views (what the verify forward of a cohort round touches): tile `slot` of its leader's workspaces for trees
+// of up to 32 nodes (32 rows per request), tiles 2 slot and 2 slot + 1 for trees of 33..64 nodes (64 rows per request; slots 0..3) — so that
+// `total_token = -1` autotuning (spec_model_ours.py:179-201: 40..60 nodes) and cohorts compose.  The DRAFT-side views (<= 16 live rows per
+// request) always stay at 32 rows per slot.  Called at creation and whenever the tree size changes (vispec_set_total_token).
+static void retarget_views(vispec_ctx* ctx) {
+  vispec_ctx* ld = ctx->leader;
+  if (!ld) return;
+  const vispec_config& c = ctx->c;
+  const size_t rows = (size_t)(c.total_token > 32 ? 64 : 32) * ctx->slot;
+  const size_t D = c.hidden_size, QKV = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
+  ctx->xa = ld->xa + rows * D; ctx->xn = ld->xn + rows * D; ctx->qkv = ld->qkv + rows * QKV;
+  ctx->attn_o = ld->attn_o + rows * (size_t)c.num_heads * c.head_dim; ctx->act = ld->act + rows * (size_t)c.intermediate_size;
+  ctx->hidden_new = ld->hidden_new + rows * D; ctx->logits = ld->logits + rows * (size_t)c.vocab_size; ctx->am = ld->am + rows;
+}
 #define CHUNK 32  /* rows per skinny-GEMM pass when a prefill stage walks a long sequence */
 static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out) {
   if (!cfg || !out) return fail("null argument");
   if (leader && leader->zombie) return fail("ctx_create_member: the leader was destroyed");
   if (leader && (leader->leader || memcmp(&leader->c, cfg, sizeof(vispec_config)) != 0))
     return fail("ctx_create_member: the leader must be an ordinary ctx created with the same config");
-  if (leader && cfg->total_token > 32) return fail("ctx_create_member: a cohort member owns one 32-row activation tile: total_token <= 32");
-  if (leader && leader->c.total_token > 32) return fail("ctx_create_member: the leader's tree must fit one 32-row activation tile (total_token <= 32)");
   int slot = 0;
   if (leader) {
     for (slot = 1; slot < MAX_COHORT && leader->members[slot - 1]; ++slot) {}
     if (slot >= MAX_COHORT) return fail("ctx_create_member: the leader already has seven members (a cohort is at most eight requests)");
+    // trees of 33..64 nodes (autotune_total_token): a request then owns TWO activation tiles of the target-side workspaces (retarget_views),
+    // which the first four request slots have
+    if (cfg->total_token > 32 && slot > 3) return fail("ctx_create_member: trees of more than 32 nodes take two activation tiles per request: at most four requests per cohort");
   }
   const vispec_config& c = *cfg;
   if (c.head_dim != 128) return fail("head_dim must be 128 (attention tiles are written for 128)");
@@ -255,6 +270,7 @@ static int ctx_create_impl(const vispec_config* cfg, vispec_ctx* leader, vispec_
   }
 #undef A
 #undef AL
+  retarget_views(ctx);
   ctx->n_hint = c.max_pos;
   const int lds = ATT2_LDS_BYTES;
   if (hipFuncSetAttribute((const void*)tree_attn2_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -909,25 +925,44 @@ struct QkvReq {  // per-request part of a q|k|v projection: positions and the ca
 // streamed once for all of them.
 static int launch_qkv_rope(vispec_ctx* ctx, hipStream_t s, const void* X, int ldx, const void* P, const void* bias, const void* wscale,
                            void* qkv, int M, int H, int H_kv, int K, const void* cosT, const void* sinT, const QkvReq* rq, int n_req,
-                           int s_max, bool slab = false, const float* xscale = nullptr /* X = e4m3 codes, ldx in 2-byte units */) {
+                           int s_max, bool slab = false, const float* xscale = nullptr /* X = e4m3 codes, ldx in 2-byte units */,
+                           bool two_tiles = false /* cohort of 33..64-row requests: request t owns rows 64t .. 64t + M - 1 (tiles 2t, 2t + 1) */) {
   const int N = (H + 2 * H_kv) * 128;
+  two_tiles = two_tiles && n_req >= 2;
+  if (two_tiles && (M < 1 || M > 64 || n_req > 4 || slab)) return fail("gemm_qkv_rope: two tiles per request: 2..4 requests of 1..64 rows");
   slab = slab && n_req >= 2 && M <= 8;  // slab: the requests' rows packed into one activation tile (request t still at rows 32t .. of X / qkv)
-  const int m_tile = slab ? -M : (n_req >= 2 ? M : 0), Mk = slab ? 8 * (n_req - 1) + M : (n_req >= 2 ? 32 * (n_req - 1) + M : M);
+  const int n_tiles2 = M > 32 ? 2 * n_req : 2 * n_req - 1;  // (two_tiles, M <= 32: the last request's second tile is not part of the launch)
+  const int m_tile = slab ? -M : (two_tiles ? std::min(M, 32) : (n_req >= 2 ? M : 0));
+  const int Mk = slab ? 8 * (n_req - 1) + M : (two_tiles ? 32 * (n_tiles2 - 1) + std::min(M, 32) : (n_req >= 2 ? 32 * (n_req - 1) + M : M));
   if (!qkv_rope_fused(N)) {
     GemmOut o0;
     o0.wscale = (const float*)wscale; o0.xscale = xscale; o0.m_tile = m_tile; o0.Y = qkv; o0.ldy = N;
     if (launch_gemm_ex(ctx, s, X, ldx, P, bias, Mk, N, K, EPI_NONE, o0)) return -1;
     for (int t = 0; t < n_req; ++t)
-      if (launch_rope(s, (bf16_t*)qkv + (size_t)32 * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
+      if (launch_rope(s, (bf16_t*)qkv + (size_t)(two_tiles ? 64 : 32) * t * N, M, H, H_kv, cosT, sinT, rq[t].ps, rq[t].kc, rq[t].vc, s_max, 1)) return -1;
     return 0;
   }
-  if (M < 1 || Mk > ROWS || (n_req == 1 && M > 64) || (n_req > 1 && M > 32)) return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32])");
+  if (M < 1 || Mk > ROWS || (n_req == 1 && M > 64) || (n_req > 1 && !two_tiles && M > 32))
+    return fail("gemm_qkv_rope: M must be in [1,64] (cohort: [1,32], or 33..64 as two tiles per request)");
 
   if (K % 16 || (wscale && K % 32)) return fail("gemm_qkv_rope: K %% 16 (fp8: 32) == 0 required");
   RopeEpi re;
   re.cosT = (const bf16_t*)cosT; re.sinT = (const bf16_t*)sinT;
-  for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   re.s_max = s_max; re.H = H; re.H_kv = H_kv;
+  if (two_tiles) {  // tile 2t = rows 0..31 of request t, tile 2t + 1 = its rows 32 .. M-1: positions and cache rows continue at +32
+    for (int t = 0; t < n_req; ++t)
+      for (int h2 = 0; h2 < 2; ++h2) {
+        PosSpec ps = rq[t].ps;
+        if (h2) { if (ps.off) ps.off += 32; else if (ps.row) ps.add += 32; ps.kv_add += 32; }
+        re.ps[2 * t + h2] = ps; re.kc[2 * t + h2] = (bf16_t*)rq[t].kc; re.vc[2 * t + h2] = (bf16_t*)rq[t].vc;
+        re.rows[2 * t + h2] = (unsigned char)(h2 ? (M > 32 ? M - 32 : 255 /* dead tile */) : std::min(M, 32));
+      }
+    GemmOut o;
+    o.wscale = (const float*)wscale; o.xscale = xscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
+    if (n_tiles2 > 4) return launch_gemm_c8(ctx, s, X, ldx, P, bias, n_tiles2, N, K, EPI_ROPE, o, -1, &re);
+    return launch_gemm_wide(ctx, s, X, ldx, P, bias, n_tiles2, N, K, EPI_ROPE, o, -1, &re);
+  }
+  for (int t = 0; t < n_req; ++t) { re.ps[t] = rq[t].ps; re.kc[t] = (bf16_t*)rq[t].kc; re.vc[t] = (bf16_t*)rq[t].vc; }
   if (n_req > 2 && !slab) {  // three or four requests: the wide-cohort kernel; five to eight: the cohort-8 kernel
     GemmOut o;
     o.wscale = (const float*)wscale; o.xscale = xscale; o.m_tile = m_tile; o.Y = qkv; o.ldy = N;
@@ -1625,14 +1660,24 @@ static const bool g_draft_slab = !(getenv("VISPEC_DRAFT_SLAB") && atoi(getenv("V
 struct Cohort {
   int n;
   vispec_ctx* c[MAX_COHORT];
+  int stride = 32;  // target-side activation rows per request: 32, or 64 for trees of 33..64 nodes (two tiles per request, n <= 4; retarget_views)
   vispec_ctx* lead() const { return c[0]; }
-  int mt(int rows) const { return n >= 2 ? rows : 0; }                    // m_tile argument
-  int M(int rows) const { return n >= 2 ? 32 * (n - 1) + rows : rows; }  // M argument of a shared GEMM
+  // TARGET-side GEMMs (rows = the tree size T).  stride 64: every request spans two full tiles — 2 n tiles of 32 "live" rows; rows T .. 63 of
+  // a request are computed on whatever its spare rows hold and land in its own spare rows (the q|k|v epilogue, which writes the KV cache, takes
+  // the exact row counts: RopeEpi::rows)
+  // (rows <= 32 at stride 64 — the AR step's single row: request t's rows sit in tile 2t, the odd tiles ride along dead)
+  int mt(int rows) const { return n >= 2 ? (stride == 64 && rows > 32 ? 32 : rows) : 0; }  // m_tile argument
+  int M(int rows) const {                                                                   // M argument of a shared GEMM
+    if (n < 2) return rows;
+    if (stride == 64) return rows > 32 ? 64 * n : 32 * (2 * n - 2) + rows;
+    return 32 * (n - 1) + rows;
+  }
   // The draft's GEMMs see at most top_k / depth + 2 / 1 live rows per request: with <= 8 of them the requests share ONE activation tile
   // (slab mode: GemmOut::m_tile < 0) and the weight pass costs what a single request's costs instead of the 128-row wide form.
   bool slab(int rows) const { return n >= 2 && rows <= 8 && g_draft_slab; }
-  int dmt(int rows) const { return slab(rows) ? -rows : mt(rows); }
-  int dM(int rows) const { return slab(rows) ? 8 * (n - 1) + rows : M(rows); }
+  // (the draft-side views stay at 32 rows per request whatever the tree size)
+  int dmt(int rows) const { return slab(rows) ? -rows : (n >= 2 ? rows : 0); }
+  int dM(int rows) const { return slab(rows) ? 8 * (n - 1) + rows : (n >= 2 ? 32 * (n - 1) + rows : rows); }
 };
 static Cohort solo_cohort(vispec_ctx* ctx) { Cohort co{}; co.n = 1; co.c[0] = ctx; return co; }
 
@@ -2009,9 +2054,10 @@ static int target_forward(const Cohort& co, hipStream_t s, int T) {
     if (a8) {
       if (l == 0 && quant(ctx->xn, D)) return -1;  // (later layers: the codes come out of the previous layer's down_proj reduce + norm)
       if (launch_qkv_rope(ctx, s, ctx->xq, D / 2, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos, false,
-                          ctx->sx))
+                          ctx->sx, co.stride == 64))
         return -1;
-    } else if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos))
+    } else if (launch_qkv_rope(ctx, s, ctx->xn, D, w.wqkv, w.bqkv, w.sqkv, ctx->qkv, T, H, Hk, D, ctx->tm.rope_cos, ctx->tm.rope_sin, rq, co.n, c.max_pos, false,
+                               nullptr, co.stride == 64))
       return -1;
     {
       AttnCall calls[MAX_COHORT];
@@ -2156,8 +2202,9 @@ static int cohort_check(vispec_ctx* const* ctxs, int n, Cohort* co) {
   vispec_ctx* a = ctxs[0];
   if (a->leader) return fail("cohort: the first ctx must be the leader (an ordinary ctx)");
   if (a->zombie) return fail("cohort: the leader was destroyed (vispec_ctx_destroy); its members can only run as single requests");
-  if (a->c.total_token > 32) return fail("cohort: every request needs a tree of <= 32 nodes (one activation tile each)");
+  if (a->c.total_token > 32 && n > 4) return fail("cohort: trees of more than 32 nodes take two activation tiles per request: at most four requests per round");
   co->n = n;
+  co->stride = a->c.total_token > 32 ? 64 : 32;
   for (int t = 0; t < MAX_COHORT; ++t) co->c[t] = nullptr;
   co->c[0] = a;
   // request t of the round sits in activation tile t: the members must own tiles 1 .. n-1 (any order of creation, no tile twice)
@@ -2266,11 +2313,11 @@ extern "C" int vispec_set_total_token(vispec_ctx* ctx, int total_token) {
   const vispec_config& c = ctx->c;
   if (total_token < 1 || total_token > TREE_MAX_T) return fail("total_token must be in [1,64]");
   if (total_token - 1 > c.top_k + c.depth * c.top_k * c.top_k) return fail("total_token larger than the candidate pool");
-  if (ctx->leader && total_token > 32) return fail("a cohort member owns one 32-row activation tile: total_token <= 32");
-  for (const vispec_ctx* m : ctx->members)
-    if (m && total_token > 32) return fail("a leader with live cohort members owns one 32-row activation tile: total_token <= 32");
+  if (ctx->leader && total_token > 32 && ctx->slot > 3)
+    return fail("trees of more than 32 nodes take two activation tiles per request: only the first four request slots of a cohort can hold them");
   ctx->c.total_token = total_token;
-  // (the tree size is part of every graph key: the captured launch sequences depend on it)
+  retarget_views(ctx);  // a member's target-side views: 32 or 64 rows per request slot (every ctx of a cohort round must agree: cohort_check)
+  // (the tree size is part of every graph key: the captured launch sequences — and the views above — depend on it)
   return 0;
 }
 extern "C" int vispec_set_rope_delta(vispec_ctx* ctx, void* stream, int delta) {

@@ -107,3 +107,55 @@ def self_launch(n, script):
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [pr.wait() for pr in procs]
     sys.exit(max(abs(rc) for rc in rcs))
+
+
+_hip_rt = None
+
+
+def _hip_runtime():
+    """The HIP runtime torch itself uses (same file -> same loaded instance)."""
+    global _hip_rt
+    if _hip_rt is None:
+        import ctypes
+        import glob
+        cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
+        for c in cands:
+            try:
+                _hip_rt = ctypes.CDLL(c)
+                break
+            except OSError:
+                continue
+        if _hip_rt is None:
+            raise RuntimeError("libamdhip64.so not found")
+    return _hip_rt
+
+
+def xcd_mask_words(lane, lanes, n_cus=256, n_xcd=8, layout=None):
+    """CU mask of lane `lane` of `lanes`: the CUs of its share of the XCDs (8 // lanes XCDs each; lanes that do not divide 8 share the last
+    XCDs round-robin).  How the bits of a HIP CU mask map to XCDs is the driver's business: `layout` "striped" = bit i is CU (i // n_xcd) of
+    XCD (i % n_xcd), "blocked" = bit i is CU (i % 32) of XCD (i // 32); $VISPEC_CU_MASK_LAYOUT overrides the default.  tools/cu_mask_probe.py
+    prints the XCC ids the masked workgroups report, i.e. which of the two this driver uses."""
+    layout = layout or os.environ.get("VISPEC_CU_MASK_LAYOUT", "blocked")
+    per = max(1, n_xcd // lanes)
+    mine = {(lane * per + j) % n_xcd for j in range(per)}
+    per_xcd = n_cus // n_xcd
+    words = [0] * ((n_cus + 31) // 32)
+    for i in range(n_cus):
+        xcd = i % n_xcd if layout == "striped" else i // per_xcd
+        if xcd in mine:
+            words[i // 32] |= 1 << (i % 32)
+    return words, sorted(mine)
+
+
+def masked_stream(device, lane, lanes):
+    """A HIP stream whose kernels only run on lane `lane`'s XCDs (hipExtStreamCreateWithCUMask), as a torch stream object."""
+    import ctypes
+    rt = _hip_runtime()
+    words, _ = xcd_mask_words(lane, lanes)
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(words)), arr)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(h.value, device=device)

@@ -435,6 +435,20 @@ class SpecModel:
         return self._finish_baseline(input_ids, st["n_ctx"], max_new_tokens)
 
 
+def _sync_tree_size(models):
+    """Every request of a cohort round needs the leader's tree size (the C library checks it): a member built before
+    `autotune_total_token()` / `spec_layer.total_tokens = ...` changed the leader's follows it here.  Trees of 33..64 nodes take two
+    activation tiles per request, so such a cohort has at most four requests (vispec_ctx_create_member / vispec_set_total_token)."""
+    lead = models[0]
+    T = lead.engine.total_token
+    if T > 32 and len(models) > 4:
+        raise ValueError(f"a cohort of {len(models)} requests with trees of {T} nodes: trees of more than 32 nodes take two activation tiles per "
+                         "request, at most four requests share a weight pass")
+    for m in models[1:]:
+        if m.engine.total_token != T:
+            m.spec_layer.total_tokens = T - 1
+
+
 @torch.no_grad()
 def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=2048, stats=None):
     """The AR baseline (gen_baseline_answer_coco_caption.py:34-133) for two to eight requests in LOCKSTEP on one weight pass: what
@@ -455,6 +469,7 @@ def baseline_generate_cohort(models, requests, max_new_tokens=512, max_steps=204
         if m.engine.leader is not lead.engine:
             raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
     budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * n
+    _sync_tree_size(models)
     prompts = [m._start_baseline(ids, None, dict(kw), mx) for m, (ids, kw), mx in zip(models, requests, budgets)]
     members = [m.engine for m in models[1:]]
     if stats is not None:
@@ -498,6 +513,7 @@ def specgenerate_cohort(models, requests, temperature=0.0, top_k=0.0, max_new_to
         if m.engine.leader is not lead.engine:
             raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
     seeds = seeds or [0] * n
+    _sync_tree_size(models)
     budgets = list(max_new_tokens) if isinstance(max_new_tokens, (list, tuple)) else [max_new_tokens] * n  # per request
     for m, (ids, kw), sd, mx in zip(models, requests, seeds, budgets):
         m._start_request(ids, None, dict(kw), temperature=temperature, top_k=top_k, seed=sd, max_new_tokens=mx, is_llama3=is_llama3)
@@ -585,6 +601,7 @@ def specgenerate_stream(models, requests, temperature=0.0, top_k=0.0, max_new_to
     for m in models[1:]:
         if m.engine.leader is not lead.engine:
             raise ValueError("models[1:] must have been built with cohort_leader=models[0]")
+    _sync_tree_size(models)
     member_engines = [m.engine for m in models[1:]]
     outs = [None] * R
     slot = [None] * n  # request index a slot is working on
