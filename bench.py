@@ -447,8 +447,6 @@ def main():
     ap.add_argument("--no-vision-in-loop", action="store_true",
                     help="start every request from its projected image features (rounds 1-4) instead of running the HF vision front-end inside the timed "
                          "specgenerate call")
-    ap.add_argument("--xcd-partition", action="store_true",
-                    help="experiment: lane l's stream is created with a CU mask of its share of the eight XCDs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-refill", action="store_true",
                     help="run a lane's requests cohort by cohort (every cohort waits for its slowest request) instead of refilling a finished "
                          "request's slot at once (continuous batching, the default)")
@@ -524,11 +522,7 @@ def main():
     sm = sms[0]
     eng = sm.engine
     K, W = args.steps, args.warmup
-    if args.xcd_partition and R >= 2:  # every lane on its own share of the XCDs: its activation blocks stay in ITS L2s (tools/cu_mask_probe.py)
-        from vispec_amd.evaluation.bench_launch import masked_stream
-        streams = [masked_stream(device, lane, R) for lane in range(R)]
-    else:
-        streams = [torch.cuda.Stream(device) for _ in range(R)]
+    streams = [torch.cuda.Stream(device) for _ in range(R)]
     from vispec_amd import parallel
     from vispec_amd.model.spec_model_ours import baseline_generate_cohort, specgenerate_cohort, specgenerate_stream
     plan, scaling = request_plan(args.requests, rank, world, R, CO, W + K)

@@ -80,7 +80,11 @@ int  vispec_ctx_create(const vispec_config* cfg, vispec_ctx** out);
    while members are alive keeps its allocations until its last member is destroyed (the members stay usable as single requests) and its
    HANDLE IS INVALID from that call on — every entry point refuses it while a member is alive, and it must not be passed anywhere (not
    even to vispec_ctx_destroy again) once the last member is gone.
-   A member is otherwise an ordinary ctx: own round state, tree, KV caches (vispec_set_kv), prefill calls. */
+   A member is otherwise an ordinary ctx: own round state, tree, KV caches (vispec_set_kv), prefill calls.
+   Tree size: with trees of up to 32 nodes a request owns ONE tile (eight requests per cohort); with 33..64 nodes (what the reference's
+   total_token = -1 autotune picks, spec_model_ours.py:179-201) it owns TWO tiles of the target-side workspaces — rows 64 slot .. of the
+   leader's — so only request slots 0..3 can hold such trees and a cohort round then serves at most four requests (2 requests: 4 tiles on
+   the wide kernel, 3 / 4 requests: 6 / 8 tiles on the cohort-8 kernel).  All contexts of one round must have the same tree size. */
 int  vispec_ctx_create_member(const vispec_config* cfg, vispec_ctx* leader, vispec_ctx** out);
 void vispec_ctx_destroy(vispec_ctx* ctx);
 int  vispec_set_target_layer(vispec_ctx*, int layer, const vispec_layer_weights*);
@@ -226,7 +230,7 @@ int vispec_draft_round(vispec_ctx*, void* stream);
    a round is bound by the HBM stream of the weights, so every GEMM is launched once on 64 activation rows (tile t = request t) and the
    weights are read once for both; trees, accept decisions, KV caches, attention and round state stay per request.  Each request keeps
    the reference's batch-1 semantics (spec_model_ours.py:247-582 per request) and produces the tokens it would produce alone, bit for
-   bit.  A request that has finished (done != 0) is frozen on the device while its partner completes.  total_token <= 32. */
+   bit.  A request that has finished (done != 0) is frozen on the device while its partner completes. */
 int vispec_cohort_verify_accept(vispec_ctx* leader, vispec_ctx* member, void* stream, int forced_accept);
 int vispec_cohort_draft_round(vispec_ctx* leader, vispec_ctx* member, void* stream);
 /* The same for n = 2..8 requests: ctxs[0] = the leader, the others its members owning activation tiles 1 .. n-1 (any order).  Five to
@@ -248,7 +252,8 @@ int vispec_cohortn_draft_round(vispec_ctx* const* ctxs, int n, void* stream);
 int vispec_set_stop_token(vispec_ctx*, void* stream, int token_id);
 /* change the tree size (nodes incl. the root, 1..64) of later rounds: what `model.spec_layer.total_tokens = total_token - 1`
    does after the total_token=-1 autotune of SpecModel.from_pretrained (spec_model_ours.py:179-201).  Trees of more than 32 nodes
-   run every verify GEMM in two 32-row passes. */
+   run every verify GEMM on two 32-row activation tiles; a cohort member then needs request slot 1..3 (see vispec_ctx_create_member),
+   and its target-side buffer views (vispec_buffer: logits, hidden_new ...) move to rows 64 slot .. of the leader's workspaces. */
 int vispec_set_total_token(vispec_ctx*, int total_token);
 /* Qwen2.5-VL: the rope_deltas cached by the prefill (modeling_qwen2_5_vl_kv.py) shift every decode position: tree verify and AR
    steps rotate at n + tree_pos + delta (utils.py:397-402; the three M-RoPE components are equal there, i.e. ordinary 1-D rotary).

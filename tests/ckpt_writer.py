@@ -119,8 +119,8 @@ def write_llava_next_dir(path, tcfg, tw, seed=0):
     tower = AutoModel.from_config(cfg.vision_config).to(torch.bfloat16)
     proj = LlavaNextMultiModalProjector(cfg).to(torch.bfloat16)
     tensors = _language_model_tensors(tw, tcfg, "language_model.model.", "language_model.lm_head.weight")
-    for k, v in tower.state_dict().items():
-        tensors["vision_tower." + k] = v.detach().cpu().contiguous()
+    for k, v in tower.state_dict().items():  # (transformers 5.x dropped the inner `vision_model.` level of CLIPVisionModel: the published files have it)
+        tensors["vision_tower." + (k if k.startswith("vision_model.") else "vision_model." + k)] = v.detach().cpu().contiguous()
     for k, v in proj.state_dict().items():
         tensors["multi_modal_projector." + k] = v.detach().cpu().contiguous()
     tensors["image_newline"] = (torch.randn(tcfg.hidden_size) * 0.02).to(torch.bfloat16)

@@ -312,8 +312,18 @@ def test_member_slots_and_cohort_shape_errors():
         sm.engine.cohort_round([m3.engine])  # a two-request round needs the member that owns tile 1
     with pytest.raises(RuntimeError, match="same member twice|tiles 1"):
         sm.engine.cohort_round([m1.engine, m1.engine])
-    with pytest.raises(RuntimeError, match="total_token <= 32"):
-        sm.engine.set_total_token(40)  # a leader with live members owns one 32-row tile
+    # trees of 33..64 nodes take two activation tiles per request (round 6): request slots 0..3 only, at most four requests per round
+    with pytest.raises(RuntimeError, match="first four request slots"):
+        _rest[0].engine.set_total_token(40)  # slot 4
+    for m in (sm, m1, m2, m3, _rest[0]):
+        m.engine.set_total_token(40 if m is not _rest[0] else 30)
+    with pytest.raises(RuntimeError, match="at most four requests per round"):
+        sm.engine.cohort_round([m1.engine, m2.engine, m3.engine, _rest[0].engine])
+    m3.engine.set_total_token(30)
+    with pytest.raises(RuntimeError, match="same tree size"):
+        sm.engine.cohort_round([m1.engine, m2.engine, m3.engine])
+    for m in (sm, m1, m2, m3):
+        m.engine.set_total_token(30)
 
 
 def test_step_api_keeps_stepping_after_done_outside_cohorts():

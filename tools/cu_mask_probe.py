@@ -59,13 +59,16 @@ def main():
         Y = [torch.empty(256, N, device=dev, dtype=torch.bfloat16) for _ in range(R)]
         Rr = [torch.randn(256, N, device=dev, dtype=torch.bfloat16) for _ in range(R)]
         res = {}
-        for mode in ("plain", "masked-striped", "masked-blocked"):
+        # "plain-shared-weights": every lane's launch `it` streams the SAME weight buffer (the lanes run the same layer in lockstep): the second
+        # to fourth reader can hit the Infinity Cache — what merging the lanes' launches would buy if HBM is what binds them
+        for mode in ("plain", "plain-shared-weights", "masked-striped", "masked-blocked"):
             os.environ["VISPEC_CU_MASK_LAYOUT"] = mode.split("-")[-1]
-            streams = [torch.cuda.Stream(dev) if mode == "plain" else masked_stream(dev, lane, R) for lane in range(R)]
+            streams = [torch.cuda.Stream(dev) if mode.startswith("plain") else masked_stream(dev, lane, R) for lane in range(R)]
+            shared = mode == "plain-shared-weights"
 
             def launch(lane, it):
-                L.check(lib.vispec_gemm_cohort(engs[lane].h, C.c_void_p(streams[lane].cuda_stream), p(X[lane]), K, p(Ws[(it * R + lane) % nbuf]), None, None,
-                                               p(Y[lane]), N, p(Rr[lane]), N, 8, 30, N, K, epi))
+                L.check(lib.vispec_gemm_cohort(engs[lane].h, C.c_void_p(streams[lane].cuda_stream), p(X[lane]), K, p(Ws[(it if shared else it * R + lane) % nbuf]),
+                                               None, None, p(Y[lane]), N, p(Rr[lane]), N, 8, 30, N, K, epi))
             for it in range(3):
                 for lane in range(R):
                     launch(lane, it)
@@ -89,7 +92,7 @@ def main():
             torch.cuda.synchronize()
             wall_ms = max(e0.elapsed_time(e) for e in ends)
             nbytes = rows * K * 2
-            res[mode] = dict(us_per_launch_per_stream=round(1e3 * wall_ms / iters, 1), weight_GBps=round(iters * R * nbytes / (wall_ms * 1e-3) / 1e9, 1))
+            res[mode] = dict(us_per_launch_per_stream=round(1e3 * wall_ms / iters, 1), weight_GBps_delivered=round(iters * R * nbytes / (wall_ms * 1e-3) / 1e9, 1))
             if wg:
                 lib.vispec_debug_wgclock_count.restype = C.c_longlong
                 n = int(lib.vispec_debug_wgclock_count())

@@ -223,6 +223,16 @@ class HFVisionFrontEnd:
 def _load(module: nn.Module, sd: dict, what: str):
     if not sd:
         raise FileNotFoundError(f"no {what} tensors in the checkpoint")
+    # The published llava-hf checkpoints carry transformers 4.x names (`vision_tower.vision_model.encoder...`); transformers 5.x builds the
+    # same CLIP tower without the inner `vision_model.` level (and a 4.x module reading a 5.x-written file is the reverse): follow the module.
+    own = list(module.state_dict().keys())
+    inner = "vision_model."
+    if own and sd:
+        has_own, has_sd = own[0].startswith(inner), next(iter(sd)).startswith(inner)
+        if has_sd and not has_own and all(k.startswith(inner) for k in sd):
+            sd = {k[len(inner):]: v for k, v in sd.items()}
+        elif has_own and not has_sd and all(k.startswith(inner) for k in own):
+            sd = {inner + k: v for k, v in sd.items()}
     missing, unexpected = module.load_state_dict(sd, strict=False)
     missing = [k for k in missing if "position_ids" not in k and "inv_freq" not in k]
     if missing or unexpected:
