@@ -61,14 +61,17 @@ def main():
         res = {}
         # "plain-shared-weights": every lane's launch `it` streams the SAME weight buffer (the lanes run the same layer in lockstep): the second
         # to fourth reader can hit the Infinity Cache — what merging the lanes' launches would buy if HBM is what binds them
-        for mode in ("plain", "plain-shared-weights", "masked-striped", "masked-blocked"):
+        # "plain-shared-x": every lane multiplies the SAME activation block (an XCD's L2 then holds one 2 MB block instead of one per lane): what the
+        # lanes' activation blocks cost each other in L2
+        modes = ("plain", "plain-shared-weights", "plain-shared-x") if os.environ.get("PROBE_MASKS", "0") == "0" else ("plain", "masked-striped", "masked-blocked")
+        for mode in modes:
             os.environ["VISPEC_CU_MASK_LAYOUT"] = mode.split("-")[-1]
             streams = [torch.cuda.Stream(dev) if mode.startswith("plain") else masked_stream(dev, lane, R) for lane in range(R)]
-            shared = mode == "plain-shared-weights"
+            shared, shared_x = mode == "plain-shared-weights", mode == "plain-shared-x"
 
             def launch(lane, it):
-                L.check(lib.vispec_gemm_cohort(engs[lane].h, C.c_void_p(streams[lane].cuda_stream), p(X[lane]), K, p(Ws[(it if shared else it * R + lane) % nbuf]),
-                                               None, None, p(Y[lane]), N, p(Rr[lane]), N, 8, 30, N, K, epi))
+                L.check(lib.vispec_gemm_cohort(engs[lane].h, C.c_void_p(streams[lane].cuda_stream), p(X[0 if shared_x else lane]), K,
+                                               p(Ws[(it if shared else it * R + lane) % nbuf]), None, None, p(Y[lane]), N, p(Rr[lane]), N, 8, 30, N, K, epi))
             for it in range(3):
                 for lane in range(R):
                     launch(lane, it)
