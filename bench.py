@@ -750,7 +750,10 @@ def main():
                             dominant_by="largest total device time (launches x average duration) among the priced kernels of this instrumented leg",
                             what=note, launches=int(d["launches"]), avg_launch_us=line["avg_launch_us"],
                             algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                            timing="device begin/end timestamps of each dispatch (hipExtLaunchKernel events) on the launch stream",
+                            timing="device begin/end timestamps of each dispatch (hipExtLaunchKernel events) on the launch stream, launches un-graphed "
+                                   "(an event pair per launch needs the direct path): the GPU idles between them, and the same kernels replayed back to "
+                                   "back from the hipGraph of the timed region measure 6-14 % longer in the rocprofv3 summaries under profiles/ "
+                                   "(c8 q|k|v 95.0 vs 87.1 us, gate|up 81.4 vs 76.8, split-K partials 44.4 vs 38.8: profiles/r06_kernel_stats_1lane_cohort8.csv)",
                             all_gemm_GBps=round(all_b / (all_ms * 1e-3) / 1e9, 1),
                             largest_bytes_gemm=dict(kernel=f"{by_bytes} ({keys.get(by_bytes, '?')})", **kernel_line(by_bytes, gemm_[by_bytes], n_req)),
                             by_kernel={k: kernel_line(k, v, n_req) for k, v in priced.items()})

@@ -1118,10 +1118,11 @@ static int launch_lstopk(vispec_ctx* ctx, hipStream_t s, const void* logits, int
     KCHK();
     return 0;
   }
-  if (V % 8 == 0 && ld % 8 == 0 && V <= 1024 * 8 * 20 && V <= row_max_v) {
+  // (rows of up to 65 536 logits: larger vocabularies take the chunked form above, which needs a ctx — the 20-values-per-thread
+  //  instantiation that used to cover them without one spilled 408 B and was unreachable from every ctx-holding caller: removed in round 6)
+  if (V % 8 == 0 && ld % 8 == 0 && V <= 1024 * 8 * 8 && V <= row_max_v) {
     if (V <= 1024 * 8 * 4) hipLaunchKernelGGL(lstk_row_kernel<4>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
-    else if (V <= 1024 * 8 * 8) hipLaunchKernelGGL(lstk_row_kernel<8>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
-    else hipLaunchKernelGGL(lstk_row_kernel<20>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
+    else hipLaunchKernelGGL(lstk_row_kernel<8>, dim3(M), dim3(1024), 0, s, (const bf16_t*)logits, ld, V, k, out_idx, out_logp);
     KCHK();
     return 0;
   }
@@ -1165,13 +1166,12 @@ static int launch_lstopk_cohort(vispec_ctx* const* x, int n, hipStream_t s, int 
     KCHK();
     return 0;
   }
-  if (n > 1 && V % 8 == 0 && V <= 1024 * 8 * 20 && V <= row_max_v && V <= chunk_min_v) {
+  if (n > 1 && V % 8 == 0 && V <= 1024 * 8 * 8 && V <= row_max_v && V <= chunk_min_v) {
     auto pr = [&](int t) { return make_pack((const bf16_t*)x[t]->dlogits, V, V, k, x[t]->top_idx, x[t]->top_logp); };
     decltype(pr(0)) a[MAX_COHORT];
     for (int t = 0; t < n; ++t) a[t] = pr(t);
     if (V <= 1024 * 8 * 4) launch_batch<lstk_row_fn<4>, 1024>(s, dim3(M), 0, a, n);
-    else if (V <= 1024 * 8 * 8) launch_batch<lstk_row_fn<8>, 1024>(s, dim3(M), 0, a, n);
-    else launch_batch<lstk_row_fn<20>, 1024>(s, dim3(M), 0, a, n);
+    else launch_batch<lstk_row_fn<8>, 1024>(s, dim3(M), 0, a, n);
     KCHK();
     return 0;
   }
