@@ -736,6 +736,27 @@ def main():
                                               f"the tree: NOT measured by this run; x2 = the guide's gfx950 correction)")
                 except Exception:
                     pass
+                # the same kernel as the committed rocprofv3 summary has it (in-graph replay of one cohort-8 / single-request lane: the durations the
+                # timed region's launches have; see `timing`): looked up, NOT measured by this run
+                in_graph = None
+                try:
+                    import csv
+                    import glob
+                    tag = "1lane_cohort8" if n_req >= 5 else ("1lane_cohort1" if n_req == 1 else None)
+                    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_stats_{tag}.csv"))) if tag and MODEL == "llava7b" else []
+                    key = keys.get(dom_)
+                    if files and key:
+                        for row in csv.DictReader(open(files[-1])):
+                            if key.replace(", ", ",") in row["Name"].replace(", ", ","):
+                                us = float(row["AverageNs"]) / 1e3
+                                b_l = d["bytes"] / d["launches"]
+                                in_graph = dict(source=f"profiles/{os.path.basename(files[-1])} (rocprofv3 --kernel-trace --stats of `bench.py --lanes 1 --cohort "
+                                                       f"{8 if n_req >= 5 else 1}`, committed with the tree)", avg_launch_us=round(us, 2),
+                                                hbm_frac=round(b_l / (us * 1e-6) / 8e12, 4),
+                                                mfma_frac=round(flops_of(dom_, d, n_req) / d["launches"] / (us * 1e-6) / 2.5e15, 4))
+                                break
+                except Exception:
+                    in_graph = None
                 # the roof that binds: the larger of the two fractions.  A cohort GEMM occupies `cus_occupied` of the chip by design (CU-time is
                 # what it costs): per occupied CU its matrix pipe is mfma_frac / cus_occupied busy.
                 bound = "mfma" if line["mfma_frac"] > line["frac"] else "hbm"
@@ -745,7 +766,7 @@ def main():
                 return dict(bound=bound, achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
                             hbm_frac=line["frac"], hbm_GBps=line["GBps"], mfma_frac=line["mfma_frac"], cus_occupied=line["cus_occupied"],
                             mfma_frac_of_occupied_cus=(round(line["mfma_frac"] / line["cus_occupied"], 4) if line["cus_occupied"] else None),
-                            traffic=traffic, traffic_source=traffic_source,
+                            traffic=traffic, traffic_source=traffic_source, in_graph=in_graph,
                             kernel=f"{dom_} ({keys.get(dom_, '?')})",
                             dominant_by="largest total device time (launches x average duration) among the priced kernels of this instrumented leg",
                             what=note, launches=int(d["launches"]), avg_launch_us=line["avg_launch_us"],

@@ -24,7 +24,8 @@ def pytest_collection_modifyitems(config, items):
     model fixture of tests/test_full_size_gpu.py is parametrised over all of them): deselected here instead of skipped inside the test."""
     keep, drop = [], []
     for it in items:
-        if it.name.startswith("test_ragged_cohort_at_full_size[") and not any(f"[{m}]" in it.name for m in ("llava7b", "qwen7b")):
+        if (it.name.startswith(("test_ragged_cohort_at_full_size[", "test_wide_tree_cohort_at_full_size["))
+                and not any(f"[{m}]" in it.name for m in ("llava7b", "qwen7b"))):
             drop.append(it)
         else:
             keep.append(it)

@@ -466,3 +466,41 @@ def test_cohort_of_eight_at_full_size(model_full):
         for m in members:
             m.engine.close()
     del members
+
+
+def test_wide_tree_cohort_at_full_size(model_full):
+    """Trees of 60 nodes (what the reference's total_token = -1 autotune may pick, spec_model_ours.py:179-201) in a cohort of FOUR at full size
+    (round 6): two activation tiles per request, eight tiles on the cohort-8 kernel, the q|k|v epilogue with per-tile row counts, 2 q-tiles per
+    head in the attention.  == the single-request runs token for token, composition-independent, speculative == AR; then back to 30 nodes."""
+    import bench
+    from vispec_amd.model.spec_model_ours import baseline_generate_cohort, specgenerate_cohort
+    sm, tcfg, name = model_full
+    assert name in ("llava7b", "qwen7b")  # (conftest.py collects this property for one LLaVA and one Qwen configuration only)
+    bench.MODEL = name
+    dev = torch.device("cuda:0")
+    reqs = [bench.make_request(tcfg, 80 + i, dev) for i in range(4)]
+    budgets = [44, 31, 52, 38]
+    members = [sm.make_cohort_member() for _ in range(3)]
+    models = [sm] + members
+    try:
+        sm.spec_layer.total_tokens = 59
+        want = [sm.specgenerate(ids, max_new_tokens=b, log=True, return_acceptance_len=True, **pix) for (ids, pix), b in zip(reqs, budgets)]
+        got = specgenerate_cohort(models, reqs, max_new_tokens=budgets)
+        assert all(m.engine.total_token == 60 for m in models)
+        rev = specgenerate_cohort(models, reqs[::-1], max_new_tokens=budgets[::-1])[::-1]
+        for t, (a, b) in enumerate(zip(got, rev)):
+            assert torch.equal(a[0], b[0]) and a[1:] == b[1:], f"{name}: request {t} depends on its cohort"
+        same = sum(int(torch.equal(g[0], w[0]) and g[1:] == (w[1], w[2], w[3])) for g, w in zip(got, want))
+        print(f"{name}: {same} of 4 wide-tree cohort requests token-for-token equal to their single-request runs; accept lengths {[round(float(np.mean(g[3])), 2) for g in got]}")
+        assert same == 4
+        ar = baseline_generate_cohort(models, reqs, max_new_tokens=budgets)
+        for t, ((toks, new_token, idx, acc), a) in enumerate(zip(got, ar)):
+            n = min(toks.shape[1], a.shape[1])
+            assert n >= reqs[t][0].shape[1] + budgets[t] and torch.equal(toks[0, :n], a[0, :n]), f"{name}: request {t}: speculative != AR"
+    finally:
+        sm.spec_layer.total_tokens = 29
+        for m in members:
+            m.engine.close()
+    out = sm.specgenerate(reqs[0][0], max_new_tokens=24, **reqs[0][1])
+    assert out.shape[1] >= reqs[0][0].shape[1] + 24
+
