@@ -34,6 +34,9 @@
 #ifndef C8_LA
 #define C8_LA 2  // groups of lookahead (-DC8_LA=3: 12 KiB of W per wave + 96 KiB of X per workgroup in flight, all 160 KiB of LDS)
 #endif
+#ifndef C8_LW
+#define C8_LW C8_LA  // groups of lookahead of the WEIGHT stream alone (registers, not LDS; round 6 experiment: -DC8_LW=3 / 4 at C8_LA = 2 keeps 12 / 16
+#endif               // KiB of weights per wave in flight against the loaded HBM latency while the activation ring, which reads L2, stays at two groups)
 #define C8_LDS_BYTES ((C8_LA + 2) * C8_BUFBYTES)  // 128 KiB (ring of LA + 1 buffers + the zero buffer): one workgroup per CU
 static_assert(C8_LDS_BYTES <= 160 * 1024, "the cohort-8 ring does not fit a CU's 160 KiB of LDS");
 
@@ -52,12 +55,17 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
   WGCLK_BEGIN();
   constexpr bool A8 = W8 == 2;
-  constexpr int NL = C8_NL, LA = C8_LA, NB = LA + 1;
+  constexpr int NL = C8_NL, LA = C8_LA, LW = C8_LW, NB = LA + 1;
   constexpr int KSTEP = A8 ? 64 : (W8 ? 32 : 16), LOADS = W8 ? 2 : 4, TPS = A8 ? 2 : 1, TL = LOADS * TPS;  // k per step, steps per group, tiles per step / group
   constexpr int GK = KSTEP * LOADS;        // k per group: 128 bytes of every activation row in all three forms
   constexpr int PPW = 4;                   // 1 KiB activation pieces a wave moves per group: the four pieces of tile `wave`
-  constexpr int QIN = LA * (TL + PPW);     // memory operations in flight per wave in steady state
-  static_assert(LA == 2 || LA == 3, "the loop below is unrolled for two or three groups of lookahead");
+  // The wave's memory queue (in order).  Group h issues D(h + LA) at its top and, after step u, W(h + LW, u).  At step u of group g the ops
+  // younger than W(g, u) are: the rest of the LW weight groups in flight (LW TL - TPS) and the LW activation groups issued since W(g, *) went
+  // out (LW PPW) -> STEP_ALLOW; at the closing barrier D(g + 1) must have landed: younger than it are the weights of LA groups and LA - 1
+  // activation groups -> BAR_ALLOW.  (LW = LA: QIN - TPS and QIN - PPW of the round-5 form, QIN = LA (TL + PPW).)
+  constexpr int STEP_ALLOW = LW * TL - TPS + LW * PPW, BAR_ALLOW = LA * TL + (LA - 1) * PPW;
+  static_assert((LA == 2 || LA == 3) && LW >= LA && LW <= 4, "the loop below is unrolled for LW = 2..4 weight groups in flight, LA = 2 or 3 ring groups");
+  static_assert(STEP_ALLOW < 64, "vmcnt is a 6-bit counter");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, hi = lane >> 5;
   // Split-K launches: the workgroups of one split read the same [256, K / S] slice of X.  Workgroups go to the XCDs round-robin by linear id
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
     const unsigned sseg = A8 ? (unsigned)(4 * (t >> 1) + 2 * (t & 1) + hi) : (W8 ? (unsigned)(4 * (t >> 1) + 2 * hi + (t & 1)) : (unsigned)(2 * t + hi));
     ro[t] = rrow + ((sseg ^ fsw) << 4);
   }
-  u32x4_t w[LA][TL];
+  u32x4_t w[LW][TL];
   uint4 xf[LOADS][NL][W8 ? 2 : 1];
 #define C8_DMA(grp, slot)                                                                                       \
   {                                                                                                             \
@@ -171,22 +179,22 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
       }                                                                                                         \
     }                                                                                                           \
   }
-  // Queue of a wave (oldest first) at the top of group g:  W(g, *), D(g+1), W(g+1, *)  — then D(g+2) is issued (QIN operations); step u needs
-  // W(g, TPS u ..): QIN - TPS younger ones may stay; after its MFMAs W(g+2, TPS u ..) is issued; the closing barrier needs D(g+1) landed:
-  // QIN - PPW younger ones may stay.  ONE code path from the first group to the last (branches around the unrolled bodies made hipcc move
+  // Queue of a wave (oldest first) at the top of group g (LW = LA = 2):  W(g, *), D(g+1), W(g+1, *)  — then D(g+2) is issued; step u needs
+  // W(g, TPS u ..): STEP_ALLOW younger ones may stay; after its MFMAs W(g+LW, TPS u ..) is issued; the closing barrier needs D(g+1) landed:
+  // BAR_ALLOW younger ones may stay.  ONE code path from the first group to the last (branches around the unrolled bodies made hipcc move
   // the accumulators through scratch): the loop runs in pairs of groups; the prefetches of the last two groups are STAND-INS — the
   // activation pieces of the last group again (L2-resident) into the free ring slot, and the workgroup's first weight tile (one 1 KiB line
   // set for all eight waves: L2 hits) — and an odd split's extra group multiplies real (finite) weight bytes by the zero buffer.
 #define C8_GROUP(SL)                                                                                            \
   {                                                                                                             \
     const bool live = gi < G;                                                                                   \
-    const bool pf_real = gi + LA < G;                                                                           \
+    const bool pf_real = gi + LW < G;                                                                           \
     const unsigned char* xb = live ? smem_w + rd * C8_BUFBYTES : smem_w + NB * C8_BUFBYTES;                     \
-    const unsigned char* wn = wsrc + (pf_real ? (long)(gi + LA) * (TL * 1024) : wstand_off);                    \
+    const unsigned char* wn = wsrc + (pf_real ? (long)(gi + LW) * (TL * 1024) : wstand_off);                    \
     C8_XREAD(0, xb)                                                                                             \
     C8_DMA(min(gi + LA, G - 1), wr)                                                                             \
-    C8_STEP(SL, 0, QIN - TPS, true) C8_STEP(SL, 1, QIN - TPS, true) C8_STEP(SL, 2, QIN - TPS, true) C8_STEP(SL, 3, QIN - TPS, true) \
-    wide_wait_barrier<QIN - PPW>();                                                                             \
+    C8_STEP(SL, 0, STEP_ALLOW, true) C8_STEP(SL, 1, STEP_ALLOW, true) C8_STEP(SL, 2, STEP_ALLOW, true) C8_STEP(SL, 3, STEP_ALLOW, true) \
+    wide_wait_barrier<BAR_ALLOW>();                                                                             \
     ++gi;                                                                                                       \
     rd = rd + 1 == NB ? 0 : rd + 1;                                                                             \
     wr = wr + 1 == NB ? 0 : wr + 1;                                                                             \
@@ -199,25 +207,23 @@ __global__ __launch_bounds__(512) void gemm_w32_c8_kernel(const bf16_t* __restri
   // stand-in weight source: tile 0 of the workgroup's first row block, every 1 KiB load at the same bytes (offsets cancelled)
   const long wstand_off = ((long)min(bx * 8, tiles - 1) - tile) * (K / KSTEP) * (TPS * 1024) - (long)g_lo * (TL * 1024);  // (relative to wsrc)
   __syncthreads();  // (the zero buffer is written; nothing else touches LDS before the first DMA lands)
-  // ---- prologue: groups 0 .. LA-1 in the steady-state order [D(0), W(0, *), D(1), W(1, *), ...]
-  C8_DMA(0, 0)
-  C8_WLOAD_ALL(0, wsrc)
-  {
-    const unsigned char* wp = wsrc + (G > 1 ? (long)(TL * 1024) : wstand_off);
-    C8_DMA(min(1, G - 1), 1)
-    C8_WLOAD_ALL(1, wp)
+  // ---- prologue: what the groups -LW .. -1 of the steady state would have issued, in their order: group h = i - LW issues D(h + LA) (if that
+  // group exists) and then W(i, *):  LW = LA = 2: [D(0), W(0), D(1), W(1)];  LW = 3, LA = 2: [W(0), D(0), W(1), D(1), W(2)]
+#define C8_PROLOGUE(i)                                                                                          \
+  if constexpr ((i) < LW) {                                                                                     \
+    if constexpr ((i) - LW + LA >= 0) C8_DMA(min(((i) - LW + LA >= 0 ? (i) - LW + LA : 0), G - 1), ((i) - LW + LA >= 0 ? (i) - LW + LA : 0)) \
+    const unsigned char* wp_ = wsrc + (G > (i) ? (long)(i) * (TL * 1024) : wstand_off);                         \
+    C8_WLOAD_ALL(((i) < LW ? (i) : 0), wp_)                                                                     \
   }
-  if constexpr (LA > 2) {
-    const unsigned char* wp = wsrc + (G > 2 ? (long)(2 * TL * 1024) : wstand_off);
-    C8_DMA(min(2, G - 1), 2)
-    C8_WLOAD_ALL((LA > 2 ? 2 : 0), wp)
-  }
-  wide_wait_barrier<QIN - PPW>();  // group 0's activations are staged
+  C8_PROLOGUE(0) C8_PROLOGUE(1) C8_PROLOGUE(2) C8_PROLOGUE(3)
+#undef C8_PROLOGUE
+  wide_wait_barrier<BAR_ALLOW>();  // group 0's activations are staged
   int rd = 0, wr = LA, gi = 0;  // ring slot read by the current group / written by the prefetch (LA ahead, mod NB)
-  while (gi < G) {
+  while (gi < G) {  // (the weight registers cycle mod LW at compile time, the ring slots mod NB at run time)
     C8_GROUP(0)
     C8_GROUP(1)
-    if constexpr (LA > 2) C8_GROUP((LA > 2 ? 2 : 0))
+    if constexpr (LW > 2) C8_GROUP((LW > 2 ? 2 : 0))
+    if constexpr (LW > 3) C8_GROUP((LW > 3 ? 3 : 0))
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stand-in fetches of the last groups (their LDS-DMAs must not outlive the workgroup)
 #undef C8_GROUP
