@@ -126,6 +126,8 @@ def main():
             wg_us=dict(mean=round(float(wg.mean()), 2), p50=pct(wg, 50), p90=pct(wg, 90), p99=pct(wg, 99)),
             span_us=dict(mean=round(float(np.mean(spans)), 2), p50=pct(spans, 50), p90=pct(spans, 90)),
             stagger_us=dict(mean=round(float(np.mean(stag)), 2), p50=pct(stag, 50), p90=pct(stag, 90)),
+            core_clock_MHz=(lambda m: dict(mean=round(float(m.mean()), 0), p10=pct(m, 10), p90=pct(m, 90)))(
+                r["p0"][r["p0"] > 0].astype(np.float64) / np.maximum(1.0, (r["t1"] - r["t0"])[r["p0"] > 0].astype(np.float64)) * 100.0) if (r["p0"] > 0).any() else None,
             cu_us_per_launch=round(float(np.mean(cus)), 1), cu_time_share_of_chip=round(cu_sum / (256.0 * span_all), 4),
             distinct_cus=int(len(np.unique((r["xcc"].astype(np.int64) << 8) | ((r["hw"] >> 8) & 0xff)))))
     out["recorded_interval_us"] = round(float(span_all), 1)
