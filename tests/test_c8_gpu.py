@@ -393,6 +393,28 @@ def test_cohorts_with_trees_of_more_than_one_tile(golden_dir, n_req, total_token
     assert back[0][3] == acc30
 
 
+def test_request_stream_with_wide_trees(golden_dir):
+    """Continuous batching over three / four slots whose requests carry 48-node trees (two activation tiles each): every request returns what it
+    returns alone; the graphs of the two-tile rounds are replayed."""
+    sm, ot, od = build(50, 60, True, arch="LlavaNextForConditionalGeneration")
+    sm.spec_layer.total_tokens = 47
+    reqs, g = make_requests(golden_dir, 9, seed=97)
+    budgets = [30, 12, 41, 8, 25, 33, 5, 19, 27]
+    want = [single(sm, *r, max_new_tokens=b) for r, b in zip(reqs, budgets)]
+    for n_slots in (3, 4):
+        models = [sm] + [sm.make_cohort_member() for _ in range(n_slots - 1)]
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            got = specgenerate_stream(models, reqs, max_new_tokens=budgets)
+            side.synchronize()
+        for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+            np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"{n_slots} slots, request {t}")
+            assert (new_token, idx, acc) == (w[1], w[2], w[3]), f"{n_slots} slots, request {t}"
+        for m in models[1:]:
+            m.engine.close()
+    assert sm.engine.graph_stats()["replays"] > 0
+
+
 def test_wide_tree_cohorts_are_at_most_four_requests():
     """Two tiles per request: a fifth request does not fit the eight tiles of a weight pass — refused loudly, by the library and by the host side."""
     sm, _, _ = build(50, 60, True)
