@@ -731,10 +731,79 @@ def g12_kvcache():
                         s2=np.array(s2), d2=d2.numpy(), idx=idx.numpy(), d3=data.numpy().copy(), len3=np.int64(int(cur)), s3=np.array(tuple(kv.shape)))
 
 
+def g18_prompts():
+    """The reference's prompt front-ends (vispec/evaluation/*_prompt.py): every `build_prompt` is run with a RECORDING processor (a stand-in
+    for transformers.AutoProcessor that stores the conversation handed to apply_chat_template and the keyword arguments of the processor call)
+    on seeded sample data; the fixture holds what each benchmark's function built — conversation, processor-construction arguments, call
+    arguments — as JSON.  Strings stand in for the images / videos (the functions only pass them through)."""
+    import importlib
+    import json
+    import types
+    from types import SimpleNamespace
+    import transformers
+
+    class Rec:
+        log = []
+
+        def __init__(self, ctor):
+            self.ctor, self.calls = ctor, []
+
+        @classmethod
+        def from_pretrained(cls, *a, **kw):
+            r = cls(dict(args=list(a), kwargs=kw))
+            cls.log.append(r)
+            return r
+
+        def apply_chat_template(self, conv, **kw):
+            self.conv, self.tmpl_kw = conv, kw
+            return "<PROMPT>"
+
+        def __call__(self, **kw):
+            self.calls.append(kw)
+            return SimpleNamespace(to=lambda dev: dict(device=dev))
+
+    qv = types.ModuleType("qwen_vl_utils")
+    qv.process_vision_info = lambda conv, return_video_kwargs=False: (None, ["<FRAMES>"], {"fps": [2.0]})
+    sys.modules["qwen_vl_utils"] = qv
+    real = transformers.AutoProcessor  # (resolving the lazy attribute may replace sys.modules["transformers"]: patch the live object)
+    transformers = sys.modules["transformers"]
+    transformers.AutoProcessor = Rec
+    out = {}
+    try:
+        data = dict(image="<IMAGE>", text="What is on the table?", question="What colour is the car?", video_name="<VIDEO>", video="<VIDEO>")
+        for task in ("coco_caption", "synthdog", "gqa", "mmbench", "mme", "seed_bench", "vqav2", "mmvet", "vizwiz", "hr_bench", "textvqa", "msvd_qa", "mvbench"):
+            mod = importlib.import_module(f"vispec.evaluation.{task}_prompt")
+            for model in ("llava-hf/llava-v1.6-vicuna-7b-hf", "Qwen/Qwen2.5-VL-7B-Instruct"):
+                Rec.log.clear()
+                ret = mod.build_prompt(dict(data), SimpleNamespace(model=model))
+                r = Rec.log[-1]
+                out[f"{task}|{model}"] = dict(ctor=r.ctor, conversation=r.conv, template_kwargs=r.tmpl_kw, call=r.calls[-1], returned=ret)
+        sqa = importlib.import_module("vispec.evaluation.scienceqa_prompt")
+        rng = np.random.default_rng(1800)
+        problems = {}
+        for q in range(5):
+            n_ch = int(rng.integers(2, 5))
+            problems[str(q)] = dict(question=f"Question number {q}?", hint="" if q % 2 else f"A hint for {q}.", caption=f"a caption {q}",
+                                    choices=[f"choice {q}.{i}" for i in range(n_ch)], answer=int(rng.integers(0, n_ch)), lecture=f"Lecture {q}.",
+                                    solution="" if q == 3 else f"Solution {q}.", image=f"<IMAGE {q}>")
+        for fmt in ("CQM-A", "QCM-LEA", "QCM-AL", "QCM-AE", "QCMLE-A", "QCLEM-A", "QCEM-A", "CQM-ELA", "QCML-AE", "QCM-ALE"):
+            for use_caption in (False, True):
+                Rec.log.clear()
+                args = SimpleNamespace(model="Qwen/Qwen2.5-VL-7B-Instruct", use_caption=use_caption, options=["A", "B", "C", "D", "E"], prompt_format=fmt)
+                ret = sqa.build_prompt(problems, ["0", "3", "1"], "4", args)
+                r = Rec.log[-1]
+                out[f"scienceqa|{fmt}|{int(use_caption)}"] = dict(ctor=r.ctor, conversation=r.conv, template_kwargs=r.tmpl_kw, call=r.calls[-1], returned=ret)
+        out["scienceqa_problems"] = problems
+    finally:
+        transformers.AutoProcessor = real
+        del sys.modules["qwen_vl_utils"]
+    json.dump(out, open(os.path.join(OUT, "g18_prompts.json"), "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     fns = dict(g14=g14_tree_levels, g1=g1_imgadaptor, g2=g2_prefill, g3=g3_decode, g4=g4_topk, g5=g5_verify, g6=g6_posterior, g7=g7_posterior_sampling,
-               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index, g16=g16_multi_image_repaired, g17=g17_multi_image_loop)
+               g8=g8_loop, g9=g9_bf16, g10=g10_qwen, g11=g11_update_inference_inputs, g12=g12_kvcache, g13=g13_real_dims, g15=g15_qwen_rope_index, g16=g16_multi_image_repaired, g17=g17_multi_image_loop, g18=g18_prompts)
     for k in which:
         print("generating", k, flush=True)
         fns[k]()

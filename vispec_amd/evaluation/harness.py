@@ -55,3 +55,18 @@ def speed(spec_file: str, baseline_file: str):
     rb, _ = rates(baseline_file)
     return {"speedup": (sum(rs) / len(rs)) / (sum(rb) / len(rb)), "tau": sum(acc) / max(1, len(acc)),
             "spec_tokens_per_s": sum(rs) / len(rs), "ar_tokens_per_s": sum(rb) / len(rb)}
+
+
+def requests_from_samples(task: str, samples, processor=None, model=None, device="cuda:0", id_key="question_id"):
+    """Benchmark samples -> the (question_id, input_ids, specgenerate kwargs) triples get_model_answers takes, through the reference's
+    prompt front-end for `task` (evaluation/prompts.py: the conversation, processor arguments and call of vispec/evaluation/<task>_prompt.py;
+    gen_spec_answer_<task>.py:160-232 feed `model_inputs` to specgenerate the same way)."""
+    from .prompts import build_prompt, make_processor
+    if processor is None:
+        processor = make_processor(model, task)
+    for i, d in enumerate(samples):
+        inputs = dict(build_prompt(task, d, processor=processor, device=device))
+        ids = inputs.pop("input_ids")
+        inputs.pop("attention_mask", None)  # (batch 1, no padding: the reference passes it on and its forward ignores it)
+        yield d.get(id_key, i), ids, inputs
+
