@@ -198,3 +198,25 @@ def test_fp8a8_cohort_of_four_equals_the_single_requests():
     for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
         np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
         assert (new_token, idx, acc) == (w[1], w[2], w[3])
+
+
+@pytest.mark.parametrize("n_req", [2, 4])
+def test_fp8a8_cohort_with_wide_trees_equals_the_single_requests(n_req):
+    """W8A8 with trees of 44 nodes inside cohorts (round 6: two activation tiles per request — the quantisation scratch, the fp8 q|k|v epilogue
+    with per-tile row counts, the split-K reduce that re-quantises the normed rows): token for token the single-request results."""
+    from vispec_amd.model.spec_model_ours import specgenerate_cohort
+    sm, ot, od, IMG = _a8_model()
+    members = [sm.make_cohort_member() for _ in range(n_req - 1)]
+    for m in members:
+        L.check(m.engine.lib.vispec_set_fp8_activations(m.engine.h, 1))
+    sm.spec_layer.total_tokens = 43
+    rng = np.random.default_rng(29)
+    reqs = [(torch.from_numpy(rng.integers(3, IMG, n))[None], {}) for n in (17, 9, 26, 12)[:n_req]]
+    budgets = [24, 30, 16, 21][:n_req]
+    want = [sm.specgenerate(ids, max_new_tokens=b, log=True, return_acceptance_len=True, **kw) for (ids, kw), b in zip(reqs, budgets)]
+    got = specgenerate_cohort([sm] + members, reqs, max_new_tokens=budgets)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    for m in members:
+        m.engine.close()
