@@ -131,6 +131,36 @@ def test_cohort_qwen_tiny_gqa_bias_mrope_and_fp8(fp8):
     assert max(max(g[3]) for g in got) >= 3
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("n_req", [2, 3])
+def test_cohort_qwen_tiny_with_wide_trees(fp8, n_req):
+    """The same Qwen2.5-VL-shaped pair with 44-node trees (two activation tiles per request, round 6): the two-kernel q|k|v + rotary path with
+    64-row request strides, GQA, rope_delta per request, W8A16 on the wide (4 tiles) and cohort-8 (6 tiles) kernels: == the single runs."""
+    from test_loop_gpu import build_qwen, build_qwen_fp8
+    sm, ot, od, IMG = build_qwen_fp8() if fp8 else build_qwen()
+    members = [sm.make_cohort_member() for _ in range(n_req - 1)]
+    sm.spec_layer.total_tokens = 43
+    Q = synth.QWEN_TINY
+    rng = np.random.default_rng(83)
+    reqs = []
+    for grids, segs in (([(1, 6, 8), (1, 4, 4)], (4, 3, 6)), ([(1, 4, 8)], (7, 5)), ([(1, 4, 4)], (9, 4)))[:n_req]:
+        parts = []
+        for gi, g3 in enumerate(grids):
+            parts += [rng.integers(3, IMG, segs[gi]), np.full(g3[1] * g3[2] // 4, IMG)]
+        parts.append(rng.integers(3, IMG, segs[-1]))
+        ids = np.concatenate(parts)
+        n_img = int((ids == IMG).sum())
+        feats = synth.bf16_grid(rng.standard_normal((n_img, Q["D"]), dtype=np.float32) * 0.05)
+        reqs.append((torch.from_numpy(ids)[None], dict(pixel_values=torch.from_numpy(feats).to(torch.bfloat16).cuda(), image_grid_thw=torch.tensor(grids))))
+    want = [single(sm, *r, max_new_tokens=24) for r in reqs]
+    got = specgenerate_cohort([sm] + members, reqs, max_new_tokens=24)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert (new_token, idx, acc) == (w[1], w[2], w[3])
+    for m in members:
+        m.engine.close()
+
+
 def test_cohort_with_sampling_uses_each_requests_seed():
     sm, ot, od = build(50, 60, True)
     mb = sm.make_cohort_member()
