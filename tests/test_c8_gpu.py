@@ -393,6 +393,22 @@ def test_cohorts_with_trees_of_more_than_one_tile(golden_dir, n_req, total_token
     assert back[0][3] == acc30
 
 
+def test_wide_tree_cohort_with_sampling_seeds():
+    """T > 0 (device sequential rejection with per-request counter-based uniforms) on 40-node trees in a cohort of three: every request's
+    stream is its single-request stream for its own seed."""
+    sm, ot, od = build(50, 60, True)
+    models = [sm] + [sm.make_cohort_member() for _ in range(2)]
+    sm.spec_layer.total_tokens = 39
+    rng = np.random.default_rng(197)
+    reqs = [(torch.from_numpy(rng.integers(3, T["V"], size=n))[None], {}) for n in (14, 19, 9)]
+    seeds = [3, 5, 7]
+    want = [sm.specgenerate(r[0], temperature=6.0, top_k=8, seed=sd, max_new_tokens=20, log=True, return_acceptance_len=True) for r, sd in zip(reqs, seeds)]
+    got = specgenerate_cohort(models, reqs, temperature=6.0, top_k=8, seeds=seeds, max_new_tokens=20)
+    for t, ((toks, new_token, idx, acc), w) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(toks[0].cpu().numpy(), w[0][0].cpu().numpy(), err_msg=f"request {t}")
+        assert acc == w[3]
+
+
 def test_request_stream_with_wide_trees(golden_dir):
     """Continuous batching over three / four slots whose requests carry 48-node trees (two activation tiles each): every request returns what it
     returns alone; the graphs of the two-tile rounds are replayed."""
